@@ -1,0 +1,154 @@
+/*
+ * libwan_hip.so -- C ABI of the MI355X (gfx950) kernels behind the Wan2.1-DiT
+ * video denoising path of VideoCoF.
+ *
+ * The reference is pure Python; it has no FFI.  Its seams are the duck-typed
+ * calls listed in SURVEY.md section 8b -- WanTransformer3DModel.forward,
+ * attention(), WanRMSNorm.forward, rope_apply_qk -- which the closed `paifuser`
+ * package monkey-patches with native code (videox_fun/models/__init__.py:43-109).
+ * Each entry point below replaces the arithmetic of one such seam and cites it
+ * (file:line relative to the reference root).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers;
+ *   - the caller owns every buffer (PyTorch caching allocator in practice); the
+ *     library keeps no state between calls except the last-error string;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and
+ *     returns without synchronising;
+ *   - bf16 tensors are `void*` to 2-byte bfloat16, fp32 tensors are `float*`;
+ *   - `ld*` are row strides in ELEMENTS; rows are contiguous in the last dim;
+ *   - return value 0 = WAN_OK, otherwise see wan_last_error().
+ */
+#ifndef WAN_HIP_H
+#define WAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAN_ABI_VERSION 1
+
+typedef enum {
+    WAN_OK = 0,
+    WAN_ERR_INVALID = 1,     /* bad shape / alignment / null pointer (Python side raises ValueError) */
+    WAN_ERR_UNSUPPORTED = 2, /* shape the kernels do not cover (RuntimeError) */
+    WAN_ERR_LAUNCH = 3       /* HIP launch failure (RuntimeError) */
+} wan_status_t;
+
+int wan_abi_version(void);
+const char* wan_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * a4  LayerNorm (no affine) + adaLN modulate, or LayerNorm with affine.
+ *     out[r,c] = bf16( LN(x[r,:])[c] * (add_one + scale[b,c]) + shift[b,c] ),  b = r / rows_per_batch
+ *     replaces: WanLayerNorm.forward + `norm(x) * (1 + e[1]) + e[0]` then `.to(dtype)`
+ *               (wan_transformer3d.py:233-243, 495-496, 507-508, 547) with add_one=1,
+ *               and norm3 = LayerNorm(affine) (wan_transformer3d.py:448-450, 504) with
+ *               add_one=0, scale=weight, shift=bias, rows_per_batch=rows.
+ *     x fp32 [rows, dim] contiguous; scale/shift fp32 [nbatch, dim]; dim % 4 == 0, dim <= 8192.
+ * ------------------------------------------------------------------------- */
+wan_status_t wan_ln_modulate(const float* x, const float* scale, const float* shift, int add_one,
+                             void* out_bf16, int64_t rows, int dim, int64_t rows_per_batch,
+                             float eps, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a5+a7  WanRMSNorm over the FULL channel dim, then 3-axis RoPE with the
+ *     VideoCoF temporal position map, in place on bf16 rows.
+ *     replaces: WanRMSNorm.forward (wan_transformer3d.py:214-230) followed by
+ *               rope_apply_qk (wan_transformer3d.py:135-211); the paifuser patch points
+ *               are models/__init__.py:78-80 (rms_norm_forward) and :85-109 (fast_rope_apply_qk).
+ *     One launch handles two tensors (q and k); pass x1 = NULL for a single tensor.
+ *     rope_cos/rope_sin: fp32 [max_pos, head_dim/2] tables (cos/sin of the angles of
+ *     rope_params, wan_transformer3d.py:44-52, 692-699); NULL = RMSNorm only (cross-attention).
+ *     Row r of the call is token  t = token_offset + (r % rows_per_batch)  of its sample;
+ *     tokens >= F*Hp*Wp are normalised but not rotated (wan_transformer3d.py:202).
+ *     mode 0: pos_t = f;  mode 1 (paired): f < f_src ? f : f - f_src;
+ *     mode 2 (CoF): f < f_src ? f+1 : (f < ground_end ? 0 : f - ground_end + 1).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int F, Hp, Wp;          /* patch grid (frames, rows, cols) */
+    int mode;               /* 0 default, 1 paired, 2 CoF */
+    int f_src;              /* frame_split_indices[b] */
+    int ground_end;         /* ground_frame_indices[b][1] (mode 2) */
+    int64_t token_offset;   /* first token of this shard (sequence parallel), else 0 */
+    int64_t rows_per_batch; /* rows per sample in this call */
+    int max_pos;            /* rows of the cos/sin tables (1024) */
+} wan_rope_params;
+
+wan_status_t wan_rmsnorm_rope(void* x0_bf16, const float* w0, void* x1_bf16, const float* w1,
+                              int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                              const float* rope_cos, const float* rope_sin,
+                              const wan_rope_params* rp, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a8/a10/a12  nn.Linear on the MFMA cores:  acc[m,n] = sum_k A[m,k] * W[n,k]   (fp32 accumulate)
+ *     replaces: nn.Linear -> cuBLAS for q/k/v/o, ffn.0/ffn.2, text_embedding, patch_embedding
+ *               (as im2col GEMM) and head.head (wan_transformer3d.py:264-267, 457-459, 662-666, 530).
+ *     A bf16 [M,K] (row stride lda), W bf16 [N,K] (nn.Linear layout, row stride ldw),
+ *     bias fp32 [N] or NULL.  K % 64 == 0, lda/ldw % 8 == 0.  M, N arbitrary (N % 4 == 0).
+ *     Epilogues:
+ *       WAN_EPI_BF16        out bf16 [M,N](ldo)  = acc + bias
+ *       WAN_EPI_GELU_BF16   out bf16             = gelu_tanh(acc + bias)     (ffn.0 + nn.GELU('tanh'))
+ *       WAN_EPI_F32         out fp32             = acc + bias
+ *       WAN_EPI_RESID_F32   out fp32 (in place)  += (acc + bias) * gate[b,n]  (gate NULL = 1):
+ *                           `x = x + y * e[2]`, `x = x + cross_attn(...)`, `x = x + y * e[5]`
+ *                           (wan_transformer3d.py:499, 504, 511); gate fp32 [nbatch, N], b = m / rows_per_batch
+ *       WAN_EPI_BF16_T      out bf16 [N, ldo] TRANSPOSED: out[n, m] = acc + bias  (V^T for the
+ *                           attention kernel; ldo >= M, ldo % 8 == 0)
+ * ------------------------------------------------------------------------- */
+typedef enum {
+    WAN_EPI_BF16 = 0,
+    WAN_EPI_GELU_BF16 = 1,
+    WAN_EPI_F32 = 2,
+    WAN_EPI_RESID_F32 = 3,
+    WAN_EPI_BF16_T = 4
+} wan_epilogue_t;
+
+wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                           void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                           const float* gate, int64_t rows_per_batch, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a9  attention(): softmax(q k^T * scale) v, non-causal, head_dim 128, bf16 in/out,
+ *     fp32 softmax and accumulation (flash-style, never materialises Lq x Lk).
+ *     replaces: attention()/flash_attention() (attention_utils.py:43-211) as called from
+ *               WanSelfAttention.forward (wan_transformer3d.py:294-299) and
+ *               WanT2VCrossAttention.forward (wan_transformer3d.py:325-330).
+ *     q   bf16 [B][Lq][H*128] (row stride ldq, sample stride q_bstride)
+ *     k   bf16 [B][Lk][H*128]
+ *     vt  bf16 [B][H*128][ldvt]  -- V TRANSPOSED: vt[h*128+d][key]; ldvt >= roundup(Lk,64),
+ *         ldvt % 8 == 0, and columns [Lk, roundup(Lk,64)) must hold finite values (zeros)
+ *     out bf16 [B][Lq][H*128]
+ *     Keys >= Lk are masked (k_lens semantics of the flash-attn branch, attention_utils.py:95-100).
+ * ------------------------------------------------------------------------- */
+wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
+                               const void* k, int64_t ldk, int64_t k_bstride,
+                               const void* vt, int64_t ldvt, int64_t vt_bstride,
+                               void* out, int64_t ldo, int64_t o_bstride,
+                               int batch, int Lq, int Lk, int num_heads, int head_dim,
+                               float softmax_scale, void* stream);
+
+/* [rows, cols] bf16 (row stride ld) -> [cols, ldt] bf16 transposed; pad columns [rows, ldt) are zeroed.
+ * Used when a caller hands attention() a row-major V (the reference's [B,L,N,D] layout). */
+wan_status_t wan_transpose_bf16(const void* in, int64_t ld, void* out_t, int64_t ldt,
+                                int64_t rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a1  patchify: latent [Cin,F,H,W] -> im2col tokens bf16 [L, Cin*pt*ph*pw], token order (f,h,w),
+ *     K index (c,pt,ph,pw) c slowest = Conv3d(k=s=patch) weight.flatten(1) order
+ *     (wan_transformer3d.py:662-663, 870-879).  in_dtype: 0 fp32, 1 bf16.
+ * a14 unpatchify: head output fp32 [L, pt*ph*pw*Cout] (c fastest) -> [Cout, F*pt, H*ph, W*pw]
+ *     (einsum 'fhwpqrc->cfphqwr', wan_transformer3d.py:1108-1131).  out_dtype: 0 fp32, 1 bf16.
+ * ------------------------------------------------------------------------- */
+wan_status_t wan_patchify(const void* latent, int in_dtype, void* tokens_bf16, int64_t ldt,
+                          int Cin, int F, int H, int W, int pt, int ph, int pw, void* stream);
+wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
+                            int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAN_HIP_H */

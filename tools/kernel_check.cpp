@@ -1,0 +1,371 @@
+// Developer harness (NOT product, NOT the parity oracle): links libwan_hip.so through its C ABI,
+// checks every kernel against naive double-precision host loops at small shapes and times the
+// hot kernels at Wan2.1 shapes with HIP events.  Avoids the 1-2 min `import torch` on a fresh box.
+//
+//   hipcc -O2 -std=c++17 tools/kernel_check.cpp -Iinclude -Lvideocof_amd -lwan_hip -Wl,-rpath,'$ORIGIN/../videocof_amd' -o tools/kernel_check
+//   tools/kernel_check [check|perf|all] [--big]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "wan_hip.h"
+
+#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define WAN(x) do { wan_status_t s_ = (x); if (s_ != WAN_OK) { printf("WAN error %d (%s) at %s:%d\n", s_, wan_last_error(), __FILE__, __LINE__); exit(3); } } while (0)
+
+typedef uint16_t bf16;
+static inline bf16 f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffff) > 0x7f800000) return 0x7fc0;
+    u += 0x7fff + ((u >> 16) & 1);
+    return (bf16)(u >> 16);
+}
+static inline float bf2f(bf16 b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+static std::mt19937 rng(1234);
+static std::vector<float> randn(size_t n, float scale = 1.f) {
+    std::normal_distribution<float> d(0.f, scale);
+    std::vector<float> v(n);
+    for (auto& x : v) x = d(rng);
+    return v;
+}
+static std::vector<bf16> to_bf(const std::vector<float>& v) { std::vector<bf16> o(v.size()); for (size_t i = 0; i < v.size(); ++i) o[i] = f2bf(v[i]); return o; }
+static std::vector<float> bf_round(const std::vector<float>& v) { std::vector<float> o(v.size()); for (size_t i = 0; i < v.size(); ++i) o[i] = bf2f(f2bf(v[i])); return o; }
+
+template <typename T> struct Dev {
+    T* p = nullptr; size_t n = 0;
+    explicit Dev(size_t n_) : n(n_) { HIP(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16))); }
+    explicit Dev(const std::vector<T>& h) : Dev(h.size()) { HIP(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice)); }
+    ~Dev() { (void)hipFree(p); }
+    std::vector<T> host() const { std::vector<T> h(n); HIP(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+    void zero() { HIP(hipMemset(p, 0, n * sizeof(T))); }
+};
+
+static int g_fail = 0;
+static void report(const char* name, double err, double tol, const char* metric = "rel_l2") {
+    const bool ok = err <= tol && err == err;
+    printf("  [%s] %-44s %s=%.3e (tol %.1e)\n", ok ? "PASS" : "FAIL", name, metric, err, tol);
+    if (!ok) ++g_fail;
+}
+static double rel_l2(const std::vector<double>& ref, const std::vector<float>& got) {
+    double num = 0, den = 0;
+    for (size_t i = 0; i < ref.size(); ++i) { double d = got[i] - ref[i]; num += d * d; den += ref[i] * ref[i]; }
+    return sqrt(num / std::max(den, 1e-300));
+}
+static std::vector<float> bf_to_f(const std::vector<bf16>& v) { std::vector<float> o(v.size()); for (size_t i = 0; i < v.size(); ++i) o[i] = bf2f(v[i]); return o; }
+
+template <typename F> static double time_ms(F&& f, int iters = 5, int warm = 2) {
+    hipEvent_t a, b; HIP(hipEventCreate(&a)); HIP(hipEventCreate(&b));
+    for (int i = 0; i < warm; ++i) f();
+    HIP(hipDeviceSynchronize());
+    HIP(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) f();
+    HIP(hipEventRecord(b, 0));
+    HIP(hipEventSynchronize(b));
+    float ms; HIP(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
+// ------------------------------------------------------------------ checks
+static void check_ln() {
+    printf("wan_ln_modulate\n");
+    for (int dim : {256, 1536, 5120}) {
+        const int rows = 37, rpb = 19;   // 2 "samples" (19 + 18 rows)
+        auto x = randn((size_t)rows * dim, 2.f); for (auto& v : x) v += 0.5f;
+        auto sc = randn(2 * dim, 0.5f), sh = randn(2 * dim, 0.5f);
+        Dev<float> dx(x), dsc(sc), dsh(sh); Dev<bf16> dout((size_t)rows * dim);
+        for (int variant = 0; variant < 3; ++variant) {
+            const bool mod = variant == 0, affine = variant == 1;
+            WAN(wan_ln_modulate(dx.p, variant == 2 ? nullptr : dsc.p, variant == 2 ? nullptr : dsh.p, mod ? 1 : 0,
+                                dout.p, rows, dim, affine ? rows : rpb, 1e-6f, nullptr));
+            HIP(hipDeviceSynchronize());
+            auto got = bf_to_f(dout.host());
+            std::vector<double> ref((size_t)rows * dim);
+            for (int r = 0; r < rows; ++r) {
+                double mu = 0, var = 0;
+                for (int c = 0; c < dim; ++c) mu += x[(size_t)r * dim + c];
+                mu /= dim;
+                for (int c = 0; c < dim; ++c) { double d = x[(size_t)r * dim + c] - mu; var += d * d; }
+                var /= dim;
+                const double rstd = 1.0 / sqrt(var + 1e-6);
+                const int b = affine ? 0 : r / rpb;
+                for (int c = 0; c < dim; ++c) {
+                    double y = (x[(size_t)r * dim + c] - mu) * rstd;
+                    if (variant != 2) y = y * ((mod ? 1.0 : 0.0) + sc[(size_t)b * dim + c]) + sh[(size_t)b * dim + c];
+                    ref[(size_t)r * dim + c] = y;
+                }
+            }
+            char nm[96]; snprintf(nm, sizeof nm, "dim=%d %s", dim, mod ? "modulate" : affine ? "affine" : "plain");
+            report(nm, rel_l2(ref, got), 4e-3);
+        }
+    }
+}
+
+static void rope_tables(int head_dim, int max_pos, std::vector<float>& c, std::vector<float>& s) {
+    const int half = head_dim / 2, d = head_dim;
+    const int dims[3] = {d - 4 * (d / 6), 2 * (d / 6), 2 * (d / 6)};
+    c.assign((size_t)max_pos * half, 0); s.assign((size_t)max_pos * half, 0);
+    int col = 0;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int i = 0; i < dims[ax] / 2; ++i, ++col) {
+            const double inv = 1.0 / pow(10000.0, (2.0 * i) / dims[ax]);
+            for (int p = 0; p < max_pos; ++p) { c[(size_t)p * half + col] = (float)cos(p * inv); s[(size_t)p * half + col] = (float)sin(p * inv); }
+        }
+}
+
+static void check_rmsnorm_rope() {
+    printf("wan_rmsnorm_rope\n");
+    const int hd = 128, maxpos = 1024;
+    std::vector<float> ct, st; rope_tables(hd, maxpos, ct, st);
+    Dev<float> dct(ct), dst(st);
+    for (int heads : {2, 12, 40}) {
+        const int dim = heads * hd;
+        const int F = 7, Hp = 3, Wp = 5, L = F * Hp * Wp;
+        const int rows = L + 3;                         // 3 pad rows: normalised, not rotated
+        const int64_t ld = 2 * dim;                     // q | k packed in one buffer
+        for (int mode = 0; mode < 4; ++mode) {          // 3 = no rope
+            auto x = bf_round(randn((size_t)rows * ld, 1.5f));
+            auto wq = randn(dim, 0.2f), wk = randn(dim, 0.2f);
+            for (auto& v : wq) v += 1.f; for (auto& v : wk) v += 1.f;
+            Dev<bf16> dx(to_bf(x)); Dev<float> dwq(wq), dwk(wk);
+            wan_rope_params rp = {F, Hp, Wp, mode % 3, 3, 4, 0, rows, maxpos};
+            WAN(wan_rmsnorm_rope(dx.p, dwq.p, dx.p + dim, dwk.p, ld, rows, dim, hd, 1e-6f,
+                                 mode == 3 ? nullptr : dct.p, mode == 3 ? nullptr : dst.p, &rp, nullptr));
+            HIP(hipDeviceSynchronize());
+            auto got = bf_to_f(dx.host());
+            std::vector<double> ref(x.size());
+            for (int r = 0; r < rows; ++r)
+                for (int which = 0; which < 2; ++which) {
+                    const float* xr = &x[(size_t)r * ld + which * dim];
+                    const float* w = which ? wk.data() : wq.data();
+                    double ss = 0; for (int c = 0; c < dim; ++c) ss += (double)xr[c] * xr[c];
+                    const double rstd = 1.0 / sqrt(ss / dim + 1e-6);
+                    const int f = r / (Hp * Wp), hh = (r / Wp) % Hp, ww = r % Wp;
+                    int pt = f;
+                    if (mode == 1) pt = f < 3 ? f : f - 3;
+                    if (mode == 2) pt = f < 3 ? f + 1 : (f < 4 ? 0 : f - 4 + 1);
+                    for (int c = 0; c < dim; c += 2) {
+                        double a = xr[c] * rstd * w[c], b = xr[c + 1] * rstd * w[c + 1];
+                        if (mode != 3 && r < L) {
+                            const int p = (c % hd) / 2;
+                            const int pos = p < 22 ? pt : (p < 43 ? hh : ww);
+                            const double cs = ct[(size_t)pos * 64 + p], sn = st[(size_t)pos * 64 + p];
+                            const double ra = a * cs - b * sn, rb = a * sn + b * cs; a = ra; b = rb;
+                        }
+                        ref[(size_t)r * ld + which * dim + c] = a; ref[(size_t)r * ld + which * dim + c + 1] = b;
+                    }
+                }
+            char nm[96]; snprintf(nm, sizeof nm, "heads=%d mode=%d", heads, mode);
+            report(nm, rel_l2(ref, got), 4e-3);
+        }
+    }
+}
+
+static void check_gemm() {
+    printf("wan_gemm_bf16\n");
+    struct Shape { int M, N, K; };
+    for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}}) {
+        const int M = sh.M, N = sh.N, K = sh.K;
+        auto A = bf_round(randn((size_t)M * K)), W = bf_round(randn((size_t)N * K, 0.1f));
+        auto bias = randn(N, 0.5f);
+        Dev<bf16> dA(to_bf(A)), dW(to_bf(W)); Dev<float> dB(bias);
+        std::vector<double> acc((size_t)M * N);
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                double s = 0;
+                for (int k = 0; k < K; ++k) s += (double)A[(size_t)m * K + k] * W[(size_t)n * K + k];
+                acc[(size_t)m * N + n] = s + bias[n];
+            }
+        char nm[96];
+        {   // bf16
+            Dev<bf16> out((size_t)M * N);
+            WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out.p, N, M, N, K, WAN_EPI_BF16, nullptr, 0, nullptr));
+            HIP(hipDeviceSynchronize());
+            snprintf(nm, sizeof nm, "%dx%dx%d bf16", M, N, K); report(nm, rel_l2(acc, bf_to_f(out.host())), 4e-3);
+        }
+        {   // gelu
+            Dev<bf16> out((size_t)M * N);
+            WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out.p, N, M, N, K, WAN_EPI_GELU_BF16, nullptr, 0, nullptr));
+            HIP(hipDeviceSynchronize());
+            std::vector<double> ref(acc.size());
+            for (size_t i = 0; i < acc.size(); ++i) { double x = acc[i]; ref[i] = 0.5 * x * (1 + tanh(0.7978845608028654 * (x + 0.044715 * x * x * x))); }
+            snprintf(nm, sizeof nm, "%dx%dx%d gelu", M, N, K); report(nm, rel_l2(ref, bf_to_f(out.host())), 4e-3);
+        }
+        {   // f32
+            Dev<float> out((size_t)M * N);
+            WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out.p, N, M, N, K, WAN_EPI_F32, nullptr, 0, nullptr));
+            HIP(hipDeviceSynchronize());
+            snprintf(nm, sizeof nm, "%dx%dx%d f32", M, N, K); report(nm, rel_l2(acc, out.host()), 1e-5);
+        }
+        {   // residual + gate, two samples
+            const int rpb = (M + 1) / 2;
+            auto x0 = randn((size_t)M * N), gate = randn(2 * N);
+            Dev<float> out(x0), dG(gate);
+            WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out.p, N, M, N, K, WAN_EPI_RESID_F32, dG.p, rpb, nullptr));
+            HIP(hipDeviceSynchronize());
+            std::vector<double> ref(acc.size());
+            for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n)
+                ref[(size_t)m * N + n] = x0[(size_t)m * N + n] + acc[(size_t)m * N + n] * gate[(size_t)(m / rpb) * N + n];
+            snprintf(nm, sizeof nm, "%dx%dx%d resid*gate", M, N, K); report(nm, rel_l2(ref, out.host()), 1e-5);
+            Dev<float> out2(x0);
+            WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out2.p, N, M, N, K, WAN_EPI_RESID_F32, nullptr, 0, nullptr));
+            HIP(hipDeviceSynchronize());
+            for (size_t i = 0; i < ref.size(); ++i) ref[i] = x0[i] + acc[i];
+            snprintf(nm, sizeof nm, "%dx%dx%d resid", M, N, K); report(nm, rel_l2(ref, out2.host()), 1e-5);
+        }
+        {   // transposed
+            const int ldo = (M + 63) / 64 * 64;
+            Dev<bf16> out((size_t)N * ldo); out.zero();
+            WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out.p, ldo, M, N, K, WAN_EPI_BF16_T, nullptr, 0, nullptr));
+            HIP(hipDeviceSynchronize());
+            auto h = bf_to_f(out.host());
+            std::vector<float> got((size_t)M * N); double padmax = 0;
+            for (int n = 0; n < N; ++n) for (int m = 0; m < ldo; ++m) {
+                if (m < M) got[(size_t)m * N + n] = h[(size_t)n * ldo + m]; else padmax = std::max(padmax, (double)fabs(h[(size_t)n * ldo + m]));
+            }
+            snprintf(nm, sizeof nm, "%dx%dx%d transposed", M, N, K); report(nm, rel_l2(acc, got), 4e-3);
+            report("   pad columns untouched", padmax, 0.0, "max_abs");
+        }
+    }
+}
+
+static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, const std::vector<float>& v,
+                     int Lq, int Lk, int H, float scale, std::vector<double>& out) {
+    const int D = 128, C = H * D;
+    out.assign((size_t)Lq * C, 0);
+    std::vector<double> s(Lk);
+    for (int h = 0; h < H; ++h)
+        for (int i = 0; i < Lq; ++i) {
+            double mx = -1e300;
+            for (int j = 0; j < Lk; ++j) {
+                double d = 0;
+                for (int c = 0; c < D; ++c) d += (double)q[(size_t)i * C + h * D + c] * k[(size_t)j * C + h * D + c];
+                s[j] = d * scale; mx = std::max(mx, s[j]);
+            }
+            double den = 0;
+            for (int j = 0; j < Lk; ++j) { s[j] = exp(s[j] - mx); den += s[j]; }
+            for (int j = 0; j < Lk; ++j) {
+                const double p = s[j] / den;
+                for (int c = 0; c < D; ++c) out[(size_t)i * C + h * D + c] += p * v[(size_t)j * C + h * D + c];
+            }
+        }
+}
+
+static void check_attn() {
+    printf("wan_attention_fwd (+ wan_transpose_bf16)\n");
+    struct Shape { int Lq, Lk, H; float qs; };
+    for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}}) {
+        const int Lq = sh.Lq, Lk = sh.Lk, H = sh.H, C = H * 128;
+        auto q = bf_round(randn((size_t)Lq * C, sh.qs)), k = bf_round(randn((size_t)Lk * C)), v = bf_round(randn((size_t)Lk * C));
+        // make V asymmetric across d and key so a transposed/permuted read cannot pass
+        for (int j = 0; j < Lk; ++j) for (int c = 0; c < C; ++c) v[(size_t)j * C + c] = bf2f(f2bf(v[(size_t)j * C + c] + 0.01f * (c % 128) - 0.003f * (j % 97)));
+        const int64_t ldvt = (Lk + 63) / 64 * 64;
+        Dev<bf16> dq(to_bf(q)), dk(to_bf(k)), dv(to_bf(v)), dvt((size_t)C * ldvt), dout((size_t)Lq * C);
+        HIP(hipMemset(dvt.p, 0xff, dvt.n * 2));   // poison: transpose must zero the pad
+        WAN(wan_transpose_bf16(dv.p, C, dvt.p, ldvt, Lk, C, nullptr));
+        const float scale = 1.f / sqrtf(128.f);
+        WAN(wan_attention_fwd(dq.p, C, 0, dk.p, C, 0, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, scale, nullptr));
+        HIP(hipDeviceSynchronize());
+        std::vector<double> ref; attn_ref(q, k, v, Lq, Lk, H, scale, ref);
+        auto got = bf_to_f(dout.host());
+        double maxabs = 0; for (size_t i = 0; i < ref.size(); ++i) maxabs = std::max(maxabs, fabs(got[i] - ref[i]));
+        char nm[96]; snprintf(nm, sizeof nm, "Lq=%d Lk=%d H=%d qscale=%.0f", Lq, Lk, H, sh.qs);
+        report(nm, rel_l2(ref, got), 6e-3);
+        report("   max abs err", maxabs, 3e-2, "max_abs");
+    }
+}
+
+static void check_layout() {
+    printf("wan_patchify / wan_unpatchify\n");
+    const int Cin = 16, F = 3, H = 8, W = 12, Fp = 3, Hp = 4, Wp = 6, L = Fp * Hp * Wp;
+    auto x = randn((size_t)Cin * F * H * W);
+    Dev<float> dx(x); Dev<bf16> tok((size_t)L * 64);
+    WAN(wan_patchify(dx.p, 0, tok.p, 64, Cin, F, H, W, 1, 2, 2, nullptr));
+    HIP(hipDeviceSynchronize());
+    auto got = bf_to_f(tok.host());
+    std::vector<double> ref((size_t)L * 64);
+    for (int f = 0; f < Fp; ++f) for (int h = 0; h < Hp; ++h) for (int w = 0; w < Wp; ++w)
+        for (int c = 0; c < Cin; ++c) for (int b = 0; b < 2; ++b) for (int d = 0; d < 2; ++d)
+            ref[(size_t)((f * Hp + h) * Wp + w) * 64 + c * 4 + b * 2 + d] = bf2f(f2bf(x[(((size_t)c * F + f) * H + 2 * h + b) * W + 2 * w + d]));
+    report("patchify fp32 in", rel_l2(ref, got), 0.0);
+    auto t = randn((size_t)L * 64);
+    Dev<float> dt(t), dout((size_t)16 * F * H * W);
+    WAN(wan_unpatchify(dt.p, 64, dout.p, 0, 16, Fp, Hp, Wp, 1, 2, 2, nullptr));
+    HIP(hipDeviceSynchronize());
+    auto g2 = dout.host();
+    std::vector<double> r2(g2.size());
+    for (int c = 0; c < 16; ++c) for (int f = 0; f < F; ++f) for (int h = 0; h < H; ++h) for (int w = 0; w < W; ++w)
+        r2[(((size_t)c * F + f) * H + h) * W + w] = t[(size_t)((f * Hp + h / 2) * Wp + w / 2) * 64 + ((h % 2) * 2 + (w % 2)) * 16 + c];
+    report("unpatchify fp32 out", rel_l2(r2, g2), 0.0);
+}
+
+// ------------------------------------------------------------------ perf
+static void perf(bool big) {
+    hipDeviceProp_t prop; HIP(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s, %d CUs, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
+    const int L = big ? 67080 : 32760;
+    {   // LN-modulate + rmsnorm/rope, 14B width
+        const int C = 5120;
+        Dev<float> x((size_t)L * C), sc(C), sh(C); Dev<bf16> o((size_t)L * C);
+        HIP(hipMemset(x.p, 0, x.n * 4)); sc.zero(); sh.zero();
+        double ms = time_ms([&] { WAN(wan_ln_modulate(x.p, sc.p, sh.p, 1, o.p, L, C, L, 1e-6f, nullptr)); });
+        printf("  ln_modulate      L=%d C=%d: %.3f ms  %.0f GB/s (6C B/row)\n", L, C, ms, 6.0 * C * L / ms / 1e6);
+        std::vector<float> ct, st; rope_tables(128, 1024, ct, st);
+        Dev<float> dct(ct), dst(st), w(C);
+        Dev<bf16> qk((size_t)L * 2 * C); qk.zero(); w.zero();
+        wan_rope_params rp = {43, 30, 52, 2, 21, 22, 0, L, 1024};
+        if (!big) { rp.F = 21; rp.mode = 0; }
+        ms = time_ms([&] { WAN(wan_rmsnorm_rope(qk.p, w.p, qk.p + C, w.p, 2 * C, L, C, 128, 1e-6f, dct.p, dst.p, &rp, nullptr)); });
+        printf("  rmsnorm_rope q+k L=%d C=%d: %.3f ms  %.0f GB/s (8C B/row)\n", L, C, ms, 8.0 * C * L / ms / 1e6);
+    }
+    struct G { int M, N, K; int epi; const char* what; };
+    std::vector<G> gs = {{L, 5120, 5120, WAN_EPI_BF16, "14B o/q proj"}, {L, 10240, 5120, WAN_EPI_BF16, "14B qk proj"},
+                         {L, 13824, 5120, WAN_EPI_GELU_BF16, "14B ffn.0+gelu"}, {L, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2+resid"},
+                         {L, 5120, 5120, WAN_EPI_BF16_T, "14B v proj (T)"}, {L, 1536, 1536, WAN_EPI_BF16, "1.3B proj"},
+                         {L, 8960, 1536, WAN_EPI_GELU_BF16, "1.3B ffn.0"}};
+    for (auto g : gs) {
+        auto hA = to_bf(randn((size_t)4096 * 64));   // fill with random data (tile the pattern)
+        Dev<bf16> A((size_t)g.M * g.K), W((size_t)g.N * g.K);
+        for (size_t off = 0; off < A.n; off += hA.size()) HIP(hipMemcpy(A.p + off, hA.data(), std::min(hA.size(), A.n - off) * 2, hipMemcpyHostToDevice));
+        for (size_t off = 0; off < W.n; off += hA.size()) HIP(hipMemcpy(W.p + off, hA.data(), std::min(hA.size(), W.n - off) * 2, hipMemcpyHostToDevice));
+        Dev<float> bias(g.N), gate(g.N); bias.zero(); gate.zero();
+        const int64_t ldo = g.epi == WAN_EPI_BF16_T ? (g.M + 63) / 64 * 64 : g.N;
+        const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
+        Dev<char> out(osz); out.zero();
+        double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
+                                                    g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
+        printf("  gemm %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
+    }
+    struct A_ { int Lq, Lk, H; const char* what; };
+    std::vector<A_> as = {{8192, 8192, 40, "self L=8k H=40"}, {L, L, big ? 40 : 12, "self full"}, {L, 512, 40, "cross Lk=512"}};
+    for (auto s : as) {
+        const int C = s.H * 128; const int64_t ldvt = (s.Lk + 63) / 64 * 64;
+        auto hq = to_bf(randn((size_t)4096 * 128));
+        Dev<bf16> q((size_t)s.Lq * C), k((size_t)s.Lk * C), vt((size_t)C * ldvt), o((size_t)s.Lq * C);
+        auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
+        fill(q); fill(k); fill(vt);
+        double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, nullptr)); }, 2, 1);
+        printf("  attn %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
+    }
+}
+
+int main(int argc, char** argv) {
+    std::string mode = argc > 1 ? argv[1] : "all";
+    bool big = false;
+    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--big")) big = true;
+    printf("libwan_hip ABI %d\n", wan_abi_version());
+    if (mode == "check" || mode == "all") {
+        check_ln(); check_rmsnorm_rope(); check_gemm(); check_attn(); check_layout();
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+    }
+    if (mode == "perf" || mode == "all") perf(big);
+    return g_fail ? 1 : 0;
+}

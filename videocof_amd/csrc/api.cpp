@@ -1,0 +1,17 @@
+// Error plumbing and ABI version of libwan_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/wan_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void wan_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* wan_last_error(void) { return g_err; }
+extern "C" int wan_abi_version(void) { return WAN_ABI_VERSION; }

@@ -1,0 +1,292 @@
+// Flash-style non-causal attention for head_dim 128 on gfx950 (the kernel that replaces the
+// flash_attn / sageattention wheels behind attention(), attention_utils.py:152-211).
+//
+// Workgroup = 8 waves x 32 query rows = 256 queries of one (batch, head); KV tiles of 64 keys are
+// streamed through a double-buffered LDS ring by LDS-DMA.  Per wave and KV tile:
+//
+//   S^T[key, q]  = K[key, :] . Q[q, :]        16 x v_mfma_f32_32x32x16_bf16  ("swapped" QK^T)
+//   online softmax in registers: lane (q = l&31, hi = l>>5) owns 32 of the 64 scores of its query
+//   O^T[d, q]   += V^T[d, key] . P^T[key, q]   16 x v_mfma_f32_32x32x16_bf16
+//
+// With the swapped product every lane owns ONE query column of S^T and of O^T, so the running
+// max / sum and the rescale of O are lane-local; the only cross-lane traffic per tile is one
+// exchange of the row max between lanes l and l^32.
+//
+// Key order: the MFMA leaves score row i = (r&3) + 8*(r>>2) + 4*hi in register r.  K rows are
+// fetched from LDS through the permutation pi (swap bits 2 and 3 of the row index), which makes
+// registers 8t..8t+7 of a lane hold the 8 CONSECUTIVE keys 16t + 8*hi .. +7 -- exactly the B-operand
+// fragment of the P.V product -- so P never moves between lanes.
+//
+// V is consumed transposed (V^T[d][key], produced by the V-projection GEMM epilogue), so both
+// MFMA operands of both products are 16-byte ds_read_b128 of k-contiguous data.
+// LDS images (LDS-DMA lands lane-linear; the swizzle is applied on the source address and mirrored
+// on the read):  K tile [64 keys][128 d]: 256-B rows, chunk' = chunk ^ (row & 15)
+//                V^T tile [128 d][64 keys]: 128-B rows, chunk' = chunk ^ ((row >> 1) & 7)
+#include "common.hpp"
+
+namespace {
+
+constexpr int kD = 128;          // head dim
+constexpr int kQPerWave = 32;
+constexpr int kWavesPerWG = 8;
+constexpr int kQPerWG = kQPerWave * kWavesPerWG;   // 256
+constexpr int kKV = 64;          // keys per tile
+constexpr int kThreads = kWavesPerWG * 64;
+constexpr int kKTileBytes = kKV * kD * 2;    // 16 KiB
+constexpr int kVTileBytes = kD * kKV * 2;    // 16 KiB
+constexpr int kStageBytes = kKTileBytes + kVTileBytes;
+constexpr int kLdsBytes = 2 * kStageBytes;   // 64 KiB
+
+struct AttnArgs {
+    const bf16_t* q; int64_t ldq, q_bs;
+    const bf16_t* k; int64_t ldk, k_bs;
+    const bf16_t* vt; int64_t ldvt, vt_bs;
+    bf16_t* o; int64_t ldo, o_bs;
+    int Lq, Lk, H;
+    float scale_log2e;    // softmax_scale * log2(e)
+};
+
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int qblk = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
+    const bf16_t* K = a.k + batch * a.k_bs + head * kD;
+    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt;
+    bf16_t* O = a.o + batch * a.o_bs + head * kD;
+
+    // ---- Q fragments: B operand of S^T = K.Q^T; lane holds Q[q][16*ks + 8*hi .. +7]
+    const int qrow = qblk * kQPerWG + wid * kQPerWave + l31;
+    const int qrow_c = min(qrow, a.Lq - 1);
+    bf16x8 qf[8];
+    {
+        const bf16_t* qp = Q + (int64_t)qrow_c * a.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+
+    // ---- LDS-DMA source addresses. Wave w copies K pieces 2w, 2w+1 (4 rows x 256 B each) and
+    //      V^T pieces 2w, 2w+1 (8 rows x 128 B each).
+    int k_row[2], k_col[2];
+    const bf16_t* v_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wid * 2 + j;
+        const int kr = p * 4 + (lane >> 4);                  // key row inside the tile
+        k_row[j] = kr;
+        k_col[j] = ((lane & 15) ^ (kr & 15)) * 8;            // logical chunk -> element offset
+        const int vr = p * 8 + (lane >> 3);                  // d row inside the tile
+        const int vc = (lane & 7) ^ ((vr >> 1) & 7);
+        v_src[j] = VT + (int64_t)vr * a.ldvt + vc * 8;
+    }
+    auto stage = [&](int buf, int kv0) {
+        char* base = smem + buf * kStageBytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kr = min(kv0 + k_row[j], a.Lk - 1);    // clamp: masked later
+            glds16(K + (int64_t)kr * a.ldk + k_col[j], base + (wid * 2 + j) * 1024);
+            glds16(v_src[j] + kv0, base + kKTileBytes + (wid * 2 + j) * 1024);
+        }
+    };
+
+    // ---- LDS read offsets
+    // K: row = 32*kt + pi(l31), logical chunk = 2*ks + hi
+    const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int k_rowoff = pi * 256;
+    const int k_sw = pi & 15;
+    // V^T: row = 32*dt + l31, logical chunk = 2*t + hi
+    const int v_rowoff = l31 * 128;
+    const int v_sw = (l31 >> 1) & 7;
+    int v_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v_off[t] = kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
+
+    f32x16 o_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+    float m_run = -INFINITY;   // running max of raw scores
+    float l_run = 0.f;         // running sum of this lane's 32-key share
+
+    const int nkv = (a.Lk + kKV - 1) / kKV;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    for (int it = 0; it < nkv; ++it) {
+        const int cur = it & 1;
+        const int kv0 = it * kKV;
+        if (it + 1 < nkv) stage(cur ^ 1, kv0 + kKV);
+        const char* sb = smem + cur * kStageBytes;
+
+        // ---- S^T = K . Q^T
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(
+                    sb + kt * 32 * 256 + k_rowoff + (((2 * ks + hi) ^ k_sw) << 4));
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        // register r of tile kt <-> key kv0 + 32*kt + 16*(r>>3) + 8*hi + (r&7)
+        if (kv0 + kKV > a.Lk) {      // ragged last tile (wave-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= a.Lk) s[kt][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (base-2)
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2e);
+        m_run = m_new;
+        const float mc = m_new * a.scale_log2e;
+        float psum = 0.f;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][8 * t2 + j], a.scale_log2e, -mc));
+                    psum += p[j];
+                }
+                u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
+                           pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+                pf[2 * kt + t2] = __builtin_bit_cast(bf16x8, w);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + dt * 32 * 128 + v_off[t]);
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t], o_acc[dt], 0, 0, 0);
+            }
+
+        __builtin_amdgcn_s_waitcnt(0);   // next tile landed + our LDS reads retired
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (q, hi) holds d = 32*dt + 8*g + 4*hi + (r&3), g = r>>2
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.Lq) {
+        bf16_t* op = O + (int64_t)qrow * a.ldo + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w = {pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv),
+                           pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv)};
+                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+            }
+    }
+}
+
+// ------------------------------------------------------------------ [rows, cols] -> [cols, ldt]
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld,
+                                                             bf16_t* __restrict__ out, int64_t ldt,
+                                                             int64_t rows, int cols) {
+    __shared__ unsigned short tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const unsigned short* src = reinterpret_cast<const unsigned short*>(in);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(out);
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        unsigned short v = 0;
+        if (r0 + r < rows && c0 + c < cols) v = src[(r0 + r) * ld + c0 + c];
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < cols && r0 + r < ldt) dst[(int64_t)(c0 + c) * ldt + r0 + r] = tile[r][c];   // pad cols get 0
+    }
+}
+
+}  // namespace
+
+extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
+                                          const void* k, int64_t ldk, int64_t k_bstride,
+                                          const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                          void* out, int64_t ldo, int64_t o_bstride,
+                                          int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                          float softmax_scale, void* stream) {
+    WAN_REQUIRE(q && k && vt && out, WAN_ERR_INVALID, "wan_attention_fwd: null tensor");
+    WAN_REQUIRE(head_dim == kD, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: head_dim=%d (only 128 is built)", head_dim);
+    WAN_REQUIRE(batch > 0 && Lq >= 0 && Lk > 0 && num_heads > 0, WAN_ERR_INVALID,
+                "wan_attention_fwd: batch=%d Lq=%d Lk=%d heads=%d", batch, Lq, Lk, num_heads);
+    const int64_t C = (int64_t)num_heads * kD;
+    WAN_REQUIRE(ldq >= C && ldk >= C && ldo >= C && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, WAN_ERR_INVALID,
+                "wan_attention_fwd: row strides (%lld,%lld,%lld) too small/misaligned for %d heads",
+                (long long)ldq, (long long)ldk, (long long)ldo, num_heads);
+    const int64_t lk_pad = ((int64_t)Lk + kKV - 1) / kKV * kKV;
+    WAN_REQUIRE(ldvt >= lk_pad && ldvt % 8 == 0, WAN_ERR_INVALID,
+                "wan_attention_fwd: ldvt=%lld must be >= roundup(Lk,64)=%lld and a multiple of 8",
+                (long long)ldvt, (long long)lk_pad);
+    WAN_REQUIRE(num_heads <= 65535 && batch <= 65535, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
+    if (Lq == 0) return WAN_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) {
+            wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.ldq = ldq; a.q_bs = q_bstride;
+    a.k = (const bf16_t*)k; a.ldk = ldk; a.k_bs = k_bstride;
+    a.vt = (const bf16_t*)vt; a.ldvt = ldvt; a.vt_bs = vt_bstride;
+    a.o = (bf16_t*)out; a.ldo = ldo; a.o_bs = o_bstride;
+    a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
+    a.scale_log2e = softmax_scale * 1.4426950408889634f;
+    dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, kLdsBytes, (hipStream_t)stream, a);
+    WAN_CHECK_LAUNCH("wan_attention_fwd");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_transpose_bf16(const void* in, int64_t ld, void* out_t, int64_t ldt,
+                                           int64_t rows, int cols, void* stream) {
+    WAN_REQUIRE(in && out_t, WAN_ERR_INVALID, "wan_transpose_bf16: null tensor");
+    WAN_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ldt >= rows, WAN_ERR_INVALID,
+                "wan_transpose_bf16: rows=%lld cols=%d ld=%lld ldt=%lld", (long long)rows, cols, (long long)ld, (long long)ldt);
+    if (ldt == 0) return WAN_OK;
+    dim3 grid((unsigned)((ldt + 63) / 64), (unsigned)((cols + 63) / 64)), block(256);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)in, ld,
+                       (bf16_t*)out_t, ldt, rows, cols);
+    WAN_CHECK_LAUNCH("wan_transpose_bf16");
+    return WAN_OK;
+}

@@ -1,0 +1,81 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, LDS-DMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/wan_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define WAN_WAVE 64
+
+// host-side error plumbing -----------------------------------------------------
+void wan_set_error(const char* fmt, ...);
+#define WAN_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            wan_set_error(__VA_ARGS__);         \
+            return (code);                      \
+        }                                       \
+    } while (0)
+#define WAN_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            wan_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return WAN_ERR_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+// device helpers ---------------------------------------------------------------
+__device__ __forceinline__ float bf16lo_to_f32(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    bf16x2 b = __builtin_convertvector(v, bf16x2);   // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned int, b);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x = NW*64; `red` is NW floats of LDS. All threads get the result.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();   // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+// async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}

@@ -1,0 +1,257 @@
+// nn.Linear on the gfx950 matrix cores:  acc[m,n] = sum_k A[m,k] * W[n,k]  (bf16 in, fp32 accumulate)
+//
+// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves (2x2), each wave 64x64 as 4x4
+// v_mfma_f32_16x16x32_bf16 tiles.  Both operands are K-contiguous ([rows][K]) so A and W tiles
+// share one LDS image: row-major [128][64] bf16 (128-byte rows, eight 16-byte chunks).
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction lands 8 rows x 128 B lane-
+// linearly, so the bank swizzle is applied to the per-lane SOURCE address and mirrored on the
+// ds_read_b128 side (physical chunk = logical chunk ^ ((row >> 1) & 7), conflict-free for the
+// 16-row MFMA fragment read).  Two LDS buffers: tile t+1 streams in while tile t is multiplied.
+//
+// MFMA operand order is chosen per epilogue so that every lane owns 4 CONSECUTIVE output elements
+// in the output's contiguous dimension:
+//   row-major epilogues:  D = mfma(Wfrag, Afrag) -> lane holds m = l&15, n = (l>>4)*4 + r
+//   transposed epilogue:  D = mfma(Afrag, Wfrag) -> lane holds n = l&15, m = (l>>4)*4 + r
+//
+// Workgroup -> tile mapping is XCD-aware: block b runs on XCD b%8 (observed, speed only); each XCD
+// walks a contiguous slab of the tile sequence ordered as 8(M) x all(N) groups so that the 64 tiles
+// resident on an XCD share 8 A-panels and 8 W-panels through its private L2.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kTileBytes = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int kStageBytes = 2 * kTileBytes;    // A + W
+constexpr int kLdsBytes = 2 * kStageBytes;     // double buffered: 64 KiB
+
+struct GemmArgs {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    const float* bias;
+    void* out; int64_t ldo;
+    const float* gate; int64_t rows_per_batch;
+    int M, N, K;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
+    // bijective XCD remap (guide T1): XCD x gets tiles [start_x, start_x + cnt_x)
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    // grouped order: 8 M-tiles x all N-tiles per group, M fastest inside the group
+    constexpr int GM = 8;
+    const int per_group = GM * g.tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * GM;
+    const int gm = min(GM, g.tiles_m - first_m);
+    const int in = t - grp * per_group;
+    tm = first_m + in % gm;
+    tn = in / gm;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
+
+    int tm, tn;
+    tile_coords(g, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+
+    // ---- staging addresses: wave `wid` DMA-copies pieces wid*4 .. wid*4+3 (8 rows each) of A and of W
+    const int srow = lane >> 3;                 // row inside an 8-row piece
+    const int spc = lane & 7;                   // physical 16-byte chunk
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wid * 4 + j) * 8 + srow;           // tile row 0..127
+        const int c = spc ^ ((row >> 1) & 7);               // logical chunk this lane must fetch
+        const int am = min(m0 + row, g.M - 1);
+        const int wn = min(n0 + row, g.N - 1);
+        a_src[j] = g.A + (int64_t)am * g.lda + c * 8;
+        w_src[j] = g.W + (int64_t)wn * g.ldw + c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * kStageBytes;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(a_src[j] + koff, base + (wid * 4 + j) * 1024);
+            glds16(w_src[j] + koff, base + kTileBytes + (wid * 4 + j) * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a tile)
+    const int frow = lane & 15;
+    const int kg = lane >> 4;                   // k-group: 8 contiguous k per lane
+    const int sw = (lane >> 1) & 7;             // == ((row >> 1) & 7) for every fragment row of this lane
+    const int off_k0 = frow * 128 + ((kg ^ sw) << 4);            // logical chunk kg      (kk = 0)
+    const int off_k1 = frow * 128 + (((kg + 4) ^ sw) << 4);      // logical chunk kg + 4  (kk = 1)
+    const int a_base = wr * 64 * 128;
+    const int w_base = kTileBytes + wc * 64 * 128;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): tile 0 landed
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * kStageBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = kk ? off_k1 : off_k0;
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * 2048 + off);
+                wf[i] = *reinterpret_cast<const bf16x8*>(sb + w_base + i * 2048 + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (kTransposed)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // next tile landed (vmcnt) + our ds_reads retired
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+    if constexpr (!kTransposed) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + l15;
+            if (m >= g.M) continue;
+            const int64_t b = g.gate ? (int64_t)m / g.rows_per_batch : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + l4;
+                if (n >= g.N) continue;      // N % 4 == 0 -> whole 4-group in or out
+                f32x4 v = acc[i][j];
+                if (g.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if constexpr (EPI == WAN_EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
+                }
+                if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
+                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)m * g.ldo + n) = o;
+                } else if constexpr (EPI == WAN_EPI_F32) {
+                    *reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {   // WAN_EPI_RESID_F32
+                    float4* p = reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n);
+                    float4 x = *p;
+                    if (g.gate) {
+                        const float4 gv = *reinterpret_cast<const float4*>(g.gate + b * g.N + n);
+                        x.x += v[0] * gv.x; x.y += v[1] * gv.y; x.z += v[2] * gv.z; x.w += v[3] * gv.w;
+                    } else {
+                        x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+                    }
+                    *p = x;
+                }
+            }
+        }
+    } else {
+        // out[n, m..m+3]: lane holds n = l&15, m = (l>>4)*4 + r
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + l15;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wr * 64 + i * 16 + l4;
+                if (m >= g.M) continue;
+                f32x4 v = acc[i][j];
+                bf16_t* p = (bf16_t*)g.out + (int64_t)n * g.ldo + m;
+                if (m + 3 < g.M) {
+                    u32x2 o = {pack_bf16x2(v[0] + bv, v[1] + bv), pack_bf16x2(v[2] + bv, v[3] + bv)};
+                    *reinterpret_cast<u32x2*>(p) = o;
+                } else {
+                    for (int r = 0; r < 4 && m + r < g.M; ++r) p[r] = (bf16_t)(v[r] + bv);
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+wan_status_t launch(const GemmArgs& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) {
+            wan_set_error("wan_gemm_bf16: cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kThreads);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, kLdsBytes, s, g);
+    WAN_CHECK_LAUNCH("wan_gemm_bf16");
+    return WAN_OK;
+}
+
+}  // namespace
+
+extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                      void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                                      const float* gate, int64_t rows_per_batch, void* stream) {
+    WAN_REQUIRE(A && W && out, WAN_ERR_INVALID, "wan_gemm_bf16: null tensor");
+    WAN_REQUIRE(M >= 0 && N > 0 && K > 0, WAN_ERR_INVALID, "wan_gemm_bf16: M=%d N=%d K=%d", M, N, K);
+    WAN_REQUIRE(K % BK == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_bf16: K=%d must be a multiple of %d", K, BK);
+    WAN_REQUIRE(N % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_bf16: N=%d must be a multiple of 4", N);
+    WAN_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, WAN_ERR_INVALID,
+                "wan_gemm_bf16: lda=%lld ldw=%lld must be multiples of 8 and >= K", (long long)lda, (long long)ldw);
+    if (epilogue == WAN_EPI_BF16_T)
+        WAN_REQUIRE(ldo >= M && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_bf16: transposed ldo=%lld < M=%d or not a multiple of 4", (long long)ldo, M);
+    else
+        WAN_REQUIRE(ldo >= N && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_bf16: ldo=%lld < N=%d or not a multiple of 4", (long long)ldo, N);
+    WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
+                "wan_gemm_bf16: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
+    if (M == 0) return WAN_OK;
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    g.M = M; g.N = N; g.K = K;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case WAN_EPI_BF16: return launch<WAN_EPI_BF16>(g, s);
+        case WAN_EPI_GELU_BF16: return launch<WAN_EPI_GELU_BF16>(g, s);
+        case WAN_EPI_F32: return launch<WAN_EPI_F32>(g, s);
+        case WAN_EPI_RESID_F32: return launch<WAN_EPI_RESID_F32>(g, s);
+        case WAN_EPI_BF16_T: return launch<WAN_EPI_BF16_T>(g, s);
+        default: wan_set_error("wan_gemm_bf16: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
+    }
+}

@@ -1,0 +1,91 @@
+// Layout glue at the two ends of the DiT: patchify (im2col of the (1,2,2) Conv3d) and unpatchify.
+// Pure data movement (HBM-bound, a few MB per forward).
+#include "common.hpp"
+
+namespace {
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void patchify_kernel(const TIn* __restrict__ x, bf16_t* __restrict__ tok,
+                                                       int64_t ldt, int Cin, int F, int H, int W,
+                                                       int pt, int ph, int pw) {
+    // one thread per output element; consecutive threads walk the K index of one token then the next token
+    const int Fp = F / pt, Hp = H / ph, Wp = W / pw;
+    const int K = Cin * pt * ph * pw;
+    const int64_t total = (int64_t)Fp * Hp * Wp * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / K;
+        int kk = (int)(i - t * K);
+        const int c = kk / (pt * ph * pw); kk -= c * pt * ph * pw;
+        const int a = kk / (ph * pw); kk -= a * ph * pw;
+        const int b = kk / pw, d = kk - b * pw;
+        const int wq = (int)(t % Wp);
+        const int hq = (int)((t / Wp) % Hp);
+        const int fq = (int)(t / ((int64_t)Wp * Hp));
+        const float v = (float)x[(((int64_t)c * F + fq * pt + a) * H + hq * ph + b) * W + wq * pw + d];
+        tok[t * ldt + (i - t * K)] = (bf16_t)v;
+    }
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ tok, int64_t ldt,
+                                                         TOut* __restrict__ out, int Cout, int Fp, int Hp, int Wp,
+                                                         int pt, int ph, int pw) {
+    // one thread per OUTPUT element (coalesced writes along W); 'fhwpqrc->cfphqwr'
+    const int F = Fp * pt, H = Hp * ph, W = Wp * pw;
+    const int64_t total = (int64_t)Cout * F * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int f = (int)(r % F); r /= F;
+        const int c = (int)r;
+        const int fq = f / pt, a = f - fq * pt;
+        const int hq = h / ph, b = h - hq * ph;
+        const int wq = w / pw, d = w - wq * pw;
+        const int64_t t = ((int64_t)fq * Hp + hq) * Wp + wq;
+        const int col = ((a * ph + b) * pw + d) * Cout + c;
+        out[i] = (TOut)tok[t * ldt + col];
+    }
+}
+
+}  // namespace
+
+extern "C" wan_status_t wan_patchify(const void* latent, int in_dtype, void* tokens_bf16, int64_t ldt,
+                                     int Cin, int F, int H, int W, int pt, int ph, int pw, void* stream) {
+    WAN_REQUIRE(latent && tokens_bf16, WAN_ERR_INVALID, "wan_patchify: null tensor");
+    WAN_REQUIRE(Cin > 0 && F > 0 && H > 0 && W > 0 && pt > 0 && ph > 0 && pw > 0, WAN_ERR_INVALID, "wan_patchify: bad shape");
+    WAN_REQUIRE(F % pt == 0 && H % ph == 0 && W % pw == 0, WAN_ERR_INVALID,
+                "wan_patchify: (%d,%d,%d) not divisible by patch (%d,%d,%d)", F, H, W, pt, ph, pw);
+    WAN_REQUIRE(ldt >= (int64_t)Cin * pt * ph * pw, WAN_ERR_INVALID, "wan_patchify: ldt too small");
+    WAN_REQUIRE(in_dtype == 0 || in_dtype == 1, WAN_ERR_INVALID, "wan_patchify: in_dtype=%d", in_dtype);
+    const int64_t total = (int64_t)Cin * F * H * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == 0)
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)latent,
+                           (bf16_t*)tokens_bf16, ldt, Cin, F, H, W, pt, ph, pw);
+    else
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)latent,
+                           (bf16_t*)tokens_bf16, ldt, Cin, F, H, W, pt, ph, pw);
+    WAN_CHECK_LAUNCH("wan_patchify");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
+                                       int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, void* stream) {
+    WAN_REQUIRE(tokens && out, WAN_ERR_INVALID, "wan_unpatchify: null tensor");
+    WAN_REQUIRE(Cout > 0 && F > 0 && Hp > 0 && Wp > 0 && pt > 0 && ph > 0 && pw > 0, WAN_ERR_INVALID, "wan_unpatchify: bad shape");
+    WAN_REQUIRE(ldt >= (int64_t)Cout * pt * ph * pw, WAN_ERR_INVALID, "wan_unpatchify: ldt too small");
+    WAN_REQUIRE(out_dtype == 0 || out_dtype == 1, WAN_ERR_INVALID, "wan_unpatchify: out_dtype=%d", out_dtype);
+    const int64_t total = (int64_t)Cout * F * pt * Hp * ph * Wp * pw;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(unpatchify_kernel<float>, dim3(blocks), dim3(256), 0, s, tokens, ldt, (float*)out,
+                           Cout, F, Hp, Wp, pt, ph, pw);
+    else
+        hipLaunchKernelGGL(unpatchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, tokens, ldt, (bf16_t*)out,
+                           Cout, F, Hp, Wp, pt, ph, pw);
+    WAN_CHECK_LAUNCH("wan_unpatchify");
+    return WAN_OK;
+}

@@ -1,0 +1,208 @@
+// HBM-bound row kernels of the DiT block:
+//   wan_ln_modulate  : LayerNorm (fp32 in) -> * (add_one + scale) + shift -> bf16
+//   wan_rmsnorm_rope : RMSNorm over the full channel dim + 3-axis RoPE (CoF positions), in place on bf16
+// One 256-thread workgroup per token row; the row lives in registers between the
+// reduction and the write, so each element is read once and written once
+// (algorithmic bytes: 6*C per row for LN-modulate, 4*C per row per tensor for RMSNorm+RoPE).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// ------------------------------------------------------------------ LN + modulate
+template <int NV>   // float4 per thread
+__global__ __launch_bounds__(kThreads) void ln_modulate_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    float add_one, bf16_t* __restrict__ out, int dim, int64_t rows_per_batch, float eps) {
+    __shared__ float red[kWaves];
+    const int64_t row = blockIdx.x;
+    const int64_t b = row / rows_per_batch;
+    const int nvec = dim >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * (int64_t)dim);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nvec) {
+            v[i] = xr[idx];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = block_sum<kWaves>(s, red) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nvec) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(block_sum<kWaves>(q, red) / (float)dim + eps);
+    const float4* sc = scale ? reinterpret_cast<const float4*>(scale + b * dim) : nullptr;
+    const float4* sh = shift ? reinterpret_cast<const float4*>(shift + b * dim) : nullptr;
+    u32x2* orow = reinterpret_cast<u32x2*>(out + row * (int64_t)dim);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nvec) {
+            float4 a = make_float4(add_one, add_one, add_one, add_one);
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sc) { const float4 t = sc[idx]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+            else if (add_one == 0.f) { a = make_float4(1.f, 1.f, 1.f, 1.f); }
+            if (sh) c = sh[idx];
+            const float y0 = (v[i].x - mean) * rstd * a.x + c.x;
+            const float y1 = (v[i].y - mean) * rstd * a.y + c.y;
+            const float y2 = (v[i].z - mean) * rstd * a.z + c.z;
+            const float y3 = (v[i].w - mean) * rstd * a.w + c.w;
+            u32x2 o = {pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
+            orow[idx] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RMSNorm + RoPE
+struct RopeDev {
+    int F, Hp, Wp, mode, f_src, ground_end, max_pos;
+    int ct, ch;                 // complex pairs on the t and h axes (rest = w)
+    int64_t token_offset, rows_per_batch;
+};
+
+template <int NV>   // 16-byte chunks (8 bf16) per thread
+__global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
+    bf16_t* __restrict__ x0, const float* __restrict__ w0, bf16_t* __restrict__ x1,
+    const float* __restrict__ w1, int64_t ld, int dim, int head_dim, float eps,
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp) {
+    __shared__ float red[kWaves];
+    __shared__ __attribute__((aligned(16))) float2 cs[128];   // (cos, sin) of this token's head_dim/2 pairs
+    const int64_t row = blockIdx.x;
+    bf16_t* xb = blockIdx.y == 0 ? x0 : x1;
+    const float* w = blockIdx.y == 0 ? w0 : w1;
+    u32x4* xr = reinterpret_cast<u32x4*>(xb + row * ld);
+    const int nchunk = dim >> 3;
+    const int half = head_dim >> 1;
+
+    bool rotate = rope_cos != nullptr;
+    if (rotate) {
+        const int64_t tok = rp.token_offset + (row % rp.rows_per_batch);
+        const int64_t hw = (int64_t)rp.Hp * rp.Wp;
+        rotate = tok < (int64_t)rp.F * hw;                 // rows past the grid pass through (:202)
+        if (rotate && threadIdx.x < half) {
+            const int f = (int)(tok / hw);
+            const int rem = (int)(tok - (int64_t)f * hw);
+            const int hh = rem / rp.Wp, ww = rem - hh * rp.Wp;
+            int pt = f;                                     // default 0..F-1 (:191)
+            if (rp.mode == 1) pt = f < rp.f_src ? f : f - rp.f_src;                    // paired (:183-188)
+            else if (rp.mode == 2)                                                     // CoF (:160-179)
+                pt = f < rp.f_src ? f + 1 : (f < rp.ground_end ? 0 : f - rp.ground_end + 1);
+            const int p = threadIdx.x;
+            int pos = p < rp.ct ? pt : (p < rp.ct + rp.ch ? hh : ww);
+            pos = pos < rp.max_pos ? pos : rp.max_pos - 1;
+            cs[p] = make_float2(rope_cos[(int64_t)pos * half + p], rope_sin[(int64_t)pos * half + p]);
+        }
+    }
+
+    u32x4 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nchunk) {
+            v[i] = xr[idx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf16lo_to_f32(v[i][j]), b = bf16hi_to_f32(v[i][j]);
+                ss += a * a + b * b;
+            }
+        }
+    }
+    const float rstd = rsqrtf(block_sum<kWaves>(ss, red) / (float)dim + eps);   // also orders cs[] writes
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nchunk) {
+            const float4 wa = reinterpret_cast<const float4*>(w)[idx * 2];
+            const float4 wb = reinterpret_cast<const float4*>(w)[idx * 2 + 1];
+            const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            const int p0 = ((idx << 3) % head_dim) >> 1;    // first complex pair of this chunk within its head
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = bf16lo_to_f32(v[i][j]) * rstd * wv[2 * j];
+                float b = bf16hi_to_f32(v[i][j]) * rstd * wv[2 * j + 1];
+                if (rotate) {
+                    const float2 c = cs[p0 + j];
+                    const float ra = a * c.x - b * c.y;
+                    const float rb = a * c.y + b * c.x;
+                    a = ra; b = rb;
+                }
+                o[j] = pack_bf16x2(a, b);
+            }
+            xr[idx] = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" wan_status_t wan_ln_modulate(const float* x, const float* scale, const float* shift, int add_one,
+                                        void* out_bf16, int64_t rows, int dim, int64_t rows_per_batch,
+                                        float eps, void* stream) {
+    WAN_REQUIRE(x && out_bf16, WAN_ERR_INVALID, "wan_ln_modulate: null tensor");
+    WAN_REQUIRE(dim > 0 && dim % 4 == 0, WAN_ERR_INVALID, "wan_ln_modulate: dim=%d must be a multiple of 4", dim);
+    WAN_REQUIRE(dim <= 8192, WAN_ERR_UNSUPPORTED, "wan_ln_modulate: dim=%d > 8192", dim);
+    WAN_REQUIRE(rows >= 0 && rows_per_batch > 0, WAN_ERR_INVALID, "wan_ln_modulate: rows=%lld rows_per_batch=%lld",
+                (long long)rows, (long long)rows_per_batch);
+    if (rows == 0) return WAN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (dim / 4 + kThreads - 1) / kThreads;
+    dim3 grid((unsigned)rows), block(kThreads);
+    bf16_t* out = (bf16_t*)out_bf16;
+    const float ao = add_one ? 1.f : 0.f;
+#define LN_CASE(N) case N: hipLaunchKernelGGL(ln_modulate_kernel<N>, grid, block, 0, s, x, scale, shift, ao, out, dim, rows_per_batch, eps); break;
+    switch (nv) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
+#undef LN_CASE
+    WAN_CHECK_LAUNCH("wan_ln_modulate");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_rmsnorm_rope(void* x0, const float* w0, void* x1, const float* w1,
+                                         int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                         const float* rope_cos, const float* rope_sin,
+                                         const wan_rope_params* rp, void* stream) {
+    WAN_REQUIRE(x0 && w0, WAN_ERR_INVALID, "wan_rmsnorm_rope: null tensor");
+    WAN_REQUIRE((x1 == nullptr) == (w1 == nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope: x1/w1 must both be set or both NULL");
+    WAN_REQUIRE(dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= dim, WAN_ERR_INVALID,
+                "wan_rmsnorm_rope: dim=%d ld=%lld must be multiples of 8, ld >= dim", dim, (long long)ld);
+    WAN_REQUIRE(dim <= 8192, WAN_ERR_UNSUPPORTED, "wan_rmsnorm_rope: dim=%d > 8192", dim);
+    WAN_REQUIRE(head_dim > 0 && head_dim % 8 == 0 && head_dim <= 256 && dim % head_dim == 0, WAN_ERR_INVALID,
+                "wan_rmsnorm_rope: head_dim=%d invalid for dim=%d", head_dim, dim);
+    WAN_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope: cos/sin mismatch");
+    RopeDev d = {};
+    d.rows_per_batch = rows > 0 ? rows : 1;
+    if (rope_cos) {
+        WAN_REQUIRE(rp != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope: rope tables given without wan_rope_params");
+        WAN_REQUIRE(rp->F > 0 && rp->Hp > 0 && rp->Wp > 0 && rp->max_pos > 0 && rp->rows_per_batch > 0,
+                    WAN_ERR_INVALID, "wan_rmsnorm_rope: bad grid (%d,%d,%d)", rp->F, rp->Hp, rp->Wp);
+        WAN_REQUIRE(rp->mode >= 0 && rp->mode <= 2, WAN_ERR_INVALID, "wan_rmsnorm_rope: mode=%d", rp->mode);
+        d.F = rp->F; d.Hp = rp->Hp; d.Wp = rp->Wp; d.mode = rp->mode; d.f_src = rp->f_src;
+        d.ground_end = rp->ground_end; d.max_pos = rp->max_pos;
+        d.token_offset = rp->token_offset; d.rows_per_batch = rp->rows_per_batch;
+        const int c = head_dim / 2;                 // split (c - 2*(c/3), c/3, c/3)  wan_transformer3d.py:141
+        d.ct = c - 2 * (c / 3); d.ch = c / 3;
+    }
+    if (rows == 0) return WAN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (dim / 8 + kThreads - 1) / kThreads;
+    dim3 grid((unsigned)rows, x1 ? 2 : 1), block(kThreads);
+#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d); break;
+    switch (nv) { RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) }
+#undef RR_CASE
+    WAN_CHECK_LAUNCH("wan_rmsnorm_rope");
+    return WAN_OK;
+}
