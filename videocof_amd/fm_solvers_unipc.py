@@ -1,0 +1,206 @@
+"""Flow-matching UniPC multistep sampler (host PyTorch, as north_star prescribes).
+
+Same contract as ``FlowUniPCMultistepScheduler`` of
+``videox_fun/utils/fm_solvers_unipc.py`` (diffusers ``SchedulerMixin`` style):
+``set_timesteps(n, device=, shift=)``, ``.timesteps`` (int64, truncated,
+:208-211), ``.sigmas``, ``.order``, ``step(model_output, timestep, sample,
+return_dict=False)[0]``, ``scale_model_input``.  Supported configuration is the one
+the VideoCoF entry points build (fast_infer.py:328-337): ``flow_prediction``,
+``predict_x0``, ``solver_type='bh2'``, ``solver_order`` 1..3, ``lower_order_final``.
+
+Own formulation: every UniP / UniC update is a linear combination of at most four
+tensors, so the per-step scalar algebra (:378-470, :520-612) is done once in
+float64 on the host and each update is applied in one fused fp32 pass
+(``torch.add``-chains on the device, no host sync), instead of the reference's
+~20 small bf16 elementwise launches.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+__all__ = ["FlowUniPCMultistepScheduler"]
+
+
+class SchedulerOutput:
+    def __init__(self, prev_sample):
+        self.prev_sample = prev_sample
+
+
+def _lam(sigma: float) -> float:
+    """lambda = log(alpha) - log(sigma) with alpha = 1 - sigma (:272-273, 386-387)."""
+    if sigma <= 0.0:
+        return math.inf
+    return math.log1p(-sigma) - math.log(sigma) if sigma < 1.0 else -math.inf
+
+
+class FlowUniPCMultistepScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2,
+                 prediction_type: str = "flow_prediction", shift: Optional[float] = 1.0,
+                 use_dynamic_shifting: bool = False, thresholding: bool = False,
+                 dynamic_thresholding_ratio: float = 0.995, sample_max_value: float = 1.0,
+                 predict_x0: bool = True, solver_type: str = "bh2", lower_order_final: bool = True,
+                 disable_corrector: List[int] = [], solver_p=None, timestep_spacing: str = "linspace",
+                 steps_offset: int = 0, final_sigmas_type: Optional[str] = "zero"):
+        if solver_type in ("midpoint", "heun", "logrho"):
+            solver_type = "bh2"                                                  # :97-99
+        if solver_type != "bh2" or prediction_type != "flow_prediction" or not predict_x0:
+            raise NotImplementedError("only flow_prediction / predict_x0 / bh2 is built (fast_infer.py:328-337)")
+        if use_dynamic_shifting or thresholding or solver_p is not None or final_sigmas_type != "zero":
+            raise NotImplementedError("dynamic shifting / thresholding / solver_p / sigma_min are not on the VideoCoF path")
+        self.config = type("Config", (), dict(
+            num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type,
+            shift=shift, use_dynamic_shifting=False, thresholding=False, predict_x0=True, solver_type="bh2",
+            lower_order_final=lower_order_final, final_sigmas_type="zero"))()
+        self.predict_x0 = True
+        self.disable_corrector = list(disable_corrector)
+        alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
+        sig = torch.from_numpy(1.0 - alphas).to(torch.float32)
+        sig = shift * sig / (1 + (shift - 1) * sig)                              # :113-116
+        self.sigmas = sig
+        self.timesteps = sig * num_train_timesteps
+        self.sigma_min, self.sigma_max = self.sigmas[-1].item(), self.sigmas[0].item()
+        self.num_inference_steps = None
+        self._reset()
+
+    def _reset(self):
+        self.model_outputs: List[Optional[torch.Tensor]] = [None] * self.config.solver_order
+        self.timestep_list = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self.this_order = None
+        self._step_index = None
+        self._begin_index = None
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    @property
+    def begin_index(self):
+        return self._begin_index
+
+    def set_begin_index(self, begin_index: int = 0):
+        self._begin_index = begin_index
+
+    def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None,
+                      sigmas: Optional[List[float]] = None, mu=None, shift: Optional[float] = None):
+        if sigmas is None:
+            sigmas = np.linspace(self.sigma_max, self.sigma_min, num_inference_steps + 1).copy()[:-1]   # :185-188
+        sigmas = np.asarray(sigmas, dtype=np.float64)
+        if shift is None:
+            shift = self.config.shift
+        sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)                     # :195-196
+        timesteps = sigmas * self.config.num_train_timesteps
+        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [0.0]]).astype(np.float32))   # stays on the host
+        self.timesteps = torch.from_numpy(timesteps).to(device=device, dtype=torch.int64)    # truncation (:210-211)
+        self.num_inference_steps = len(timesteps)
+        self._reset()
+
+    def scale_model_input(self, sample: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        return sample
+
+    # ------------------------------------------------------------------ scalar algebra (float64, host)
+    def _coeffs(self, i_t: int, i_s0: int, i_prev: Optional[int], order: int, corrector: bool):
+        """Return (a, b0, b_prev, b_new): x_t = a*x + b0*m0 + b_prev*m_prev + b_new*m_new
+        for a step from sigma[i_s0] to sigma[i_t] (m_prev at sigma[i_prev])."""
+        s = self.sigmas.double()
+        sigma_t, sigma_s0 = s[i_t].item(), s[i_s0].item()
+        alpha_t = 1.0 - sigma_t
+        h = _lam(sigma_t) - _lam(sigma_s0)
+        hh = -h
+        h_phi_1 = math.expm1(hh) if hh > -math.inf else -1.0
+        B_h = h_phi_1                                                             # bh2 (:407-408)
+        a = sigma_t / sigma_s0
+        b0 = -alpha_t * h_phi_1
+        rhos: List[float] = []
+        rk = None
+        if order >= 2:
+            rk = (_lam(s[i_prev].item()) - _lam(sigma_s0)) / h
+        if not corrector:
+            if order == 2:
+                rhos = [0.5]                                                      # :437-438
+            elif order > 2:
+                raise NotImplementedError("solver_order > 2")
+        else:
+            if order == 1:
+                rhos = [0.5]                                                      # :597-598
+            else:
+                rks = np.array([rk, 1.0])
+                R, bvec = [], []
+                h_phi_k = h_phi_1 / hh - 1.0
+                fact = 1
+                for i in range(1, order + 1):
+                    R.append(rks ** (i - 1))
+                    bvec.append(h_phi_k * fact / B_h)
+                    fact *= i + 1
+                    h_phi_k = h_phi_k / hh - 1.0 / fact
+                rhos = list(np.linalg.solve(np.stack(R), np.array(bvec)))          # :600
+        k = -alpha_t * B_h
+        b_prev = b_new = 0.0
+        if not corrector:
+            if order == 2:
+                b_prev = k * rhos[0] / rk
+                b0 -= b_prev
+        else:
+            if order == 1:
+                b_new = k * rhos[0]
+                b0 -= b_new
+            else:
+                b_prev = k * rhos[0] / rk
+                b_new = k * rhos[1]
+                b0 -= b_prev + b_new
+        return a, b0, b_prev, b_new
+
+    @staticmethod
+    def _combine(dtype, terms: List[Tuple[float, Optional[torch.Tensor]]]) -> torch.Tensor:
+        acc = None
+        for c, ten in terms:
+            if ten is None or c == 0.0:
+                continue
+            acc = ten.float() * c if acc is None else acc.add_(ten.float(), alpha=c)
+        return acc.to(dtype)
+
+    # ------------------------------------------------------------------ step
+    def index_for_timestep(self, timestep):
+        idx = (self.timesteps == timestep).nonzero()
+        return idx[1 if len(idx) > 1 else 0].item()
+
+    def step(self, model_output: torch.Tensor, timestep: Union[int, torch.Tensor], sample: torch.Tensor,
+             return_dict: bool = True, generator=None):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self._step_index is None:
+            self._step_index = self._begin_index if self._begin_index is not None else self.index_for_timestep(
+                timestep.to(self.timesteps.device) if torch.is_tensor(timestep) else timestep)
+        i = self._step_index
+        sig_i = float(self.sigmas[i])
+        x0 = self._combine(sample.dtype, [(1.0, sample), (-sig_i, model_output)])      # convert_model_output :318-320
+        use_corrector = i > 0 and (i - 1) not in self.disable_corrector and self.last_sample is not None
+        if use_corrector:
+            a, b0, bp, bn = self._coeffs(i, i - 1, i - 2 if self.this_order >= 2 else None, self.this_order, True)
+            sample = self._combine(sample.dtype, [(a, self.last_sample), (b0, self.model_outputs[-1]),
+                                                  (bp, self.model_outputs[-2]), (bn, x0)])
+        self.model_outputs = self.model_outputs[1:] + [x0]
+        self.timestep_list = self.timestep_list[1:] + [timestep]
+        if self.config.lower_order_final:
+            this_order = min(self.config.solver_order, len(self.timesteps) - i)                    # :713-716
+        else:
+            this_order = self.config.solver_order
+        self.this_order = min(this_order, self.lower_order_nums + 1)                               # :720
+        assert self.this_order > 0
+        self.last_sample = sample
+        a, b0, bp, _ = self._coeffs(i + 1, i, i - 1 if self.this_order >= 2 else None, self.this_order, False)
+        prev_sample = self._combine(sample.dtype, [(a, sample), (b0, x0),
+                                                   (bp, self.model_outputs[-2] if self.this_order >= 2 else None)])
+        if self.lower_order_nums < self.config.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        if not return_dict:
+            return (prev_sample,)
+        return SchedulerOutput(prev_sample=prev_sample)

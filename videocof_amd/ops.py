@@ -1,0 +1,219 @@
+"""Torch-tensor front end of the C ABI (``include/wan_hip.h``).
+
+Every function takes CUDA(HIP) tensors, validates dtype/layout, and enqueues the
+kernel on torch's current stream.  Nothing here computes on the host and nothing
+falls back to eager PyTorch: a CPU tensor raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import RopeParams
+
+EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32, EPI_BF16_T = (
+    _lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_F32, _lib.EPI_RESID_F32, _lib.EPI_BF16_T)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------
+def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+                add_one: bool, rows_per_batch: int, eps: float,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x fp32 [rows, dim]; scale/shift fp32 [nbatch, dim] or None -> bf16 [rows, dim]."""
+    _need(x, torch.float32, "ln_modulate.x")
+    if not x.is_contiguous() or x.dim() != 2:
+        raise ValueError("ln_modulate.x must be a contiguous [rows, dim] tensor")
+    rows, dim = x.shape
+    for nm, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _need(t, torch.float32, "ln_modulate." + nm)
+            if not t.is_contiguous() or t.shape[-1] != dim or t.numel() * rows_per_batch < rows * dim:
+                raise ValueError(f"ln_modulate.{nm}: shape {tuple(t.shape)} does not cover {rows} rows of {dim}")
+    if out is None:
+        out = torch.empty(rows, dim, device=x.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "ln_modulate.out")
+    lib = _lib.load()
+    _lib.check(lib.wan_ln_modulate(_p(x), _p(scale), _p(shift), int(bool(add_one)), _p(out), rows, dim,
+                                   int(rows_per_batch), float(eps), _stream()), "wan_ln_modulate")
+    return out
+
+
+def rmsnorm_rope_(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor], w1: Optional[torch.Tensor],
+                  head_dim: int, eps: float, rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                  rope_params: Optional[RopeParams] = None) -> None:
+    """In-place RMSNorm(+RoPE) of one or two bf16 [rows, dim] views sharing a row stride."""
+    _need(x0, torch.bfloat16, "rmsnorm_rope.x0")
+    _need(w0, torch.float32, "rmsnorm_rope.w0")
+    rows, dim = x0.shape
+    ld = x0.stride(0)
+    if x1 is not None:
+        _need(x1, torch.bfloat16, "rmsnorm_rope.x1")
+        _need(w1, torch.float32, "rmsnorm_rope.w1")
+        if x1.shape != x0.shape or x1.stride(0) != ld:
+            raise ValueError("rmsnorm_rope: x0 and x1 must have the same shape and row stride")
+    cos = sin = None
+    if rope is not None:
+        cos, sin = rope
+        _need(cos, torch.float32, "rmsnorm_rope.cos")
+        _need(sin, torch.float32, "rmsnorm_rope.sin")
+        if cos.shape != sin.shape or cos.shape[1] != head_dim // 2 or not (cos.is_contiguous() and sin.is_contiguous()):
+            raise ValueError("rmsnorm_rope: cos/sin must be contiguous [max_pos, head_dim/2]")
+        if rope_params is None:
+            raise ValueError("rmsnorm_rope: rope tables given without rope_params")
+    lib = _lib.load()
+    _lib.check(lib.wan_rmsnorm_rope(_p(x0), _p(w0), _p(x1), _p(w1), ld, rows, dim, head_dim, float(eps),
+                                    _p(cos), _p(sin),
+                                    ctypes.byref(rope_params) if rope_params is not None else None,
+                                    _stream()), "wan_rmsnorm_rope")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
+         out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+         rows_per_batch: int = 0, ldo_t: int = 0) -> torch.Tensor:
+    """acc = a @ w.T (+bias) with one of the fused epilogues.  a bf16 [M,K] (row stride free),
+    w bf16 [N,K] (nn.Linear layout).  For EPI_RESID_F32 `out` is updated in place.  For
+    EPI_BF16_T the result is [N, ldo_t] with out[n, m] (ldo_t >= M)."""
+    _need(a, torch.bfloat16, "gemm.a")
+    _need(w, torch.bfloat16, "gemm.w")
+    M, K = a.shape
+    N, Kw = w.shape
+    if K != Kw:
+        raise ValueError(f"gemm: a is [{M},{K}] but w is [{N},{Kw}]")
+    if bias is not None:
+        _need(bias, torch.float32, "gemm.bias")
+        if bias.numel() != N:
+            raise ValueError("gemm: bias length != N")
+    dev = a.device
+    if epilogue in (EPI_BF16, EPI_GELU_BF16):
+        if out is None:
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        _need(out, torch.bfloat16, "gemm.out")
+    elif epilogue == EPI_F32:
+        if out is None:
+            out = torch.empty(M, N, device=dev, dtype=torch.float32)
+        _need(out, torch.float32, "gemm.out")
+    elif epilogue == EPI_RESID_F32:
+        if out is None:
+            raise ValueError("gemm: EPI_RESID_F32 needs the residual stream as `out`")
+        _need(out, torch.float32, "gemm.out")
+        if gate is not None:
+            _need(gate, torch.float32, "gemm.gate")
+            if not gate.is_contiguous() or gate.shape[-1] != N:
+                raise ValueError("gemm.gate must be contiguous [nbatch, N]")
+    elif epilogue == EPI_BF16_T:
+        if out is None:
+            ldo_t = ldo_t or round_up(M, 64)
+            out = torch.zeros(N, ldo_t, device=dev, dtype=torch.bfloat16)
+        _need(out, torch.bfloat16, "gemm.out")
+        if out.shape[0] != N or out.shape[1] < M:
+            raise ValueError(f"gemm: transposed out must be [N={N}, >= M={M}], got {tuple(out.shape)}")
+    else:
+        raise ValueError(f"gemm: unknown epilogue {epilogue}")
+    if epilogue != EPI_BF16_T and tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm: out shape {tuple(out.shape)} != ({M},{N})")
+    lib = _lib.load()
+    _lib.check(lib.wan_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
+                                 M, N, K, epilogue, _p(gate), int(rows_per_batch), _stream()), "wan_gemm_bf16")
+    return out
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads: int, k_len: Optional[int] = None,
+                  softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q bf16 [B,Lq,H*128], k bf16 [B,Lk,H*128], vt bf16 [B,H*128,ldvt] (V transposed, ldvt >=
+    roundup(k_len,64), finite padding) -> bf16 [B,Lq,H*128].  Keys >= k_len are masked."""
+    for nm, t in (("q", q), ("k", k), ("vt", vt)):
+        _need(t, torch.bfloat16, "attention." + nm)
+        if t.dim() != 3:
+            raise ValueError(f"attention.{nm} must be 3-D [B, rows, cols]")
+    B, Lq, C = q.shape
+    Lk = k.shape[1] if k_len is None else int(k_len)
+    if Lk > k.shape[1] or Lk <= 0:
+        raise ValueError(f"attention: k_len={Lk} outside (0, {k.shape[1]}]")
+    head_dim = C // num_heads
+    if out is None:
+        out = torch.empty(B, Lq, C, device=q.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "attention.out")
+    if vt.shape[1] != C or k.shape[2] != C or k.shape[0] != B or vt.shape[0] != B:
+        raise ValueError("attention: q/k/vt shapes disagree")
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(head_dim)
+    lib = _lib.load()
+    _lib.check(lib.wan_attention_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
+                                     _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
+                                     B, Lq, Lk, num_heads, head_dim, float(scale), _stream()), "wan_attention_fwd")
+    return out
+
+
+def transpose_pad(v: torch.Tensor, ldt: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [rows, cols] -> [cols, ldt] (zero padded columns), ldt default roundup(rows, 64)."""
+    _need(v, torch.bfloat16, "transpose.v")
+    rows, cols = v.shape
+    ldt = ldt or round_up(rows, 64)
+    if out is None:
+        out = torch.empty(cols, ldt, device=v.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "transpose.out")
+    lib = _lib.load()
+    _lib.check(lib.wan_transpose_bf16(_p(v), v.stride(0), _p(out), out.stride(0), rows, cols, _stream()),
+               "wan_transpose_bf16")
+    return out
+
+
+def patchify(latent: torch.Tensor, patch: Tuple[int, int, int], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """latent [Cin,F,H,W] fp32|bf16 -> bf16 tokens [L, Cin*pt*ph*pw]."""
+    if latent.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"patchify: latent dtype {latent.dtype} not supported (fp32 or bf16)")
+    _need(latent, latent.dtype, "patchify.latent")
+    if not latent.is_contiguous() or latent.dim() != 4:
+        raise ValueError("patchify: latent must be contiguous [Cin,F,H,W]")
+    Cin, F, H, W = latent.shape
+    pt, ph, pw = patch
+    L = (F // pt) * (H // ph) * (W // pw)
+    K = Cin * pt * ph * pw
+    if out is None:
+        out = torch.empty(L, K, device=latent.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "patchify.out")
+    lib = _lib.load()
+    _lib.check(lib.wan_patchify(_p(latent), 0 if latent.dtype == torch.float32 else 1, _p(out), out.stride(0),
+                                Cin, F, H, W, pt, ph, pw, _stream()), "wan_patchify")
+    return out
+
+
+def unpatchify(tokens: torch.Tensor, grid: Tuple[int, int, int], patch: Tuple[int, int, int], cout: int,
+               out_dtype: torch.dtype) -> torch.Tensor:
+    """tokens fp32 [L, pt*ph*pw*Cout] -> [Cout, F*pt, Hp*ph, Wp*pw] in out_dtype (fp32|bf16)."""
+    _need(tokens, torch.float32, "unpatchify.tokens")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"unpatchify: out dtype {out_dtype} not supported")
+    F, Hp, Wp = grid
+    pt, ph, pw = patch
+    if tokens.shape[0] < F * Hp * Wp:
+        raise ValueError("unpatchify: fewer token rows than the grid")
+    out = torch.empty(cout, F * pt, Hp * ph, Wp * pw, device=tokens.device, dtype=out_dtype)
+    lib = _lib.load()
+    _lib.check(lib.wan_unpatchify(_p(tokens), tokens.stride(0), _p(out), 0 if out_dtype == torch.float32 else 1,
+                                  cout, F, Hp, Wp, pt, ph, pw, _stream()), "wan_unpatchify")
+    return out

@@ -1,0 +1,213 @@
+"""VideoCoF denoising pipeline on the HIP-backed DiT.
+
+Mirror of ``WanPipeline`` (``videox_fun/pipeline/pipeline_wan.py:125-138, 516-799``):
+same constructor ``(tokenizer, text_encoder, vae, transformer, scheduler)``, same
+``__call__`` argument names and ``WanPipelineOutput(videos, ground_videos,
+edit_videos)``.  The denoise loop reproduces the reference's glue exactly:
+
+    condition_count = (source_frames-1)//4 + 1                              (:630-631)
+    G = 1 if reasoning_frames <= 1 else (reasoning_frames-1)//4 + 1          (:637)
+    latents = cat([vae.encode(video).mode(), randn(Fs+G)], dim=2)            (:406-417)
+    per step: v = transformer(x, t, ctx, seq_len, fsi=[cc]*B, gfi=[(cc,cc+G)]*B)
+              CFG: v = v_uncond + s*(v_text - v_uncond), batch order [uncond, cond] (:700, 731-733)
+              v[:, :, :cc] = 0                                              (:736)
+              latents = scheduler.step(v, t, latents)[0]                    (:740)
+    decode only the grounding and edit segments                             (:760-777)
+
+The umT5 text encoder is outside the hot path: pass
+``prompt_embeds`` / ``negative_prompt_embeds`` (lists of ``[len<=512, 4096]``
+tensors) or construct the pipeline with a ``text_encoder`` callable
+``(list[str]) -> list[Tensor]``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+__all__ = ["WanPipeline", "WanPipelineOutput"]
+
+
+@dataclass
+class WanPipelineOutput:
+    videos: Optional[Union[torch.Tensor, np.ndarray]]
+    ground_videos: Optional[Union[torch.Tensor, np.ndarray]] = None
+    edit_videos: Optional[Union[torch.Tensor, np.ndarray]] = None
+    latents: Optional[torch.Tensor] = None          # extension: final latents (output_type="latent")
+
+
+class WanPipeline:
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None):
+        if transformer is None or scheduler is None:
+            raise ValueError("WanPipeline needs at least a transformer and a scheduler")
+        self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
+        self.transformer, self.scheduler = transformer, scheduler
+        self._guidance_scale = 1.0
+        self._num_timesteps = 0
+        self._interrupt = False
+
+    guidance_scale = property(lambda self: self._guidance_scale)
+    num_timesteps = property(lambda self: self._num_timesteps)
+    interrupt = property(lambda self: self._interrupt)
+
+    # -------------------------------------------------------------- prompt handling (:595-608)
+    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device):
+        def enc(p):
+            if self.text_encoder is None:
+                raise ValueError("no text_encoder: provide `prompt_embeds` (umT5 is outside the accelerated path)")
+            p = [p] if isinstance(p, str) else list(p)
+            return [e.to(device) for e in self.text_encoder(p)]
+        if prompt_embeds is None:
+            prompt_embeds = enc(prompt)
+        prompt_embeds = [prompt_embeds] if torch.is_tensor(prompt_embeds) and prompt_embeds.dim() == 2 else list(prompt_embeds)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                negative_prompt_embeds = enc(negative_prompt if negative_prompt is not None else [""] * len(prompt_embeds))
+            negative_prompt_embeds = ([negative_prompt_embeds] if torch.is_tensor(negative_prompt_embeds)
+                                      and negative_prompt_embeds.dim() == 2 else list(negative_prompt_embeds))
+            if len(negative_prompt_embeds) != len(prompt_embeds):
+                raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same batch size")
+        return prompt_embeds, negative_prompt_embeds
+
+    def check_inputs(self, prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds):
+        if height % 8 != 0 or width % 8 != 0:                                                   # :458-459
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+
+    # -------------------------------------------------------------- latents (:381-419)
+    def prepare_cot_video_latents(self, video, reasoning_latent_count, dtype, device, generator,
+                                  latents=None, source_latents=None):
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype)
+        if source_latents is None:
+            if self.vae is None:
+                raise ValueError("no VAE: provide `source_latents` (or full `latents`)")
+            video = video.to(device=device, dtype=dtype)
+            source_latents = torch.cat([self.vae.encode(video[i:i + 1])[0].mode() for i in range(video.shape[0])])
+        org = source_latents.to(device=device, dtype=dtype)
+        B, Cl, Fs, h, w = org.shape
+        noise = torch.randn((B, Cl, Fs + reasoning_latent_count, h, w), generator=generator,
+                            device=generator.device if generator is not None else device, dtype=dtype).to(device)
+        return torch.cat([org, noise], dim=2)
+
+    def decode_latents(self, latents: torch.Tensor) -> np.ndarray:
+        frames = self.vae.decode(latents.to(self.vae.dtype)).sample                             # :423-428
+        frames = (frames / 2 + 0.5).clamp(0, 1)
+        return frames.cpu().float().numpy()
+
+    # -------------------------------------------------------------- __call__ (:516-799)
+    @torch.no_grad()
+    def __call__(self, video: Optional[torch.Tensor] = None, prompt=None, negative_prompt=None,
+                 height: int = 480, width: int = 832, num_frames: int = 49, source_frames: int = 33,
+                 reasoning_frames: int = 4, num_inference_steps: int = 50, guidance_scale: float = 6.0,
+                 shift: float = 5.0, repeat_rope: bool = False, cot: bool = False,
+                 num_videos_per_prompt: int = 1, generator: Optional[torch.Generator] = None,
+                 latents: Optional[torch.Tensor] = None, source_latents: Optional[torch.Tensor] = None,
+                 prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "numpy",
+                 return_dict: bool = False, callback_on_step_end: Optional[Callable] = None,
+                 max_sequence_length: int = 512, device=None, weight_dtype: torch.dtype = torch.bfloat16,
+                 cache_context: bool = True):
+        if num_videos_per_prompt != 1:
+            raise NotImplementedError("num_videos_per_prompt must be 1 (as in fast_infer.py / inference.py)")
+        self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        self._guidance_scale = guidance_scale
+        self._interrupt = False
+        device = torch.device(device) if device is not None else self.transformer.device
+        do_cfg = guidance_scale > 1.0                                                           # :592
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device)
+        in_prompt_embeds = (negative_prompt_embeds + prompt_embeds) if do_cfg else prompt_embeds   # :605-608
+
+        if not isinstance(self.scheduler, FlowUniPCMultistepScheduler):
+            raise NotImplementedError("only FlowUniPCMultistepScheduler is built (fast_infer.py:152)")
+        self.scheduler.set_timesteps(num_inference_steps, device=device, shift=shift)           # :613-615
+        timesteps = self.scheduler.timesteps
+        self._num_timesteps = len(timesteps)
+
+        ratio = getattr(self.vae, "temporal_compression_ratio", 4)
+        condition_count = 1 if source_frames == 1 else (source_frames - 1) // ratio + 1         # :630-631
+        ground_latent_count = 0
+        if cot:
+            ground_latent_count = 1 if reasoning_frames <= 1 else (reasoning_frames - 1) // ratio + 1   # :637
+            latents = self.prepare_cot_video_latents(video, ground_latent_count, weight_dtype, device,
+                                                     generator, latents, source_latents)
+        else:
+            # repeat / org layouts: noise block has the source's frame count (:370-379)
+            latents = self.prepare_cot_video_latents(video, 0, weight_dtype, device, generator, latents,
+                                                     source_latents)
+        B, _, Ftot, hl, wl = latents.shape
+        ps = self.transformer.config.patch_size
+        seq_len = math.ceil((hl * wl) / (ps[1] * ps[2]) * Ftot)                                 # :686-689
+        self.transformer.num_inference_steps = num_inference_steps
+        prev_cache = getattr(self.transformer, "cache_context", False)
+        if hasattr(self.transformer, "cache_context"):
+            self.transformer.cache_context = cache_context    # the prompt is fixed across steps
+
+        try:
+            for i, t in enumerate(timesteps):                                                   # :694
+                self.transformer.current_steps = i
+                if self._interrupt:
+                    continue
+                latent_model_input = torch.cat([latents] * 2) if do_cfg else latents           # :700
+                latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+                timestep = t.expand(latent_model_input.shape[0])                                # :705
+                nb = latent_model_input.shape[0]
+                fsi = gfi = None
+                if repeat_rope and (video is not None or source_latents is not None or latents is not None):
+                    fsi = [condition_count] * nb                                                # :713
+                    if cot:
+                        gfi = [(condition_count, condition_count + ground_latent_count)] * nb  # :716-718
+                noise_pred = self.transformer(x=latent_model_input, context=in_prompt_embeds, t=timestep,
+                                              seq_len=seq_len, frame_split_indices=fsi,
+                                              ground_frame_indices=gfi)                         # :721-728
+                if do_cfg:
+                    nu, nt = noise_pred.chunk(2)
+                    noise_pred = nu + self.guidance_scale * (nt - nu)                           # :731-733
+                noise_pred[:, :, :condition_count] = 0                                          # :736
+                latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]     # :740
+                if callback_on_step_end is not None:
+                    out = callback_on_step_end(self, i, t, {"latents": latents})
+                    if out:
+                        latents = out.pop("latents", latents)
+        finally:
+            if hasattr(self.transformer, "cache_context"):
+                self.transformer.cache_context = prev_cache
+
+        # -- decode (:757-790)
+        ground_video = edit_video = video_out = None
+        if output_type == "numpy":
+            if self.vae is None:
+                raise ValueError("output_type='numpy' needs a VAE; use output_type='latent'")
+            if cot:
+                g0, g1 = condition_count, condition_count + ground_latent_count
+                parts = []
+                if g1 > g0 and g0 < Ftot:
+                    ground_video = self.decode_latents(latents[:, :, g0:g1])
+                    parts.append(ground_video)
+                if g1 < Ftot:
+                    edit_video = self.decode_latents(latents[:, :, g1:])
+                    parts.append(edit_video)
+                video_out = np.concatenate(parts, axis=2)
+            else:
+                if condition_count < Ftot:
+                    edit_video = self.decode_latents(latents[:, :, condition_count:])
+                video_out = edit_video
+            if not return_dict:
+                video_out = torch.from_numpy(video_out) if isinstance(video_out, np.ndarray) else video_out
+                ground_video = torch.from_numpy(ground_video) if isinstance(ground_video, np.ndarray) else ground_video
+                edit_video = torch.from_numpy(edit_video) if isinstance(edit_video, np.ndarray) else edit_video
+        elif output_type != "latent":
+            raise ValueError(f"output_type {output_type!r} not supported ('numpy' or 'latent')")
+        return WanPipelineOutput(videos=video_out, ground_videos=ground_video, edit_videos=edit_video, latents=latents)

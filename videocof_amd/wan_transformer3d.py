@@ -1,0 +1,413 @@
+"""MI355X-native Wan2.1 DiT behind the reference's ``WanTransformer3DModel`` surface.
+
+Drop-in for ``videox_fun/models/wan_transformer3d.py:567-1105`` on the T2V /
+VideoCoF path: same constructor argument names, same reference-format state-dict
+keys, same ``forward(x, t, context, seq_len, ..., frame_split_indices,
+ground_frame_indices)`` call and the attributes ``WanPipeline`` touches
+(``.config.in_channels``, ``.config.patch_size``, ``.num_inference_steps``,
+``.current_steps``, ``.freqs``, ``.dtype``, ``.device``).
+
+Host orchestration is PyTorch-ROCm; all per-token arithmetic runs in the HIP
+kernels of ``libwan_hip.so`` (see ``include/wan_hip.h``).  Data layout in HBM for one
+forward of B samples with Ll local tokens each (Ll = L when not sequence-parallel):
+
+    x    fp32 [B*Ll, C]     residual stream (fp32 from the first block on)
+    h    bf16 [B*Ll, C]     LN/modulate output feeding the GEMMs
+    qk   bf16 [B*Ll, 2C]    fused q|k projection, RMSNorm+RoPE applied in place
+    vt   bf16 [B, C, ldvt]  V^T written by the V-projection epilogue (attention operand)
+    att  bf16 [B*Ll, C]     attention output
+    ff   bf16 [B*Ll, ffn]   GELU(ffn.0)
+
+There is no eager fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import RopeParams
+from .dist import get_sp_group
+
+__all__ = ["WanTransformer3DModel", "sinusoidal_embedding_1d", "rope_params"]
+
+
+def sinusoidal_embedding_1d(dim: int, position: torch.Tensor) -> torch.Tensor:
+    """cat(cos, sin) of position * 10000^(-i/half) in fp64 (wan_transformer3d.py:31-41)."""
+    if dim % 2:
+        raise AssertionError("dim must be even")
+    half = dim // 2
+    pos = position.to(torch.float64)
+    inv = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float64, device=pos.device) / half)
+    ang = torch.outer(pos, inv)
+    return torch.cat([ang.cos(), ang.sin()], dim=1)
+
+
+def rope_params(max_seq_len: int, dim: int, theta: float = 10000.0) -> torch.Tensor:
+    """complex128 [max_seq_len, dim/2] unit phasors (wan_transformer3d.py:44-52)."""
+    inv = 1.0 / torch.pow(torch.tensor(theta, dtype=torch.float64),
+                          torch.arange(0, dim, 2, dtype=torch.float64) / dim)
+    ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64), inv)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+class _Block:
+    """Packed weights of one WanAttentionBlock (device tensors; bf16 matrices, fp32 vectors)."""
+    __slots__ = ("w_qk", "b_qk", "w_v", "b_v", "w_o", "b_o", "nq", "nk",
+                 "w_cq", "b_cq", "w_ck", "b_ck", "w_cv", "b_cv", "w_co", "b_co", "ncq", "nck",
+                 "n3w", "n3b", "w1", "b1", "w2", "b2", "modulation")
+
+
+class WanTransformer3DModel(nn.Module):
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048,
+                 ffn_dim=8192, freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32,
+                 window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6, in_channels=16,
+                 hidden_size=2048, add_control_adapter=False, in_dim_control_adapter=24,
+                 downscale_factor_control_adapter=8, add_ref_conv=False, in_dim_ref_conv=16,
+                 cross_attn_type=None):
+        super().__init__()
+        if model_type != "t2v" or cross_attn_type not in (None, "t2v_cross_attn"):
+            raise NotImplementedError("only the t2v cross-attention variant is on the VideoCoF path")
+        if add_control_adapter or add_ref_conv:
+            raise NotImplementedError("control adapter / ref conv belong to other model families")
+        if not (qk_norm and cross_attn_norm) or tuple(window_size) != (-1, -1):
+            raise NotImplementedError("Wan2.1 T2V uses qk_norm, cross_attn_norm and global attention")
+        if dim % num_heads or dim // num_heads != 128:
+            raise NotImplementedError(f"head_dim {dim / num_heads} (the gfx950 attention kernel is built for 128)")
+        self.config = SimpleNamespace(
+            model_type=model_type, patch_size=tuple(patch_size), text_len=text_len, in_dim=in_dim, dim=dim,
+            ffn_dim=ffn_dim, freq_dim=freq_dim, text_dim=text_dim, out_dim=out_dim, num_heads=num_heads,
+            num_layers=num_layers, window_size=tuple(window_size), qk_norm=qk_norm,
+            cross_attn_norm=cross_attn_norm, eps=eps, in_channels=in_dim, hidden_size=dim)
+        self.model_type, self.patch_size, self.text_len = model_type, tuple(patch_size), text_len
+        self.in_dim, self.dim, self.ffn_dim, self.freq_dim = in_dim, dim, ffn_dim, freq_dim
+        self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
+        self.eps = eps
+        self.d = dim // num_heads
+        d = self.d
+        # complex table kept for API parity (:692-699); kernels use fp32 cos/sin of the same fp64 angles
+        self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                                rope_params(1024, 2 * (d // 6))], dim=1)
+        self._rope_dev: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self.blocks: List[_Block] = []
+        self._w: Dict[str, torch.Tensor] = {}
+        self._dtype = torch.bfloat16
+        self._device = torch.device("cpu")
+        self.teacache = None
+        self.cfg_skip_ratio = None
+        self.current_steps = 0
+        self.num_inference_steps = None
+        self.sp_world_size = 1
+        self.sp_world_rank = 0
+        self._sp = None
+        self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
+        self._ctx_cache = None
+        self._attn_events = None            # bench.py: list collecting (start, end) HIP events per self-attn launch
+        self._last_attn_rows = 0
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict: bool = True, device=None):  # type: ignore[override]
+        """Pack a REFERENCE-format state dict (keys as in wan_transformer3d.py's modules) for the
+        kernels: bf16 [N,K] matrices (q|k fused), fp32 bias / norm / modulation vectors."""
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.type != "cuda":
+            raise RuntimeError("WanTransformer3DModel runs on a HIP device only (no CPU fallback)")
+        sd = state_dict
+        used = set()
+
+        def get(k):
+            if k not in sd:
+                raise KeyError(f"missing key in state_dict: {k}")
+            used.add(k)
+            return sd[k]
+
+        def mat(k):
+            return get(k).detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+
+        def vec(k):
+            return get(k).detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        C = self.dim
+        w = self._w = {}
+        w["pe_w"] = get("patch_embedding.weight").detach().reshape(C, -1).to(device=dev, dtype=torch.bfloat16).contiguous()
+        w["pe_b"] = vec("patch_embedding.bias")
+        for i in ("0", "2"):
+            w[f"te_w{i}"] = mat(f"text_embedding.{i}.weight")
+            w[f"te_b{i}"] = vec(f"text_embedding.{i}.bias")
+            # time MLP runs under autocast(float32) in the reference (:913-929): keep fp32
+            w[f"tm_w{i}"] = get(f"time_embedding.{i}.weight").detach().to(device=dev, dtype=torch.float32)
+            w[f"tm_b{i}"] = vec(f"time_embedding.{i}.bias")
+        w["tp_w"] = get("time_projection.1.weight").detach().to(device=dev, dtype=torch.float32)
+        w["tp_b"] = vec("time_projection.1.bias")
+        w["head_w"] = mat("head.head.weight")
+        w["head_b"] = vec("head.head.bias")
+        w["head_mod"] = vec("head.modulation").reshape(2, C)
+        self.blocks = []
+        for i in range(self.num_layers):
+            p = f"blocks.{i}."
+            b = _Block()
+            b.w_qk = torch.cat([mat(p + "self_attn.q.weight"), mat(p + "self_attn.k.weight")], dim=0).contiguous()
+            b.b_qk = torch.cat([vec(p + "self_attn.q.bias"), vec(p + "self_attn.k.bias")]).contiguous()
+            b.w_v, b.b_v = mat(p + "self_attn.v.weight"), vec(p + "self_attn.v.bias")
+            b.w_o, b.b_o = mat(p + "self_attn.o.weight"), vec(p + "self_attn.o.bias")
+            b.nq, b.nk = vec(p + "self_attn.norm_q.weight"), vec(p + "self_attn.norm_k.weight")
+            b.w_cq, b.b_cq = mat(p + "cross_attn.q.weight"), vec(p + "cross_attn.q.bias")
+            b.w_ck, b.b_ck = mat(p + "cross_attn.k.weight"), vec(p + "cross_attn.k.bias")
+            b.w_cv, b.b_cv = mat(p + "cross_attn.v.weight"), vec(p + "cross_attn.v.bias")
+            b.w_co, b.b_co = mat(p + "cross_attn.o.weight"), vec(p + "cross_attn.o.bias")
+            b.ncq, b.nck = vec(p + "cross_attn.norm_q.weight"), vec(p + "cross_attn.norm_k.weight")
+            b.n3w, b.n3b = vec(p + "norm3.weight"), vec(p + "norm3.bias")
+            b.w1, b.b1 = mat(p + "ffn.0.weight"), vec(p + "ffn.0.bias")
+            b.w2, b.b2 = mat(p + "ffn.2.weight"), vec(p + "ffn.2.bias")
+            b.modulation = vec(p + "modulation").reshape(6, C)
+            self.blocks.append(b)
+        w["mod_all"] = torch.stack([b.modulation for b in self.blocks])        # [layers, 6, C]
+        if strict:
+            extra = [k for k in sd.keys() if k not in used]
+            if extra:
+                raise KeyError(f"unexpected keys in state_dict: {extra[:5]}{'...' if len(extra) > 5 else ''}")
+        ang = torch.view_as_real(self.freqs)          # [1024, 64, 2] = (cos, sin) of the fp64 angles
+        self._rope_dev = (ang[..., 0].to(torch.float32).contiguous().to(dev),
+                          ang[..., 1].to(torch.float32).contiguous().to(dev))
+        self._device = dev
+        self._ctx_cache = None
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
+                        low_cpu_mem_usage=False, torch_dtype=torch.bfloat16):
+        """config.json + *.safetensors loader (wan_transformer3d.py:1157-1299); shards are merged."""
+        from safetensors.torch import load_file
+        path = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        import inspect
+        ok = inspect.signature(cls.__init__).parameters
+        kw = {k: v for k, v in cfg.items() if k in ok}
+        kw.update({k: v for k, v in dict(transformer_additional_kwargs).items() if k in ok})
+        model = cls(**kw)
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        sd = {}
+        for fpath in files:
+            sd.update(load_file(fpath))
+        model.load_state_dict(sd, strict=False)
+        return model
+
+    # ------------------------------------------------------------------ reference API surface
+    def enable_multi_gpus_inference(self):
+        """wan_transformer3d.py:802-816: pick up the sequence-parallel group (Ulysses)."""
+        sp = get_sp_group()
+        if sp is None:
+            raise RuntimeError("sequence-parallel group is not initialised (videocof_amd.dist.set_multi_gpus_devices)")
+        if self.num_heads % sp.world_size:
+            raise ValueError(f"num_heads={self.num_heads} is not divisible by ulysses degree {sp.world_size}")
+        self._sp, self.sp_world_size, self.sp_world_rank = sp, sp.world_size, sp.rank
+
+    def enable_teacache(self, *a, **k):
+        raise NotImplementedError("TeaCache changes outputs and is dead in the CLI path (SURVEY.md section 2, row 7)")
+
+    def disable_teacache(self):
+        self.teacache = None
+
+    def enable_cfg_skip(self, cfg_skip_ratio, num_steps):
+        if cfg_skip_ratio:
+            raise NotImplementedError("cfg_skip is identity on every supported config (SURVEY.md section 2, row 8)")
+        self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
+
+    def disable_cfg_skip(self):
+        self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
+
+    # ------------------------------------------------------------------ pieces of forward
+    def _time_embed(self, t: torch.Tensor):
+        w = self._w
+        s = sinusoidal_embedding_1d(self.freq_dim, t.to(self._device)).float()
+        e = torch.addmm(w["tm_b2"], torch.nn.functional.silu(torch.addmm(w["tm_b0"], s, w["tm_w0"].t())), w["tm_w2"].t())
+        e0 = torch.addmm(w["tp_b"], torch.nn.functional.silu(e), w["tp_w"].t()).unflatten(1, (6, self.dim))
+        return e, e0          # fp32 [B,C], [B,6,C]
+
+    def _text_embed(self, context: Sequence[torch.Tensor]) -> torch.Tensor:
+        w = self._w
+        B = len(context)
+        ctx = torch.zeros(B * self.text_len, self.text_dim, device=self._device, dtype=torch.bfloat16)
+        for b, u in enumerate(context):
+            if u.shape[0] > self.text_len or u.shape[1] != self.text_dim:
+                raise ValueError(f"context[{b}] has shape {tuple(u.shape)}; expected [<= {self.text_len}, {self.text_dim}]")
+            ctx[b * self.text_len: b * self.text_len + u.shape[0]] = u.to(device=self._device, dtype=torch.bfloat16)
+        hid = ops.gemm(ctx, w["te_w0"], w["te_b0"], ops.EPI_GELU_BF16)
+        return ops.gemm(hid, w["te_w2"], w["te_b2"], ops.EPI_BF16)       # [B*512, C]
+
+    def _context_kv(self, blk: _Block, ctx: torch.Tensor, B: int):
+        C, T = self.dim, self.text_len
+        ck = ops.gemm(ctx, blk.w_ck, blk.b_ck, ops.EPI_BF16)
+        ops.rmsnorm_rope_(ck, blk.nck, None, None, self.d, self.eps)
+        cvt = torch.empty(B, C, T, device=self._device, dtype=torch.bfloat16)
+        for b in range(B):
+            ops.gemm(ctx[b * T:(b + 1) * T], blk.w_cv, blk.b_cv, ops.EPI_BF16_T, out=cvt[b])
+        return ck.view(B, T, C), cvt
+
+    def _event_pair(self):
+        if self._attn_events is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()          # on torch's current stream = the stream the kernel is launched on
+        return a, b
+
+    def _event_done(self, ev, rows):
+        if ev is not None:
+            ev[1].record()
+            self._attn_events.append(ev)
+            self._last_attn_rows = rows
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, t, context, seq_len, clip_fea=None, y=None, y_camera=None, full_ref=None,
+                subject_ref=None, cond_flag=True, frame_split_indices=None, ground_frame_indices=None):
+        if not self.blocks:
+            raise RuntimeError("weights are not loaded (call load_state_dict / from_pretrained)")
+        if any(v is not None for v in (clip_fea, y, y_camera, full_ref, subject_ref)):
+            raise NotImplementedError("i2v / camera / reference conditioning are other model families "
+                                      "(SURVEY.md section 2, rows 13-14)")
+        if isinstance(x, (list, tuple)):
+            if len({tuple(u.shape) for u in x}) != 1:
+                raise NotImplementedError("samples of one call must share a latent shape")
+            x = torch.stack(list(x))
+        if not x.is_cuda:
+            raise RuntimeError("input latents are on the CPU; the HIP path has no CPU fallback")
+        dtype = x.dtype
+        self._dtype = dtype if dtype in (torch.bfloat16, torch.float32) else self._dtype
+        B, Cin, F, Hh, Ww = x.shape
+        pt, ph, pw = self.patch_size
+        if Cin != self.in_dim:
+            raise ValueError(f"latent has {Cin} channels, model expects {self.in_dim}")
+        grid = (F // pt, Hh // ph, Ww // pw)
+        L = grid[0] * grid[1] * grid[2]
+        if t.dim() != 1:
+            raise NotImplementedError("per-token timesteps (Wan2.2-5B) are never produced by WanPipeline")
+        if t.numel() != B or len(context) != B:
+            raise ValueError(f"batch mismatch: x has {B} samples, t {t.numel()}, context {len(context)}")
+        P, rank = self.sp_world_size, self.sp_world_rank
+        if P > 1:
+            # :904-905 pads to a multiple of P; we pad to 8*P so every shard keeps 16-byte aligned rows
+            seq_len = int(math.ceil(seq_len / (8 * P))) * 8 * P
+        assert L <= seq_len, f"sequence of {L} tokens exceeds seq_len={seq_len}"         # :906
+        Ll = seq_len // P
+        C, H, dev, w = self.dim, self.num_heads, self._device, self._w
+        M = B * Ll
+
+        # -- time / text embeddings ------------------------------------------------------------
+        e, e0 = self._time_embed(t)
+        emod = (w["mod_all"][:, None] + e0[None]).permute(0, 2, 1, 3).contiguous()      # [layers, 6, B, C]
+        ehead = (w["head_mod"][None] + e[:, None]).permute(1, 0, 2).contiguous()         # [2, B, C]
+
+        ctx_key = None
+        if self.cache_context:
+            ctx_key = tuple((u.data_ptr(), tuple(u.shape), u._version) for u in context)
+        if self._ctx_cache is not None and self._ctx_cache[0] == ctx_key and ctx_key is not None:
+            ctx_kv = self._ctx_cache[1]
+        else:
+            ctx = self._text_embed(context)
+            ctx_kv = [None] * self.num_layers
+            if self.cache_context:
+                ctx_kv = [self._context_kv(blk, ctx, B) for blk in self.blocks]
+                self._ctx_cache = (ctx_key, ctx_kv)
+
+        # -- patch embedding into the fp32 residual stream (this rank's token rows only) --------
+        xs = torch.zeros(M, C, device=dev, dtype=torch.float32)
+        lo, hi = rank * Ll, min((rank + 1) * Ll, L)
+        for b in range(B):
+            tok = ops.patchify(x[b].contiguous() if x.dtype in (torch.float32, torch.bfloat16)
+                               else x[b].float().contiguous(), self.patch_size)
+            if hi > lo:
+                ops.gemm(tok[lo:hi], w["pe_w"], w["pe_b"], ops.EPI_F32, out=xs[b * Ll: b * Ll + (hi - lo)])
+
+        # -- RoPE position map -------------------------------------------------------------------
+        mode, f_src, g_end = 0, 0, 0
+        if frame_split_indices is not None and len(frame_split_indices) > 0:
+            if len(set(frame_split_indices)) != 1:
+                raise NotImplementedError("all samples of a call must share frame_split_indices")
+            f_src, mode = int(frame_split_indices[0]), 1
+            if ground_frame_indices is not None and len(ground_frame_indices) > 0:
+                if len(set(tuple(g) for g in ground_frame_indices)) != 1:
+                    raise NotImplementedError("all samples of a call must share ground_frame_indices")
+                g0, g1 = ground_frame_indices[0]
+                if int(g0) != f_src:
+                    raise ValueError("ground frames must start at frame_split_indices (pipeline_wan.py:716-718)")
+                mode, g_end = 2, int(g1)
+        rp = RopeParams(grid[0], grid[1], grid[2], mode, f_src, g_end, rank * Ll, Ll, self.freqs.shape[0])
+
+        # -- workspaces ----------------------------------------------------------------------------
+        h = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        qk = torch.empty(M, 2 * C, device=dev, dtype=torch.bfloat16)
+        att = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        cq = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        ff = torch.empty(M, self.ffn_dim, device=dev, dtype=torch.bfloat16)
+        if P == 1:
+            vt = torch.zeros(B, C, ops.round_up(L, 64), device=dev, dtype=torch.bfloat16)
+        else:
+            vt = torch.zeros(B, C, Ll, device=dev, dtype=torch.bfloat16)
+        qk3 = qk.view(B, Ll, 2 * C)
+
+        for li, blk in enumerate(self.blocks):
+            em = emod[li]
+            # ---- self attention (:495-499)
+            ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
+            ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
+            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp)
+            if P == 1:
+                for b in range(B):
+                    ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
+                ev = self._event_pair()
+                ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C))
+                self._event_done(ev, B * Ll)
+                o_in = att
+            else:
+                sp = self._sp
+                fq = sp.scatter_heads(qk3[:, :, :C], async_op=True)
+                fk = sp.scatter_heads(qk3[:, :, C:], async_op=True)
+                for b in range(B):      # V projection overlaps the q/k exchange
+                    ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
+                fv = sp.scatter_heads_t(vt, ld=ops.round_up(seq_len, 64), async_op=True)
+                q_full, k_full, vt_full = fq().contiguous(), fk().contiguous(), fv()
+                ev = self._event_pair()
+                o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L)
+                self._event_done(ev, B * seq_len)
+                o_in = sp.gather_heads(o_full).reshape(M, C)
+            ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
+            # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
+            ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
+            ops.gemm(h, blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq)
+            ops.rmsnorm_rope_(cq, blk.ncq, None, None, self.d, self.eps)
+            ck, cvt = ctx_kv[li] if ctx_kv[li] is not None else self._context_kv(blk, ctx, B)
+            ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C))
+            ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
+            # ---- FFN (:507-511)
+            ops.ln_modulate(xs, em[4], em[3], True, Ll, self.eps, out=h)
+            ops.gemm(h, blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff)
+            ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
+
+        # -- head (:535-548) + unpatchify (:1108-1131)
+        ops.ln_modulate(xs, ehead[1], ehead[0], True, Ll, self.eps, out=h)
+        yt = ops.gemm(h, w["head_w"], w["head_b"], ops.EPI_F32).view(B, Ll, -1)
+        if P > 1:
+            yt = self._sp.all_gather_tokens(yt)                                        # :1085-1086
+        out_dtype = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
+        outs = [ops.unpatchify(yt[b], grid, self.patch_size, self.out_dim, out_dtype) for b in range(B)]
+        return torch.stack(outs).to(dtype)
