@@ -46,6 +46,10 @@ struct AttnArgs {
     float scale_log2e;    // softmax_scale * log2(e)
 };
 
+// VARIANT only names the instantiation so profiles separate the two call sites:
+//   0 = attn_self  (long KV stream: self-attention, Lk ~ 1e4..1e5)
+//   1 = attn_cross (short KV: the 512 text tokens of WanT2VCrossAttention)
+template <int VARIANT>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -257,8 +261,11 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (Lq == 0) return WAN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) {
             wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
             return WAN_ERR_LAUNCH;
@@ -273,7 +280,10 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
     a.scale_log2e = softmax_scale * 1.4426950408889634f;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, kLdsBytes, (hipStream_t)stream, a);
+    if (Lk > 1024)
+        hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, (hipStream_t)stream, a);
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;
 }

@@ -43,6 +43,18 @@ class SequenceParallelGroup:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        # gloo cannot move device memory: stage through the host (used only by the 1-GPU
+        # 2-rank validation test; RCCL exchanges device buffers directly over xGMI)
+        self._host_staged = dist.get_backend(group) == "gloo"
+
+    def _a2a(self, recv, send, async_op):
+        if self._host_staged and send.is_cuda:
+            s_cpu = send.cpu()
+            r_cpu = torch.empty_like(s_cpu)
+            dist.all_to_all_single(r_cpu, s_cpu, group=self.group)
+            recv.copy_(r_cpu)
+            return None
+        return dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
 
     # token-sharded [B, Ll, C] -> head-sharded [B, P*Ll, C/P]; `x` may be a strided view
     def scatter_heads(self, x: torch.Tensor, async_op: bool = False):
@@ -50,7 +62,7 @@ class SequenceParallelGroup:
         B, Ll, C = x.shape
         send = x.reshape(B, Ll, P, C // P).permute(2, 0, 1, 3).contiguous()
         recv = torch.empty_like(send)
-        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        work = self._a2a(recv, send, async_op)
 
         def finish() -> torch.Tensor:
             if work is not None:
@@ -64,7 +76,7 @@ class SequenceParallelGroup:
         B, C, Ll = vt.shape
         send = vt.reshape(B, P, C // P, Ll).permute(1, 0, 2, 3).contiguous()
         recv = torch.empty_like(send)
-        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        work = self._a2a(recv, send, async_op)
         ld = ld or P * Ll
 
         def finish() -> torch.Tensor:
@@ -82,13 +94,18 @@ class SequenceParallelGroup:
         Ll = L // P
         send = o.reshape(B, P, Ll, Cs).permute(1, 0, 2, 3).contiguous()
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
+        self._a2a(recv, send, False)
         return recv.permute(1, 2, 0, 3).reshape(B, Ll, P * Cs)
 
     # [B, Ll, N] -> [B, P*Ll, N]
     def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
         P = self.world_size
         y = y.contiguous()
+        if self._host_staged and y.is_cuda:
+            yc = y.cpu()
+            parts = [torch.empty_like(yc) for _ in range(P)]
+            dist.all_gather(parts, yc, group=self.group)
+            return torch.cat(parts, dim=1).to(y.device)
         parts = [torch.empty_like(y) for _ in range(P)]
         dist.all_gather(parts, y, group=self.group)
         return torch.cat(parts, dim=1)
