@@ -112,3 +112,106 @@ def random_dit_state_dict(device, dtype=torch.bfloat16, seed: int = 0, **cfg) ->
             t = (torch.rand(shape, device=device, generator=g, dtype=torch.float32) * 2 - 1) * bound
         sd[name] = t.to(dtype) if t.dim() > 1 and "modulation" not in name else t
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# WanVAE (videox_fun/models/wan_vae.py:269-476, 599-617): parameter names exactly as saved by
+# AutoencoderKLWan.state_dict() ("model." prefix, :699-702)
+# ----------------------------------------------------------------------------------------------
+def vae_param_shapes(dim: int = 96, z_dim: int = 16, dim_mult=(1, 2, 4, 4), num_res_blocks: int = 2,
+                     temporal_downsample=(False, True, True), prefix: str = "model.") -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def conv3(name, cin, cout, k=(3, 3, 3)):
+        s[name + ".weight"] = (cout, cin) + tuple(k)
+        s[name + ".bias"] = (cout,)
+
+    def res(name, cin, cout):
+        s[name + ".residual.0.gamma"] = (cin, 1, 1, 1)
+        conv3(name + ".residual.2", cin, cout)
+        s[name + ".residual.3.gamma"] = (cout, 1, 1, 1)
+        conv3(name + ".residual.6", cout, cout)
+        if cin != cout:
+            conv3(name + ".shortcut", cin, cout, (1, 1, 1))
+
+    def attn(name, c):
+        s[name + ".norm.gamma"] = (c, 1, 1)
+        s[name + ".to_qkv.weight"], s[name + ".to_qkv.bias"] = (3 * c, c, 1, 1), (3 * c,)
+        s[name + ".proj.weight"], s[name + ".proj.bias"] = (c, c, 1, 1), (c,)
+
+    mult = list(dim_mult)
+    # encoder (:288-320)
+    dims = [dim * u for u in [1] + mult]
+    conv3("encoder.conv1", 3, dims[0])
+    idx, cur = 0, dims[0]
+    for i, out_dim in enumerate(dims[1:]):
+        for _ in range(num_res_blocks):
+            res(f"encoder.downsamples.{idx}", cur, out_dim)
+            cur = out_dim
+            idx += 1
+        if i != len(mult) - 1:
+            s[f"encoder.downsamples.{idx}.resample.1.weight"] = (cur, cur, 3, 3)
+            s[f"encoder.downsamples.{idx}.resample.1.bias"] = (cur,)
+            if temporal_downsample[i]:
+                conv3(f"encoder.downsamples.{idx}.time_conv", cur, cur, (3, 1, 1))
+            idx += 1
+    res("encoder.middle.0", cur, cur)
+    attn("encoder.middle.1", cur)
+    res("encoder.middle.2", cur, cur)
+    s["encoder.head.0.gamma"] = (cur, 1, 1, 1)
+    conv3("encoder.head.2", cur, 2 * z_dim)
+    conv3("conv1", 2 * z_dim, 2 * z_dim, (1, 1, 1))
+    conv3("conv2", z_dim, z_dim, (1, 1, 1))
+    # decoder (:392-425)
+    tup = list(temporal_downsample)[::-1]
+    dims = [dim * u for u in [mult[-1]] + mult[::-1]]
+    conv3("decoder.conv1", z_dim, dims[0])
+    res("decoder.middle.0", dims[0], dims[0])
+    attn("decoder.middle.1", dims[0])
+    res("decoder.middle.2", dims[0], dims[0])
+    idx = 0
+    for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            in_dim = in_dim // 2
+        for _ in range(num_res_blocks + 1):
+            res(f"decoder.upsamples.{idx}", in_dim, out_dim)
+            in_dim = out_dim
+            idx += 1
+        if i != len(mult) - 1:
+            s[f"decoder.upsamples.{idx}.resample.1.weight"] = (out_dim // 2, out_dim, 3, 3)
+            s[f"decoder.upsamples.{idx}.resample.1.bias"] = (out_dim // 2,)
+            if tup[i]:
+                conv3(f"decoder.upsamples.{idx}.time_conv", out_dim, 2 * out_dim, (3, 1, 1))
+            idx += 1
+    s["decoder.head.0.gamma"] = (dims[-1], 1, 1, 1)
+    conv3("decoder.head.2", dims[-1], 3)
+    return {prefix + k: v for k, v in s.items()}
+
+
+def deterministic_vae_state_dict(**cfg) -> Dict[str, torch.Tensor]:
+    sd = {}
+    for name, shape in vae_param_shapes(**cfg).items():
+        if name.endswith("gamma"):
+            sd[name] = det_uniform(name, shape, 0.2, 1.0)
+        elif name.endswith(".bias"):
+            sd[name] = det_uniform(name, shape, 0.05)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            sd[name] = det_uniform(name, shape, (3.0 / fan_in) ** 0.5)      # unit-gain uniform
+    return sd
+
+
+@torch.no_grad()
+def random_vae_state_dict(device, seed: int = 0, **cfg) -> Dict[str, torch.Tensor]:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sd = {}
+    for name, shape in vae_param_shapes(**cfg).items():
+        if name.endswith("gamma"):
+            sd[name] = torch.ones(shape, device=device)
+        elif name.endswith(".bias"):
+            sd[name] = torch.zeros(shape, device=device)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            sd[name] = (torch.rand(shape, device=device, generator=g) * 2 - 1) * (3.0 / fan_in) ** 0.5
+    return sd
