@@ -148,6 +148,54 @@ wan_status_t wan_patchify(const void* latent, int in_dtype, void* tokens_bf16, i
 wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
                             int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, void* stream);
 
+/* ===========================================================================
+ * WanVAE (videox_fun/models/wan_vae.py).  Activations are CHANNELS-LAST bf16 [T, H, W, C].
+ * ------------------------------------------------------------------------- */
+
+/* a18/a19  every convolution of the VAE as one implicit-GEMM kernel:
+ *     out[(to,ho,wo), n] = bias[n] + sum_{kt,kh,kw,ci} in[to*st+kt-pt, ho*sh+kh-ph, wo*sw+kw-pw, ci] * w[n,(kt,kh,kw,ci)]
+ *                          (+ resid[(to,ho,wo), n])
+ *     replaces: CausalConv3d.forward incl. the cache_x halo (wan_vae.py:21-40: frames with negative
+ *               time index are read from `hist`, the last `hist_frames` (<= 2) frames of the previous
+ *               chunk, CACHE_T :18; missing history = the zero padding of :38);
+ *               Resample's Conv2d: upsample2x=1 fuses Upsample(nearest-exact, 2x) (:81-83) into the
+ *               gather, ZeroPad2d((0,1,0,1)) + stride 2 (:92-94) is ph=pw=0, sh=sw=2 with zero fill;
+ *               upsample3d's time_conv + the channel->time interleave (:132-141): time_interleave=1
+ *               writes channel n of frame t to frame 2t + n/(Cout/2), channel n%(Cout/2);
+ *               ResidualBlock's `x + h` (:224) through `resid`; all 1x1 convs (:203, 238-239, 509-510).
+ *     x    bf16 [T_in, H_in, W_in, Cin], Cin % 8 == 0
+ *     w    bf16 [Cout, ldw] with k = ((kt*KH + kh)*KW + kw)*Cin + ci, zero padded to ldw >= roundup(K, 64)
+ *     out  bf16 [T_out*H_out*W_out, ldo]  (time_interleave: [2*T_out*H_out*W_out, ldo], Cout/2 channels) */
+typedef struct {
+    int T_in, H_in, W_in, Cin;
+    int T_out, H_out, W_out, Cout;
+    int KT, KH, KW;          /* each 1 or 3 */
+    int st, sh, sw;          /* strides */
+    int pt, ph, pw;          /* leading pads (time pad = causal front pad) */
+    int upsample2x;          /* gather from a virtual nearest-exact 2x upsample of (H_in, W_in) */
+    int time_interleave;
+} wan_conv_params;
+
+wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_frames, const void* w, int64_t ldw,
+                         const float* bias, const void* resid, void* out, int64_t ldo,
+                         const wan_conv_params* p, void* stream);
+
+/* a19  RMS_norm (F.normalize over channels * sqrt(C) * gamma, wan_vae.py:43-58) + optional SiLU,
+ *      per pixel on channels-last rows.  C % 8 == 0, C <= 512. */
+wan_status_t wan_rmsnorm_silu_cl(const void* x_bf16, const float* gamma, void* out_bf16, int64_t rows, int C,
+                                 int silu, void* stream);
+
+/* a19  row softmax for AttentionBlock (single head of dim C over h*w, wan_vae.py:256-260):
+ *      probs[r, i] = softmax_i(scale * scores[r, i]) for i < n, 0 for n <= i < npad. */
+wan_status_t wan_softmax_rows(const float* scores, int64_t lds, void* probs_bf16, int64_t ldp, int64_t rows,
+                              int n, int npad, float scale, void* stream);
+
+/* boundary layout: planar [Cv, npix] (the reference's [C,T,H,W]) <-> channels-last [npix, Cpad] bf16.
+ * dtype: 0 fp32, 1 bf16.  cl_to_video optionally clamps to [-1, 1] (wan_vae.py:669). */
+wan_status_t wan_video_to_cl(const void* video, int in_dtype, void* out_bf16, int Cv, int Cpad, int64_t npix, void* stream);
+wan_status_t wan_cl_to_video(const void* x_bf16, int64_t ld, void* out, int out_dtype, int Cv, int64_t npix,
+                             int clamp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

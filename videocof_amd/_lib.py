@@ -26,6 +26,13 @@ class RopeParams(Structure):
                 ("max_pos", c_int)]
 
 
+class ConvParams(Structure):
+    """``wan_conv_params`` of include/wan_hip.h."""
+    _fields_ = [(n, c_int) for n in ("T_in", "H_in", "W_in", "Cin", "T_out", "H_out", "W_out", "Cout",
+                                     "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw",
+                                     "upsample2x", "time_interleave")]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "wan_abi_version": (c_int, []),
@@ -44,6 +51,12 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_void_p]),
     "wan_unpatchify": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
+    "wan_conv_cl": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                            POINTER(ConvParams), c_void_p]),
+    "wan_rmsnorm_silu_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "wan_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),
+    "wan_video_to_cl": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "wan_cl_to_video": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,393 @@
+// WanVAE convolutions as ONE implicit-GEMM kernel on the gfx950 matrix cores.
+//
+// Replaces CausalConv3d (+ its 2-frame feat_cache halo), the Conv2d of Resample (nearest-exact 2x
+// upsample fused into the gather; ZeroPad2d((0,1,0,1)) + stride 2), the (3,1,1) time_conv of
+// upsample3d (with the channel->time interleave fused into the store) and every 1x1 conv of
+// videox_fun/models/wan_vae.py:21-40, 70-164, 190-266.
+//
+// Layout: activations are CHANNELS-LAST bf16 [T, H, W, C]; weights are [Cout][KT][KH][KW][Cin]
+// flattened to K = taps*Cin (zero padded to a multiple of 64).  Then
+//     out[pixel m, n] = sum_k A[m, k] * Wt[n, k],   A[m, (tap, ci)] = in[pixel m shifted by tap][ci]
+// is exactly the bf16 GEMM of gemm_bf16.hip, except that the A tile is GATHERED: every 16-byte
+// chunk of an A-tile row is 8 consecutive channels of ONE input pixel, so the LDS-DMA staging
+// keeps its shape and only the per-lane source address changes (a tap decode + bounds test per
+// chunk; out-of-range taps, causal history before the sequence start and K padding read a zero
+// page).  Frames with negative time index come from the `hist` buffer (the per-conv history that
+// the reference calls feat_cache).
+//
+// Tile 128 pixels x (32*NT) channels x 64 k, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, double
+// buffered LDS, same source-side XOR swizzle as the GEMM.  NT = 3 / 4 / 6 -> BN = 96 / 128 / 192 so
+// the VAE widths 96 / 192 / 384 waste no MFMA columns.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kATile = BM * BK * 2;   // 16 KiB
+
+__device__ __attribute__((aligned(128))) unsigned int wan_zero_page[64];   // 256 B of zeros
+
+struct ConvArgs {
+    const bf16_t* x; const bf16_t* hist; const bf16_t* w; int64_t ldw;
+    const float* bias; const bf16_t* resid; bf16_t* out; int64_t ldo;
+    int T_in, H_in, W_in, Cin;
+    int T_out, H_out, W_out, Cout;
+    int KT, KH, KW, st, sh, sw, pt, ph, pw;
+    int ups, interleave, hist_frames, silu;
+    int M, ntaps, nk, tiles_m, tiles_n;
+    unsigned cin_magic;          // ceil(2^32 / Cin)
+};
+
+__device__ __forceinline__ int div3(int a) { return (a * 171) >> 9; }   // exact for 0 <= a < 256
+
+template <int NT>
+__global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(ConvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 32 * NT;
+    constexpr int kWTile = BN * BK * 2;
+    constexpr int kStage = kATile + kWTile;
+    constexpr int WP = BN / 8 / 4;          // W pieces (8 rows each) per wave: 3, 4, 6
+
+    // tile coordinates: N fastest so the CUs working at one time share the gathered A panel in L2
+    const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+
+    // ---- A gather bookkeeping: piece j of this wave = tile rows (wid*4+j)*8 .. +7
+    const int srow = lane >> 3, spc = lane & 7;
+    int ti0[4], hw0[4];          // hw0 packs (hi0 + 4096) << 16 | (wi0 + 4096)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (wid * 4 + j) * 8 + srow;
+        if (m < g.M) {
+            const int wo = m % g.W_out;
+            const int r = m / g.W_out;
+            const int ho = r % g.H_out, to = r / g.H_out;
+            ti0[j] = to * g.st - g.pt;
+            hw0[j] = ((ho * g.sh - g.ph + 4096) << 16) | (wo * g.sw - g.pw + 4096);
+        } else {
+            ti0[j] = -(1 << 20);           // never valid
+            hw0[j] = (4096 << 16) | 4096;
+        }
+    }
+    // logical chunk of this lane for even / odd pieces (swizzle depends on (row >> 1) & 7)
+    const int cl[2] = {spc ^ ((srow >> 1) & 7), spc ^ ((4 + (srow >> 1)) & 7)};
+    const int Hlim = g.H_in << g.ups, Wlim = g.W_in << g.ups;
+    const int64_t frame_elems = (int64_t)g.H_in * g.W_in * g.Cin;
+
+    const bf16_t* w_src[WP];
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+        const int row = (wid * WP + j) * 8 + srow;
+        const int c = spc ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, g.Cout - 1);
+        w_src[j] = g.w + (int64_t)n * g.ldw + c * 8;
+    }
+
+    auto stage = [&](int buf, int kstep) {
+        char* base = smem + buf * kStage;
+        // decode (tap, ci) once per swizzle parity
+        int dt[2], dh[2], dw[2], ci[2];
+        bool tapok[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned k = (unsigned)(kstep * BK + cl[p] * 8);
+            const int tap = (int)__umulhi(k, g.cin_magic);
+            ci[p] = (int)k - tap * g.Cin;
+            tapok[p] = tap < g.ntaps;
+            int rest = tap;
+            int kw = 0, kh = 0;
+            if (g.KW == 3) { const int q = div3(rest); kw = rest - 3 * q; rest = q; }
+            if (g.KH == 3) { const int q = div3(rest); kh = rest - 3 * q; rest = q; }
+            dt[p] = rest; dh[p] = kh; dw[p] = kw;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = j & 1;
+            const int ti = ti0[j] + dt[p];
+            const int hi = (hw0[j] >> 16) - 4096 + dh[p];
+            const int wi = (hw0[j] & 0xffff) - 4096 + dw[p];
+            const bool ok = tapok[p] && (unsigned)hi < (unsigned)Hlim && (unsigned)wi < (unsigned)Wlim &&
+                            ti < g.T_in && ti >= -g.hist_frames;
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(wan_zero_page);
+            if (ok) {
+                const int64_t pix = ((int64_t)(hi >> g.ups) * g.W_in + (wi >> g.ups)) * g.Cin + ci[p];
+                src = ti >= 0 ? g.x + ti * frame_elems + pix : g.hist + (ti + g.hist_frames) * frame_elems + pix;
+            }
+            glds16(src, base + (wid * 4 + j) * 1024);
+        }
+        const int koff = kstep * BK;
+#pragma unroll
+        for (int j = 0; j < WP; ++j) glds16(w_src[j] + koff, base + kATile + (wid * WP + j) * 1024);
+    };
+
+    // ---- fragment read offsets (identical to gemm_bf16.hip)
+    const int frow = lane & 15, kg = lane >> 4, sw_ = (lane >> 1) & 7;
+    const int off_k0 = frow * 128 + ((kg ^ sw_) << 4);
+    const int off_k1 = frow * 128 + (((kg + 4) ^ sw_) << 4);
+    const int a_base = wr * 64 * 128;
+    const int w_base = kATile + wc * (16 * NT) * 128;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (int kt = 0; kt < g.nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < g.nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * kStage;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = kk ? off_k1 : off_k0;
+            bf16x8 af[4], wf[NT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * 2048 + off);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_base + j * 2048 + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds pixel m = l&15, channels n = (l>>4)*4 + r
+    const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+    const int Ch = g.interleave ? g.Cout >> 1 : g.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + l15;
+        if (m >= g.M) continue;
+        int64_t orow = m;
+        int to = 0, rem = 0;
+        if (g.interleave) {
+            const int hw = g.H_out * g.W_out;
+            to = m / hw;
+            rem = m - to * hw;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wc * (16 * NT) + j * 16 + l4;
+            if (n >= g.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (g.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            int col = n;
+            if (g.interleave) {            // frame 2t + half, channel n - half*Ch   (wan_vae.py:138-141)
+                const int half = n >= Ch;
+                col = n - half * Ch;
+                orow = (int64_t)(2 * to + half) * (g.H_out * g.W_out) + rem;
+            }
+            if (g.resid) {
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(g.resid + orow * g.ldo + col);
+                v[0] += bf16lo_to_f32(rv[0]); v[1] += bf16hi_to_f32(rv[0]);
+                v[2] += bf16lo_to_f32(rv[1]); v[3] += bf16hi_to_f32(rv[1]);
+            }
+            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(g.out + orow * g.ldo + col) = o;
+        }
+    }
+}
+
+template <int NT>
+wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
+    constexpr int lds = 2 * (kATile + 32 * NT * BK * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cl_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            wan_set_error("wan_conv_cl: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_cl_kernel<NT>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), lds, s, g);
+    WAN_CHECK_LAUNCH("wan_conv_cl");
+    return WAN_OK;
+}
+
+// ------------------------------------------------------------------ per-pixel RMS_norm (+SiLU)
+// F.normalize(x, dim=channel) * sqrt(C) * gamma  (wan_vae.py:43-58), optional SiLU; one wave per pixel.
+__global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                              bf16_t* __restrict__ out, int64_t rows, int C, int silu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    const bool act = lane < nchunk;
+    u32x4 v = {0, 0, 0, 0};
+    if (act) v = reinterpret_cast<const u32x4*>(x + row * C)[lane];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float a = bf16lo_to_f32(v[j]), b = bf16hi_to_f32(v[j]); ss += a * a + b * b; }
+    ss = wave_sum(ss);
+    const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+    if (act) {
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[lane * 2], gb = reinterpret_cast<const float4*>(gamma)[lane * 2 + 1];
+        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = bf16lo_to_f32(v[j]) * scale * gv[2 * j], b = bf16hi_to_f32(v[j]) * scale * gv[2 * j + 1];
+            if (silu) { a = a / (1.f + __expf(-a)); b = b / (1.f + __expf(-b)); }
+            o[j] = pack_bf16x2(a, b);
+        }
+        reinterpret_cast<u32x4*>(out + row * C)[lane] = o;
+    }
+}
+
+// ------------------------------------------------------------------ row softmax for the VAE's single-head attention
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, bf16_t* __restrict__ p,
+                                                           int64_t ldp, int n, int npad, float scale) {
+    __shared__ float red[4];
+    const float* sr = s + (int64_t)blockIdx.x * lds_;
+    bf16_t* pr = p + (int64_t)blockIdx.x * ldp;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, sr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) sum += __expf((sr[i] - mx) * scale);
+    sum = block_sum<4>(sum, red);
+    const float inv = 1.f / sum;
+    for (int i = threadIdx.x; i < npad; i += 256)
+        pr[i] = (bf16_t)(i < n ? __expf((sr[i] - mx) * scale) * inv : 0.f);
+}
+
+// ------------------------------------------------------------------ layout converters at the VAE boundary
+template <typename T>
+__global__ __launch_bounds__(256) void video_to_cl_kernel(const T* __restrict__ v, bf16_t* __restrict__ out, int Cv, int Cpad,
+                                                          int64_t npix) {
+    // [Cv, npix] planar -> [npix, Cpad] channels-last, extra channels zero
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256)
+        for (int c = 0; c < Cpad; ++c) out[i * Cpad + c] = (bf16_t)(c < Cv ? (float)v[(int64_t)c * npix + i] : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cl_to_video_kernel(const bf16_t* __restrict__ x, int64_t ld, T* __restrict__ out, int Cv,
+                                                          int64_t npix, int clamp) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256)
+        for (int c = 0; c < Cv; ++c) {
+            float f = (float)x[i * ld + c];
+            if (clamp) f = fminf(fmaxf(f, -1.f), 1.f);
+            out[(int64_t)c * npix + i] = (T)f;
+        }
+}
+
+}  // namespace
+
+extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_frames, const void* w, int64_t ldw,
+                                    const float* bias, const void* resid, void* out, int64_t ldo,
+                                    const wan_conv_params* p, void* stream) {
+    WAN_REQUIRE(x && w && out && p, WAN_ERR_INVALID, "wan_conv_cl: null tensor");
+    WAN_REQUIRE(p->Cin > 0 && p->Cin % 8 == 0, WAN_ERR_UNSUPPORTED, "wan_conv_cl: Cin=%d must be a multiple of 8", p->Cin);
+    WAN_REQUIRE(p->Cout > 0 && p->Cout % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_conv_cl: Cout=%d must be a multiple of 4", p->Cout);
+    WAN_REQUIRE((p->KT == 1 || p->KT == 3) && (p->KH == 1 || p->KH == 3) && (p->KW == 1 || p->KW == 3), WAN_ERR_UNSUPPORTED,
+                "wan_conv_cl: kernel (%d,%d,%d) (extents must be 1 or 3)", p->KT, p->KH, p->KW);
+    WAN_REQUIRE(p->T_in > 0 && p->H_in > 0 && p->W_in > 0 && p->T_out > 0 && p->H_out > 0 && p->W_out > 0, WAN_ERR_INVALID,
+                "wan_conv_cl: bad extents");
+    WAN_REQUIRE(p->st > 0 && p->sh > 0 && p->sw > 0 && p->pt >= 0 && p->ph >= 0 && p->pw >= 0 && p->pt < 4096 && p->ph < 4096,
+                WAN_ERR_INVALID, "wan_conv_cl: bad stride/pad");
+    WAN_REQUIRE(p->H_out * p->sh + 8 < 28000 && p->W_out * p->sw + 8 < 28000, WAN_ERR_UNSUPPORTED,
+                "wan_conv_cl: spatial extent too large for the packed coordinates");
+    WAN_REQUIRE(hist_frames >= 0 && hist_frames <= 2 && (hist_frames == 0 || hist != nullptr), WAN_ERR_INVALID,
+                "wan_conv_cl: hist_frames=%d needs a history buffer", hist_frames);
+    const int ntaps = p->KT * p->KH * p->KW;
+    const int K = ntaps * p->Cin;
+    const int Kpad = (K + BK - 1) / BK * BK;
+    WAN_REQUIRE(ldw >= Kpad && ldw % 8 == 0, WAN_ERR_INVALID, "wan_conv_cl: ldw=%lld must be >= roundup(K=%d,64) and %%8", (long long)ldw, K);
+    WAN_REQUIRE(!p->time_interleave || (p->Cout % 8 == 0), WAN_ERR_INVALID, "wan_conv_cl: interleave needs even channel halves %%4");
+    const int64_t M = (int64_t)p->T_out * p->H_out * p->W_out;
+    WAN_REQUIRE(M < (1LL << 31), WAN_ERR_UNSUPPORTED, "wan_conv_cl: too many output pixels");
+    WAN_REQUIRE(ldo % 4 == 0 && ldo >= (p->time_interleave ? p->Cout / 2 : p->Cout), WAN_ERR_INVALID, "wan_conv_cl: ldo=%lld", (long long)ldo);
+    ConvArgs g;
+    g.x = (const bf16_t*)x; g.hist = (const bf16_t*)hist; g.w = (const bf16_t*)w; g.ldw = ldw; g.bias = bias;
+    g.resid = (const bf16_t*)resid; g.out = (bf16_t*)out; g.ldo = ldo;
+    g.T_in = p->T_in; g.H_in = p->H_in; g.W_in = p->W_in; g.Cin = p->Cin;
+    g.T_out = p->T_out; g.H_out = p->H_out; g.W_out = p->W_out; g.Cout = p->Cout;
+    g.KT = p->KT; g.KH = p->KH; g.KW = p->KW; g.st = p->st; g.sh = p->sh; g.sw = p->sw; g.pt = p->pt; g.ph = p->ph; g.pw = p->pw;
+    g.ups = p->upsample2x ? 1 : 0; g.interleave = p->time_interleave ? 1 : 0; g.hist_frames = hist_frames; g.silu = 0;
+    g.M = (int)M; g.ntaps = ntaps; g.nk = Kpad / BK;
+    g.cin_magic = (unsigned)((0x100000000ULL + p->Cin - 1) / p->Cin);
+    g.tiles_m = (g.M + BM - 1) / BM;
+    hipStream_t s = (hipStream_t)stream;
+    if (p->Cout <= 96) { g.tiles_n = (p->Cout + 95) / 96; return launch_conv<3>(g, s); }
+    if (p->Cout % 192 == 0) { g.tiles_n = p->Cout / 192; return launch_conv<6>(g, s); }
+    g.tiles_n = (p->Cout + 127) / 128;
+    return launch_conv<4>(g, s);
+}
+
+extern "C" wan_status_t wan_rmsnorm_silu_cl(const void* x, const float* gamma, void* out, int64_t rows, int C, int silu,
+                                            void* stream) {
+    WAN_REQUIRE(x && gamma && out, WAN_ERR_INVALID, "wan_rmsnorm_silu_cl: null tensor");
+    WAN_REQUIRE(C > 0 && C % 8 == 0 && C <= 512, WAN_ERR_UNSUPPORTED, "wan_rmsnorm_silu_cl: C=%d (multiple of 8, <= 512)", C);
+    if (rows <= 0) return WAN_OK;
+    hipLaunchKernelGGL(rmsnorm_silu_cl_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, gamma, (bf16_t*)out, rows, C, silu);
+    WAN_CHECK_LAUNCH("wan_rmsnorm_silu_cl");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_softmax_rows(const float* scores, int64_t lds, void* probs_bf16, int64_t ldp, int64_t rows,
+                                         int n, int npad, float scale, void* stream) {
+    WAN_REQUIRE(scores && probs_bf16, WAN_ERR_INVALID, "wan_softmax_rows: null tensor");
+    WAN_REQUIRE(n > 0 && npad >= n && lds >= n && ldp >= npad && rows >= 0, WAN_ERR_INVALID, "wan_softmax_rows: n=%d npad=%d", n, npad);
+    if (rows == 0) return WAN_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, scores, lds,
+                       (bf16_t*)probs_bf16, ldp, n, npad, scale);
+    WAN_CHECK_LAUNCH("wan_softmax_rows");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_video_to_cl(const void* video, int in_dtype, void* out_bf16, int Cv, int Cpad, int64_t npix,
+                                        void* stream) {
+    WAN_REQUIRE(video && out_bf16, WAN_ERR_INVALID, "wan_video_to_cl: null tensor");
+    WAN_REQUIRE(Cv > 0 && Cpad >= Cv && Cpad % 8 == 0 && npix >= 0, WAN_ERR_INVALID, "wan_video_to_cl: Cv=%d Cpad=%d", Cv, Cpad);
+    WAN_REQUIRE(in_dtype == 0 || in_dtype == 1, WAN_ERR_INVALID, "wan_video_to_cl: in_dtype=%d", in_dtype);
+    if (npix == 0) return WAN_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((npix + 255) / 256, 8192);
+    if (in_dtype == 0)
+        hipLaunchKernelGGL(video_to_cl_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)video,
+                           (bf16_t*)out_bf16, Cv, Cpad, npix);
+    else
+        hipLaunchKernelGGL(video_to_cl_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)video,
+                           (bf16_t*)out_bf16, Cv, Cpad, npix);
+    WAN_CHECK_LAUNCH("wan_video_to_cl");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_cl_to_video(const void* x_bf16, int64_t ld, void* out, int out_dtype, int Cv, int64_t npix,
+                                        int clamp, void* stream) {
+    WAN_REQUIRE(x_bf16 && out, WAN_ERR_INVALID, "wan_cl_to_video: null tensor");
+    WAN_REQUIRE(Cv > 0 && ld >= Cv && npix >= 0, WAN_ERR_INVALID, "wan_cl_to_video: Cv=%d ld=%lld", Cv, (long long)ld);
+    WAN_REQUIRE(out_dtype == 0 || out_dtype == 1, WAN_ERR_INVALID, "wan_cl_to_video: out_dtype=%d", out_dtype);
+    if (npix == 0) return WAN_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((npix + 255) / 256, 8192);
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(cl_to_video_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ld,
+                           (float*)out, Cv, npix, clamp);
+    else
+        hipLaunchKernelGGL(cl_to_video_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ld,
+                           (bf16_t*)out, Cv, npix, clamp);
+    WAN_CHECK_LAUNCH("wan_cl_to_video");
+    return WAN_OK;
+}

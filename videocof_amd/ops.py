@@ -217,3 +217,90 @@ def unpatchify(tokens: torch.Tensor, grid: Tuple[int, int, int], patch: Tuple[in
     _lib.check(lib.wan_unpatchify(_p(tokens), tokens.stride(0), _p(out), 0 if out_dtype == torch.float32 else 1,
                                   cout, F, Hp, Wp, pt, ph, pw, _stream()), "wan_unpatchify")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# WanVAE kernels (channels-last bf16 activations [T, H, W, C])
+# ---------------------------------------------------------------------------------------------
+def conv_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, kernel, stride=(1, 1, 1),
+            pad=(0, 0, 0), out_thw=None, hist: Optional[torch.Tensor] = None, upsample2x: bool = False,
+            time_interleave: bool = False, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [T,H,W,Cin]; w bf16 [Cout, Kpad] packed (kt,kh,kw,ci); hist bf16 [n<=2,H,W,Cin] or None.
+    Returns bf16 [T_out,H_out,W_out,Cout] (time_interleave: [2*T_out,H_out,W_out,Cout/2])."""
+    _need(x, torch.bfloat16, "conv_cl.x")
+    _need(w, torch.bfloat16, "conv_cl.w")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("conv_cl.x must be contiguous [T,H,W,C]")
+    T, H, W, Cin = x.shape
+    To, Ho, Wo = out_thw
+    nh = 0
+    if hist is not None:
+        _need(hist, torch.bfloat16, "conv_cl.hist")
+        if not hist.is_contiguous() or tuple(hist.shape[1:]) != (H, W, Cin):
+            raise ValueError("conv_cl.hist must be contiguous [n,H,W,Cin]")
+        nh = hist.shape[0]
+    if bias is not None:
+        _need(bias, torch.float32, "conv_cl.bias")
+    ch = cout // 2 if time_interleave else cout
+    out = torch.empty((2 * To if time_interleave else To), Ho, Wo, ch, device=x.device, dtype=torch.bfloat16)
+    if resid is not None:
+        _need(resid, torch.bfloat16, "conv_cl.resid")
+        if resid.shape != out.shape or not resid.is_contiguous():
+            raise ValueError("conv_cl.resid must match the output")
+    p = _lib.ConvParams(T, H, W, Cin, To, Ho, Wo, cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
+                        pad[0], pad[1], pad[2], int(upsample2x), int(time_interleave))
+    lib = _lib.load()
+    _lib.check(lib.wan_conv_cl(_p(x), _p(hist), nh, _p(w), w.stride(0), _p(bias), _p(resid), _p(out), ch,
+                               ctypes.byref(p), _stream()), "wan_conv_cl")
+    return out
+
+
+def rmsnorm_silu_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool) -> torch.Tensor:
+    _need(x, torch.bfloat16, "rmsnorm_silu_cl.x")
+    _need(gamma, torch.float32, "rmsnorm_silu_cl.gamma")
+    if not x.is_contiguous():
+        raise ValueError("rmsnorm_silu_cl.x must be contiguous")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.wan_rmsnorm_silu_cl(_p(x), _p(gamma), _p(out), x.numel() // C, C, int(silu), _stream()),
+               "wan_rmsnorm_silu_cl")
+    return out
+
+
+def softmax_rows(scores: torch.Tensor, n: int, npad: int, scale: float) -> torch.Tensor:
+    _need(scores, torch.float32, "softmax_rows.scores")
+    rows = scores.shape[0]
+    out = torch.empty(rows, npad, device=scores.device, dtype=torch.bfloat16)
+    lib = _lib.load()
+    _lib.check(lib.wan_softmax_rows(_p(scores), scores.stride(0), _p(out), npad, rows, n, npad, float(scale), _stream()),
+               "wan_softmax_rows")
+    return out
+
+
+def video_to_cl(video: torch.Tensor, cpad: int = 8) -> torch.Tensor:
+    """[C,T,H,W] fp32|bf16 -> bf16 [T,H,W,cpad] (extra channels zero)."""
+    if video.dtype not in (torch.float32, torch.bfloat16):
+        video = video.float()
+    _need(video, video.dtype, "video_to_cl.video")
+    video = video.contiguous()
+    C, T, H, W = video.shape
+    out = torch.empty(T, H, W, cpad, device=video.device, dtype=torch.bfloat16)
+    lib = _lib.load()
+    _lib.check(lib.wan_video_to_cl(_p(video), 0 if video.dtype == torch.float32 else 1, _p(out), C, cpad, T * H * W,
+                                   _stream()), "wan_video_to_cl")
+    return out
+
+
+def cl_to_video(x: torch.Tensor, cv: int, out_dtype: torch.dtype, clamp: bool) -> torch.Tensor:
+    """bf16 [T,H,W,C>=cv] -> [cv,T,H,W] in out_dtype (fp32|bf16), optional clamp to [-1,1]."""
+    _need(x, torch.bfloat16, "cl_to_video.x")
+    if not x.is_contiguous():
+        raise ValueError("cl_to_video.x must be contiguous")
+    T, H, W, C = x.shape
+    dt = out_dtype if out_dtype in (torch.float32, torch.bfloat16) else torch.float32
+    out = torch.empty(cv, T, H, W, device=x.device, dtype=dt)
+    lib = _lib.load()
+    _lib.check(lib.wan_cl_to_video(_p(x), C, _p(out), 0 if dt == torch.float32 else 1, cv, T * H * W, int(clamp),
+                                   _stream()), "wan_cl_to_video")
+    return out.to(out_dtype)
