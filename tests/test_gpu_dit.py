@@ -159,3 +159,41 @@ def test_wider_model_3_heads_vs_oracle():
     cfg = O.DiTConfig(dim=384, ffn_dim=768, num_heads=3, num_layers=3, text_dim=128)
     ref = O.dit_forward(sd, cfg, lat, torch.tensor([650]), ctx, 175, [2], [(2, 3)])
     assert rel_l2(out, ref) < 1e-2 and cosine(out, ref) > 0.9999
+
+
+def test_end_to_end_video_in_video_out():
+    """WanPipeline with the HIP VAE and the HIP DiT: source video -> VAE encode -> CoF latents ->
+    4-step denoise -> decode ground + edit segments, against the same chain built from the CPU oracles
+    (pipeline_wan.py:595-799)."""
+    from oracle.vae_oracle import WanVAEOracle
+    from videocof_amd import AutoencoderKLWan
+    from videocof_amd.weights import deterministic_vae_state_dict
+    vsd = deterministic_vae_state_dict()
+    vae = AutoencoderKLWan()
+    vae.load_state_dict(vsd, device=DEV)
+    sd = deterministic_dit_state_dict(**TINY)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(sd, device=DEV)
+    video = det_uniform("e2e.video", (1, 3, 9, 32, 48), 0.8)           # 9 source frames -> 3 latent frames
+    ctx = [det_uniform("e2e.ctx", (11, 64), 1.0)]
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    pipe = WanPipeline(vae=vae, transformer=m, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    out = pipe(video=video.to(DEV), prompt_embeds=[c.to(DEV) for c in ctx], height=32, width=48, source_frames=9,
+               reasoning_frames=4, num_inference_steps=4, guidance_scale=1.0, shift=3, repeat_rope=True, cot=True,
+               generator=gen, weight_dtype=torch.float32, output_type="numpy", return_dict=True)
+    assert out.ground_videos.shape == (1, 3, 1, 32, 48)        # 1 grounding latent -> 1 frame
+    assert out.edit_videos.shape == (1, 3, 9, 32, 48)          # 3 target latents -> 9 frames
+    assert out.videos.shape == (1, 3, 10, 32, 48)
+    assert 0.0 <= float(out.videos.min()) and float(out.videos.max()) <= 1.0
+    # oracle chain from the SAME noise (the pipeline's latents[:, :, 3:] at step 0 are the generator's draw)
+    gen2 = torch.Generator(device=DEV).manual_seed(7)
+    noise = torch.randn((1, 16, 4, 4, 6), generator=gen2, device=DEV, dtype=torch.float32).cpu()
+    orc = WanVAEOracle(vsd)
+    src = orc.encode(video[0])[:16][None]
+    steps = O.cof_denoise(sd, CFG, src, noise, ctx, 4, 3.0, 3, 1)
+    lat = steps[-1]
+    ref_ground = (orc.decode(lat[0, :, 3:4]) / 2 + 0.5).clamp(0, 1)
+    ref_edit = (orc.decode(lat[0, :, 4:]) / 2 + 0.5).clamp(0, 1)
+    assert rel_l2(out.latents, lat) < 4e-2
+    assert rel_l2(out.ground_videos[0], ref_ground) < 5e-2
+    assert rel_l2(out.edit_videos[0], ref_edit) < 5e-2
