@@ -5,7 +5,8 @@ CSRC  := videocof_amd/csrc
 SRCS  := $(CSRC)/api.cpp $(wildcard $(CSRC)/*.hip)
 HDRS  := $(CSRC)/common.hpp include/wan_hip.h
 LIB   := videocof_amd/libwan_hip.so
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude
+# -fno-honor-nans: lets fmaxf/fminf lower to one v_max/v_min (no canonicalising v_max on MFMA outputs)
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fno-honor-nans -Iinclude
 
 all: $(LIB) tools/kernel_check
 

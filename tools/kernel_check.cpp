@@ -170,9 +170,11 @@ static void check_rmsnorm_rope() {
 }
 
 static void check_gemm() {
-    printf("wan_gemm_bf16\n");
+  for (const char* var : {"1", "2"}) {
+    setenv("WAN_GEMM_VARIANT", var, 1);
+    printf("wan_gemm_bf16 variant %s\n", var);
     struct Shape { int M, N, K; };
-    for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}}) {
+    for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}, Shape{1100, 520, 448}}) {
         const int M = sh.M, N = sh.N, K = sh.K;
         auto A = bf_round(randn((size_t)M * K)), W = bf_round(randn((size_t)N * K, 0.1f));
         auto bias = randn(N, 0.5f);
@@ -235,6 +237,8 @@ static void check_gemm() {
             report("   pad columns untouched", padmax, 0.0, "max_abs");
         }
     }
+  }
+  unsetenv("WAN_GEMM_VARIANT");
 }
 
 static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, const std::vector<float>& v,
@@ -260,7 +264,9 @@ static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, c
 }
 
 static void check_attn() {
-    printf("wan_attention_fwd (+ wan_transpose_bf16)\n");
+  for (const char* var : {"1", "2", "3"}) {
+    setenv("WAN_ATTN_VARIANT", var, 1);
+    printf("wan_attention_fwd variant %s (+ wan_transpose_bf16)\n", var);
     struct Shape { int Lq, Lk, H; float qs; };
     for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}}) {
         const int Lq = sh.Lq, Lk = sh.Lk, H = sh.H, C = H * 128;
@@ -281,6 +287,8 @@ static void check_attn() {
         report(nm, rel_l2(ref, got), 6e-3);
         report("   max abs err", maxabs, 3e-2, "max_abs");
     }
+  }
+  unsetenv("WAN_ATTN_VARIANT");
 }
 
 static void check_layout() {
@@ -308,11 +316,11 @@ static void check_layout() {
 }
 
 // ------------------------------------------------------------------ perf
-static void perf(bool big) {
+static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
     hipDeviceProp_t prop; HIP(hipGetDeviceProperties(&prop, 0));
     printf("device: %s, %d CUs, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
     const int L = big ? 67080 : 32760;
-    {   // LN-modulate + rmsnorm/rope, 14B width
+    if (!attn_only && !gemm_only) {   // LN-modulate + rmsnorm/rope, 14B width
         const int C = 5120;
         Dev<float> x((size_t)L * C), sc(C), sh(C); Dev<bf16> o((size_t)L * C);
         HIP(hipMemset(x.p, 0, x.n * 4)); sc.zero(); sh.zero();
@@ -331,6 +339,7 @@ static void perf(bool big) {
                          {L, 13824, 5120, WAN_EPI_GELU_BF16, "14B ffn.0+gelu"}, {L, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2+resid"},
                          {L, 5120, 5120, WAN_EPI_BF16_T, "14B v proj (T)"}, {L, 1536, 1536, WAN_EPI_BF16, "1.3B proj"},
                          {L, 8960, 1536, WAN_EPI_GELU_BF16, "1.3B ffn.0"}};
+    if (attn_only) gs.clear();
     for (auto g : gs) {
         auto hA = to_bf(randn((size_t)4096 * 64));   // fill with random data (tile the pattern)
         Dev<bf16> A((size_t)g.M * g.K), W((size_t)g.N * g.K);
@@ -340,11 +349,17 @@ static void perf(bool big) {
         const int64_t ldo = g.epi == WAN_EPI_BF16_T ? (g.M + 63) / 64 * 64 : g.N;
         const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
         Dev<char> out(osz); out.zero();
-        double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
-                                                    g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
-        printf("  gemm %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
+        for (int round = 0; round < 2; ++round)
+        for (const char* var : {"1", "2"}) {
+            setenv("WAN_GEMM_VARIANT", var, 1);
+            double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
+                                                        g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
+            printf("  gemm[v%s] %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", var, g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
+        }
+        unsetenv("WAN_GEMM_VARIANT");
     }
     struct A_ { int Lq, Lk, H; const char* what; };
+    if (gemm_only) return;
     std::vector<A_> as = {{8192, 8192, 40, "self L=8k H=40"}, {L, L, big ? 40 : 12, "self full"}, {L, 512, 40, "cross Lk=512"}};
     for (auto s : as) {
         const int C = s.H * 128; const int64_t ldvt = (s.Lk + 63) / 64 * 64;
@@ -352,8 +367,14 @@ static void perf(bool big) {
         Dev<bf16> q((size_t)s.Lq * C), k((size_t)s.Lk * C), vt((size_t)C * ldvt), o((size_t)s.Lq * C);
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(q); fill(k); fill(vt);
-        double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, nullptr)); }, 2, 1);
-        printf("  attn %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
+        for (int round = 0; round < (attn_only ? 2 : 1); ++round)
+        for (const char* var : {"1", "2", "3"}) {
+            if (!attn_only && strcmp(var, "3")) continue;
+            setenv("WAN_ATTN_VARIANT", var, 1);
+            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, nullptr)); }, 3, 1);
+            printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
+        }
+        unsetenv("WAN_ATTN_VARIANT");
     }
 }
 
@@ -366,6 +387,8 @@ int main(int argc, char** argv) {
         check_ln(); check_rmsnorm_rope(); check_gemm(); check_attn(); check_layout();
         printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
     }
+    if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
+    if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
     if (mode == "perf" || mode == "all") perf(big);
     return g_fail ? 1 : 0;
 }

@@ -22,6 +22,8 @@
 // LDS images (LDS-DMA lands lane-linear; the swizzle is applied on the source address and mirrored
 // on the read):  K tile [64 keys][128 d]: 256-B rows, chunk' = chunk ^ (row & 15)
 //                V^T tile [128 d][64 keys]: 128-B rows, chunk' = chunk ^ ((row >> 1) & 7)
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -215,6 +217,289 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// ====================================================================================================
+// v2: software-pipelined variant.  Per KV tile j a wave runs three straight-line segments:
+//   A  finish the row max of S(j) (its per-lane partial max was computed as filler of the previous
+//      tile), one lane^32 exchange, and the rare rescale of O (deferred: while the running max grows
+//      by less than 2^kDeferLog2 the old max is kept and O / l are not touched -- guide T13);
+//   B  the 16 MFMAs of S(j+1) = K(j+1).Q^T in the SAME basic block as the exp2 / convert work of S(j),
+//      so the scheduler interleaves transcendentals with independent matrix work;
+//   C  the 16 MFMAs of O^T += V^T(j).P^T(j).
+// S ping-pongs between two register sets (loop unrolled by two); the ragged last tile is peeled so the
+// steady-state loop carries no masking code.  K ring: 2 slots (K(j+1), K(j+2)); V^T ring: 3 slots.
+//
+// STAGGER (v3): waves w and w+4 of a workgroup share a SIMD.  Waves 4..7 run segment C one barrier
+// interval LATE (interval j: C(j-1), A(j), B(j)) while waves 0..3 run A(j), B(j), C(j).  Between two
+// barriers each SIMD then hosts one wave in the VALU-heavy segment B next to one in the MFMA-only
+// segment C instead of two waves fighting for the same pipe at the same time (the "alternate
+// compute and load/softmax roles" structure of the CDNA4 guide, obtained from program order alone).
+// ====================================================================================================
+constexpr float kDeferLog2 = 6.0f;
+constexpr int kDefaultAttnVariant = 2;   // staggered (3) measured equal to 2 within noise; 2 needs no Q image in LDS
+constexpr int kVRing = 3;
+constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 80 KiB
+constexpr int kLdsBytesV3 = kLdsBytesV2 + kWavesPerWG * 8192;          // + per-wave Q image: 144 KiB
+
+__device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
+    float m0 = fmaxf(s[0][0], s[0][1]), m1 = fmaxf(s[1][0], s[1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) {
+        m0 = fmaxf(m0, fmaxf(s[0][r], s[0][r + 1]));
+        m1 = fmaxf(m1, fmaxf(s[1][r], s[1][r + 1]));
+    }
+    return fmaxf(m0, m1);
+}
+
+template <int VARIANT, bool STAGGER>
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int qblk = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
+    const bf16_t* K = a.k + batch * a.k_bs + head * kD;
+    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt;
+    bf16_t* O = a.o + batch * a.o_bs + head * kD;
+
+    const int qrow = qblk * kQPerWG + wid * kQPerWave + l31;
+    const int qrow_c = min(qrow, a.Lq - 1);
+    // Q fragments: registers (32 VGPRs) or, in the staggered build where the late group also carries
+    // P(t-1) across the barrier, a private lane-linear LDS image per wave (8 x 1 KiB) re-read per tile.
+    constexpr bool kQInLds = STAGGER;
+    bf16x8 qf[kQInLds ? 1 : 8];
+    char* const qlds = smem + kLdsBytesV2 + wid * 8192 + lane * 16;
+    {
+        const bf16_t* qp = Q + (int64_t)qrow_c * a.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+            if constexpr (kQInLds) *reinterpret_cast<bf16x8*>(qlds + ks * 1024) = v;
+            else qf[ks] = v;
+        }
+    }
+    auto q_frag = [&](int ks) -> bf16x8 {
+        if constexpr (kQInLds) return *reinterpret_cast<const bf16x8*>(qlds + ks * 1024);
+        else return qf[ks];
+    };
+
+    char* const kring = smem;                       // K tile t -> slot t & 1
+    char* const vring = smem + 2 * kKTileBytes;     // V^T tile t -> slot t % 3
+    int k_row[2], k_col[2];
+    const bf16_t* v_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wid * 2 + j;
+        const int kr = p * 4 + (lane >> 4);
+        k_row[j] = kr;
+        k_col[j] = ((lane & 15) ^ (kr & 15)) * 8;
+        const int vr = p * 8 + (lane >> 3);
+        const int vc = (lane & 7) ^ ((vr >> 1) & 7);
+        v_src[j] = VT + (int64_t)vr * a.ldvt + vc * 8;
+    }
+    auto stage_k = [&](int t) {
+        const int kv0 = t * kKV;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kr = min(kv0 + k_row[j], a.Lk - 1);
+            glds16(K + (int64_t)kr * a.ldk + k_col[j], kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
+        }
+    };
+    auto stage_v = [&](int t) {
+        const int kv0 = t * kKV;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(v_src[j] + kv0, vring + (t % kVRing) * kVTileBytes + (wid * 2 + j) * 1024);
+    };
+
+    const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int k_rowoff = pi * 256, k_sw = pi & 15;
+    int k_off[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) k_off[ks] = k_rowoff + (((2 * ks + hi) ^ k_sw) << 4);
+    const int v_rowoff = l31 * 128, v_sw = (l31 >> 1) & 7;
+    int v_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v_off[t] = v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
+
+    f32x16 o_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = a.scale_log2e;
+    const int nkv = (a.Lk + kKV - 1) / kKV;
+
+    // segment A: finish the row max, decide / apply the rescale; returns m*c
+    auto seg_a = [&](float mx_part) -> float {
+        const float mx = fmaxf(mx_part, __shfl_xor(mx_part, 32, 64));
+        if (!__all((mx - m_run) * c <= kDeferLog2)) {     // wave-uniform; rare after the first tiles
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+        }
+        return m_run * c;
+    };
+    auto p_group = [&](const f32x16& sv, int t2, float mc, float& psum) -> bf16x8 {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 * t2 + j], c, -mc));
+            psum += p[j];
+        }
+        u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+        return __builtin_bit_cast(bf16x8, w);
+    };
+    // segment C
+    auto pv = [&](int t, const bf16x8 (&pf)[4]) {
+        const char* vb = vring + (t % kVRing) * kVTileBytes;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_off[tt]);
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tt], o_acc[dt], 0, 0, 0);
+            }
+    };
+    // segment B: S(t+1) -> sn from K(t+1), P(t) -> pf from sc
+    auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t, float mc, bf16x8 (&pf)[4]) {
+        const char* kb = kring + ((t + 1) & 1) * kKTileBytes;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 qv = q_frag(ks);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * 256 + k_off[ks]);
+                sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
+            }
+            if ((ks & 1) == 1) pf[ks >> 1] = p_group(sc[ks >> 2], (ks >> 1) & 1, mc, psum);
+        }
+        l_run += psum;
+    };
+    auto prefetch = [&](int t) {        // issued at the top of interval t
+        if (t + 2 < nkv) stage_k(t + 2);    // slot of K(t), last read in interval t-1
+        stage_v(t + 1);                      // slot of V(t-2), last read (by the late group) in interval t-1
+    };
+    auto fence = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    };
+
+    stage_k(0);
+    stage_v(0);
+    if (nkv > 1) stage_k(1);
+    fence();
+    f32x16 s0[2], s1[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kring + kt * 32 * 256 + k_off[ks]);
+            s0[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q_frag(ks), s0[kt], 0, 0, 0);
+        }
+    }
+    float mx_part = rowmax32(s0);
+    __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
+
+    const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
+    const bool late = STAGGER && wid >= kWavesPerWG / 2;
+    bf16x8 pf[4];
+    int it = 0;
+    bool last_in_s1 = false;
+    if (!late) {
+        // ---- early group (or every wave when not staggered): A(t) B(t) C(t) per interval
+        for (; it + 2 <= nfull; it += 2) {
+            prefetch(it);
+            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
+            fence();
+            prefetch(it + 1);
+            { const float mc = seg_a(mx_part); seg_b(s1, s0, it + 1, mc, pf); pv(it + 1, pf); mx_part = rowmax32(s0); }
+            fence();
+        }
+        if (it < nfull) {
+            prefetch(it);
+            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
+            fence();
+            ++it;
+            last_in_s1 = true;
+        }
+    } else {
+        // ---- late group: C(t-1) A(t) B(t) per interval; P(t-1) lives in pf across the barrier
+        for (; it + 2 <= nfull; it += 2) {
+            prefetch(it);
+            if (it > 0) pv(it - 1, pf);
+            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); mx_part = rowmax32(s1); }
+            fence();
+            prefetch(it + 1);
+            pv(it, pf);
+            { const float mc = seg_a(mx_part); seg_b(s1, s0, it + 1, mc, pf); mx_part = rowmax32(s0); }
+            fence();
+        }
+        if (it < nfull) {
+            prefetch(it);
+            if (it > 0) pv(it - 1, pf);
+            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); mx_part = rowmax32(s1); }
+            fence();
+            ++it;
+            last_in_s1 = true;
+        }
+        if (nfull > 0) pv(nfull - 1, pf);       // drain the pending P.V
+    }
+    // ---- peeled last tile (it == nkv-1): mask keys >= Lk, no prefetch, no next S
+    {
+        f32x16 sl[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) sl[kt] = last_in_s1 ? s1[kt] : s0[kt];
+        const int kv0 = it * kKV;
+        if (kv0 + kKV > a.Lk) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= a.Lk) sl[kt][r] = -INFINITY;
+                }
+            mx_part = rowmax32(sl);
+        }
+        const float mc = seg_a(mx_part);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) pf[2 * kt + t2] = p_group(sl[kt], t2, mc, psum);
+        l_run += psum;
+        pv(it, pf);
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.Lq) {
+        bf16_t* op = O + (int64_t)qrow * a.ldo + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w = {pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv),
+                           pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv)};
+                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ [rows, cols] -> [cols, ldt]
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld,
                                                              bf16_t* __restrict__ out, int64_t ldt,
@@ -261,14 +546,16 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (Lq == 0) return WAN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e != hipSuccess) {
-            wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
-            return WAN_ERR_LAUNCH;
+        const void* fns[6] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
+                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
+                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>)};
+        for (int i = 0; i < 6; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               i < 2 ? kLdsBytes : (i < 4 ? kLdsBytesV2 : kLdsBytesV3));
+            if (e != hipSuccess) {
+                wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
+                return WAN_ERR_LAUNCH;
+            }
         }
         attr_set = true;
     }
@@ -280,10 +567,21 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
     a.scale_log2e = softmax_scale * 1.4426950408889634f;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
-    if (Lk > 1024)
-        hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    // developer A/B switch (not a product option): WAN_ATTN_VARIANT = 1 plain, 2 pipelined, 3 pipelined + staggered
+    const char* ev = getenv("WAN_ATTN_VARIANT");
+    const int variant = ev ? atoi(ev) : kDefaultAttnVariant;
+    const bool self = Lk > 1024;
+    if (variant == 1) {
+        if (self) hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, st, a);
+        else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, st, a);
+    } else if (variant == 2) {
+        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
+    } else {
+        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV3, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV3, st, a);
+    }
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;
 }

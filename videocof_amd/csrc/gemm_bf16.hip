@@ -17,7 +17,14 @@
 // Workgroup -> tile mapping is XCD-aware: block b runs on XCD b%8 (observed, speed only); each XCD
 // walks a contiguous slab of the tile sequence ordered as 8(M) x all(N) groups so that the 64 tiles
 // resident on an XCD share 8 A-panels and 8 W-panels through its private L2.
+#include <stdlib.h>
+
 #include "common.hpp"
+
+// gemm_bf16_256.hip: the 256 x 256 phased kernel used for large shapes
+wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                               void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                               const float* gate, int64_t rows_per_batch, hipStream_t s);
 
 namespace {
 
@@ -240,6 +247,14 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
     WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
                 "wan_gemm_bf16: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
     if (M == 0) return WAN_OK;
+    {   // large shapes -> 256^2 phased kernel.  WAN_GEMM_VARIANT=1|2 is a developer A/B switch, not a product option.
+        const char* ev = getenv("WAN_GEMM_VARIANT");
+        const int variant = ev ? atoi(ev) : 0;
+        const bool big = M >= 1024 && N >= 256;
+        if (variant == 2 || (variant == 0 && big))
+            return wan_gemm_bf16_256(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch,
+                                     (hipStream_t)stream);
+    }
     GemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
