@@ -170,8 +170,9 @@ static void check_rmsnorm_rope() {
 }
 
 static void check_gemm() {
-  for (const char* var : {"1", "2"}) {
-    setenv("WAN_GEMM_VARIANT", var, 1);
+  for (const char* var : {"1", "2", "2p4"}) {
+    setenv("WAN_GEMM_VARIANT", var[0] == '1' ? "1" : "2", 1);
+    setenv("WAN_GEMM_PHASES", strlen(var) > 1 ? "4" : "2", 1);
     printf("wan_gemm_bf16 variant %s\n", var);
     struct Shape { int M, N, K; };
     for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}, Shape{1100, 520, 448}}) {
@@ -238,7 +239,7 @@ static void check_gemm() {
         }
     }
   }
-  unsetenv("WAN_GEMM_VARIANT");
+  unsetenv("WAN_GEMM_VARIANT"); unsetenv("WAN_GEMM_PHASES");
 }
 
 static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, const std::vector<float>& v,
@@ -264,7 +265,7 @@ static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, c
 }
 
 static void check_attn() {
-  for (const char* var : {"1", "2", "3"}) {
+  for (const char* var : {"1", "2"}) {
     setenv("WAN_ATTN_VARIANT", var, 1);
     printf("wan_attention_fwd variant %s (+ wan_transpose_bf16)\n", var);
     struct Shape { int Lq, Lk, H; float qs; };
@@ -350,13 +351,14 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
         Dev<char> out(osz); out.zero();
         for (int round = 0; round < 2; ++round)
-        for (const char* var : {"1", "2"}) {
-            setenv("WAN_GEMM_VARIANT", var, 1);
+        for (const char* var : {"1", "2", "2p4"}) {
+            setenv("WAN_GEMM_VARIANT", var[0] == '1' ? "1" : "2", 1);
+            setenv("WAN_GEMM_PHASES", strlen(var) > 1 ? "4" : "2", 1);
             double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
                                                         g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
             printf("  gemm[v%s] %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", var, g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
         }
-        unsetenv("WAN_GEMM_VARIANT");
+        unsetenv("WAN_GEMM_VARIANT"); unsetenv("WAN_GEMM_PHASES");
     }
     struct A_ { int Lq, Lk, H; const char* what; };
     if (gemm_only) return;
@@ -368,8 +370,8 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(q); fill(k); fill(vt);
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
-        for (const char* var : {"1", "2", "3"}) {
-            if (!attn_only && strcmp(var, "3")) continue;
+        for (const char* var : {"1", "2"}) {
+            if (!attn_only && strcmp(var, "2")) continue;
             setenv("WAN_ATTN_VARIANT", var, 1);
             double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);

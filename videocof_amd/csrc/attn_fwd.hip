@@ -226,19 +226,20 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 //      so the scheduler interleaves transcendentals with independent matrix work;
 //   C  the 16 MFMAs of O^T += V^T(j).P^T(j).
 // S ping-pongs between two register sets (loop unrolled by two); the ragged last tile is peeled so the
-// steady-state loop carries no masking code.  K ring: 2 slots (K(j+1), K(j+2)); V^T ring: 3 slots.
+// steady-state loop carries no masking code.  K ring: 2 slots (K(j+1), K(j+2)); V^T ring: 2 slots.
 //
-// STAGGER (v3): waves w and w+4 of a workgroup share a SIMD.  Waves 4..7 run segment C one barrier
-// interval LATE (interval j: C(j-1), A(j), B(j)) while waves 0..3 run A(j), B(j), C(j).  Between two
-// barriers each SIMD then hosts one wave in the VALU-heavy segment B next to one in the MFMA-only
-// segment C instead of two waves fighting for the same pipe at the same time (the "alternate
-// compute and load/softmax roles" structure of the CDNA4 guide, obtained from program order alone).
+// Measured alternatives that did NOT pay on MI355X (round 1, same harness, L = 67 080, 40 heads; kept out
+// of the source): (a) waves 4..7 running segment C one barrier late so every SIMD pairs a softmax
+// segment with an MFMA-only segment: 1076 vs 1080 TFLOP/s; (b) the 4-barrier "load | MFMA cluster |
+// softmax+load | MFMA cluster" phasing that gives the GEMM +30 %: 929 TFLOP/s; (c) 4-slot rings with one
+// barrier per tile pair: 1080 vs 1120.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
+// ~1200 VALU-pipe cycles against 1024 MFMA-pipe cycles -- with two waves per SIMD the softmax VALU
+// work, not the matrix pipe, bounds the loop, so re-arranging who waits for whom moves nothing.
 // ====================================================================================================
 constexpr float kDeferLog2 = 6.0f;
-constexpr int kDefaultAttnVariant = 2;   // staggered (3) measured equal to 2 within noise; 2 needs no Q image in LDS
-constexpr int kVRing = 3;
-constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 80 KiB
-constexpr int kLdsBytesV3 = kLdsBytesV2 + kWavesPerWG * 8192;          // + per-wave Q image: 144 KiB
+constexpr int kDefaultAttnVariant = 2;
+constexpr int kVRing = 2;
+constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 64 KiB
 
 __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
     float m0 = fmaxf(s[0][0], s[0][1]), m1 = fmaxf(s[1][0], s[1][1]);
@@ -250,7 +251,7 @@ __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
     return fmaxf(m0, m1);
 }
 
-template <int VARIANT, bool STAGGER>
+template <int VARIANT>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -266,24 +267,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 
     const int qrow = qblk * kQPerWG + wid * kQPerWave + l31;
     const int qrow_c = min(qrow, a.Lq - 1);
-    // Q fragments: registers (32 VGPRs) or, in the staggered build where the late group also carries
-    // P(t-1) across the barrier, a private lane-linear LDS image per wave (8 x 1 KiB) re-read per tile.
-    constexpr bool kQInLds = STAGGER;
-    bf16x8 qf[kQInLds ? 1 : 8];
-    char* const qlds = smem + kLdsBytesV2 + wid * 8192 + lane * 16;
+    bf16x8 qf[8];
     {
         const bf16_t* qp = Q + (int64_t)qrow_c * a.ldq + hi * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-            if constexpr (kQInLds) *reinterpret_cast<bf16x8*>(qlds + ks * 1024) = v;
-            else qf[ks] = v;
-        }
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
     }
-    auto q_frag = [&](int ks) -> bf16x8 {
-        if constexpr (kQInLds) return *reinterpret_cast<const bf16x8*>(qlds + ks * 1024);
-        else return qf[ks];
-    };
+    auto q_frag = [&](int ks) -> bf16x8 { return qf[ks]; };
 
     char* const kring = smem;                       // K tile t -> slot t & 1
     char* const vring = smem + 2 * kKTileBytes;     // V^T tile t -> slot t % 3
@@ -390,7 +380,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     };
     auto prefetch = [&](int t) {        // issued at the top of interval t
         if (t + 2 < nkv) stage_k(t + 2);    // slot of K(t), last read in interval t-1
-        stage_v(t + 1);                      // slot of V(t-2), last read (by the late group) in interval t-1
+        stage_v(t + 1);                      // slot of V(t-1), last read in interval t-1
     };
     auto fence = [&]() {
         __builtin_amdgcn_s_waitcnt(0);
@@ -416,48 +406,23 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
 
     const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
-    const bool late = STAGGER && wid >= kWavesPerWG / 2;
     bf16x8 pf[4];
     int it = 0;
     bool last_in_s1 = false;
-    if (!late) {
-        // ---- early group (or every wave when not staggered): A(t) B(t) C(t) per interval
-        for (; it + 2 <= nfull; it += 2) {
-            prefetch(it);
-            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
-            fence();
-            prefetch(it + 1);
-            { const float mc = seg_a(mx_part); seg_b(s1, s0, it + 1, mc, pf); pv(it + 1, pf); mx_part = rowmax32(s0); }
-            fence();
-        }
-        if (it < nfull) {
-            prefetch(it);
-            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
-            fence();
-            ++it;
-            last_in_s1 = true;
-        }
-    } else {
-        // ---- late group: C(t-1) A(t) B(t) per interval; P(t-1) lives in pf across the barrier
-        for (; it + 2 <= nfull; it += 2) {
-            prefetch(it);
-            if (it > 0) pv(it - 1, pf);
-            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); mx_part = rowmax32(s1); }
-            fence();
-            prefetch(it + 1);
-            pv(it, pf);
-            { const float mc = seg_a(mx_part); seg_b(s1, s0, it + 1, mc, pf); mx_part = rowmax32(s0); }
-            fence();
-        }
-        if (it < nfull) {
-            prefetch(it);
-            if (it > 0) pv(it - 1, pf);
-            { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); mx_part = rowmax32(s1); }
-            fence();
-            ++it;
-            last_in_s1 = true;
-        }
-        if (nfull > 0) pv(nfull - 1, pf);       // drain the pending P.V
+    for (; it + 2 <= nfull; it += 2) {
+        prefetch(it);
+        { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
+        fence();
+        prefetch(it + 1);
+        { const float mc = seg_a(mx_part); seg_b(s1, s0, it + 1, mc, pf); pv(it + 1, pf); mx_part = rowmax32(s0); }
+        fence();
+    }
+    if (it < nfull) {
+        prefetch(it);
+        { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
+        fence();
+        ++it;
+        last_in_s1 = true;
     }
     // ---- peeled last tile (it == nkv-1): mask keys >= Lk, no prefetch, no next S
     {
@@ -546,12 +511,10 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (Lq == 0) return WAN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[6] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
-                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
-                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>)};
-        for (int i = 0; i < 6; ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               i < 2 ? kLdsBytes : (i < 4 ? kLdsBytesV2 : kLdsBytesV3));
+        const void* fns[4] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
+                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1>)};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? kLdsBytes : kLdsBytesV2);
             if (e != hipSuccess) {
                 wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
                 return WAN_ERR_LAUNCH;
@@ -568,19 +531,16 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.scale_log2e = softmax_scale * 1.4426950408889634f;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
-    // developer A/B switch (not a product option): WAN_ATTN_VARIANT = 1 plain, 2 pipelined, 3 pipelined + staggered
+    // developer A/B switch (not a product option): WAN_ATTN_VARIANT = 1 plain, 2 software-pipelined (default)
     const char* ev = getenv("WAN_ATTN_VARIANT");
     const int variant = ev ? atoi(ev) : kDefaultAttnVariant;
     const bool self = Lk > 1024;
     if (variant == 1) {
         if (self) hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, st, a);
         else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, st, a);
-    } else if (variant == 2) {
-        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
     } else {
-        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV3, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV3, st, a);
+        if (self) hipLaunchKernelGGL(attn_fwd_v2_kernel<0>, grid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL(attn_fwd_v2_kernel<1>, grid, block, kLdsBytesV2, st, a);
     }
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;

@@ -20,10 +20,13 @@
 // XOR swizzle as the 128^2 kernel.  K tile t+1 streams into the other buffer during phases 2
 // and 3 of tile t (regions whose last reader finished two barriers earlier) and is waited for before
 // the barrier that closes tile t for BOTH groups (the late group waits one segment earlier).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
 
+constexpr int kDefaultPhases = 2;
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int kThreads = 512;
 constexpr int kHalfBytes = 128 * BK * 2;       // 16 KiB: 128 rows x 64 k
@@ -62,7 +65,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn)
 #define RAW_BARRIER() __builtin_amdgcn_s_barrier()
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI>
+template <int EPI, int PHASES>
 __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2];      // current M-quadrant: 4 m-tiles x 2 kk
-    bf16x8 wf[2][2];      // current N-quadrant: 2 n-tiles x 2 kk
+    bf16x8 af[4][2];                        // current M-half: 4 m-tiles x 2 kk
+    bf16x8 wf[PHASES == 4 ? 2 : 4][2];      // 4-phase: current N-quadrant (2 n-tiles); 2-phase: all 4 n-tiles
 
     auto load_a = [&](const char* sb, int mi) {
 #pragma unroll
@@ -148,6 +151,33 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    auto load_w_all = [&](const char* sb) {
+        if constexpr (PHASES == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    wf[j][kk] = *reinterpret_cast<const bf16x8*>(sb + w_base + j * 2048 + off_kk[kk]);
+        }
+    };
+    auto mma_half = [&](int mi) {           // 32 MFMAs: 4 m-tiles x 4 n-tiles x 2 kk
+        if constexpr (PHASES == 2) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (kTransposed)
+                            acc[mi * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], wf[j][kk], acc[mi * 4 + i][j], 0, 0, 0);
+                        else
+                            acc[mi * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], acc[mi * 4 + i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
     const int nk = g.K / BK;
     stage_a(0, 0);
     stage_w(0, 0);
@@ -155,6 +185,32 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     RAW_BARRIER();
     if (wr == 1) RAW_BARRIER();          // stagger: the second wave group runs one barrier late
 
+    if constexpr (PHASES == 2) {
+        // Two 32-MFMA phases per K tile (one per 64-row half of the wave tile): half the barriers per MFMA.
+        // Next tile: W streams in from L1 (its region was last read four intervals earlier); A is issued in
+        // the interval after the late group's last A read has been waited for (early group: top of M1,
+        // late group: L1), and every wave drains before the barrier that closes the tile.
+        const bool late = wr == 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sb = smem + (kt & 1) * kBufBytes;
+            const int nxt = (kt & 1) ^ 1;
+            const bool more = kt + 1 < nk;
+            const int koff = (kt + 1) * BK;
+            load_w_all(sb);
+            load_a(sb, 0);
+            if (more) { stage_w(nxt, koff); if (late) stage_a(nxt, koff); }
+            SCHED_FENCE(); RAW_BARRIER(); WAIT_LGKM0(); SCHED_FENCE();
+            if (more && !late) stage_a(nxt, koff);
+            mma_half(0);
+            SCHED_FENCE(); RAW_BARRIER(); SCHED_FENCE();
+            load_a(sb, 1);
+            if (late) WAIT_VM0();
+            SCHED_FENCE(); RAW_BARRIER(); WAIT_LGKM0(); SCHED_FENCE();
+            mma_half(1);
+            if (!late) WAIT_VM0();
+            SCHED_FENCE(); RAW_BARRIER(); SCHED_FENCE();
+        }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const char* sb = smem + (kt & 1) * kBufBytes;
         const int nxt = (kt & 1) ^ 1;
@@ -250,11 +306,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     }
 }
 
-template <int EPI>
+template <int EPI, int PHASES>
 wan_status_t launch256(const GemmArgs& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, PHASES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16(256): cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
@@ -262,7 +318,7 @@ wan_status_t launch256(const GemmArgs& g, hipStream_t s) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), kLdsBytes, s, g);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, PHASES>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), kLdsBytes, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16(256)");
     return WAN_OK;
 }
@@ -278,12 +334,16 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    const char* ev = getenv("WAN_GEMM_PHASES");          // developer A/B switch
+    const int phases = ev ? atoi(ev) : kDefaultPhases;
+#define WAN_G256(E) (phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
     switch (epilogue) {
-        case WAN_EPI_BF16: return launch256<WAN_EPI_BF16>(g, s);
-        case WAN_EPI_GELU_BF16: return launch256<WAN_EPI_GELU_BF16>(g, s);
-        case WAN_EPI_F32: return launch256<WAN_EPI_F32>(g, s);
-        case WAN_EPI_RESID_F32: return launch256<WAN_EPI_RESID_F32>(g, s);
-        case WAN_EPI_BF16_T: return launch256<WAN_EPI_BF16_T>(g, s);
+        case WAN_EPI_BF16: return WAN_G256(WAN_EPI_BF16);
+        case WAN_EPI_GELU_BF16: return WAN_G256(WAN_EPI_GELU_BF16);
+        case WAN_EPI_F32: return WAN_G256(WAN_EPI_F32);
+        case WAN_EPI_RESID_F32: return WAN_G256(WAN_EPI_RESID_F32);
+        case WAN_EPI_BF16_T: return WAN_G256(WAN_EPI_BF16_T);
         default: wan_set_error("wan_gemm_bf16: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
     }
+#undef WAN_G256
 }
