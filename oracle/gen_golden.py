@@ -168,6 +168,29 @@ def main():
         steps.append(latents)
     save("dit_g8b_cfg_loop", neg=neg[0], steps=torch.stack(steps))
 
+    # (12) merge_lora of the reference (lora_utils.py:371-500) in the three key styles it accepts
+    lu = ns.load_lora_utils()
+    r = 4
+    lora = {
+        "diffusion_model.blocks.0.self_attn.q.lora_down.weight": det_uniform("l.a.down", (r, C), 0.3),
+        "diffusion_model.blocks.0.self_attn.q.lora_up.weight": det_uniform("l.a.up", (C, r), 0.3),
+        "diffusion_model.blocks.0.self_attn.q.alpha": torch.tensor(2.0),
+        "blocks.1.ffn.0.lora_A.default.weight": det_uniform("l.b.down", (r, C), 0.3),
+        "blocks.1.ffn.0.lora_B.default.weight": det_uniform("l.b.up", (TINY["ffn_dim"], r), 0.3),
+        "lora_unet__blocks_1_cross_attn_o.lora_down.weight": det_uniform("l.c.down", (r, C), 0.3),
+        "lora_unet__blocks_1_cross_attn_o.lora_up.weight": det_uniform("l.c.up", (C, r), 0.3),
+        "lora_unet__blocks_1_cross_attn_o.alpha": torch.tensor(8.0),
+        "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight": torch.zeros(r, 8),   # must be ignored
+    }
+    model12 = build_ref_model(ns, sd)
+    import types
+    pipe = types.SimpleNamespace(transformer=model12)
+    lu.merge_lora(pipe, None, 0.75, device="cpu", dtype=torch.float32, state_dict=dict(lora), transformer_only=True)
+    msd = model12.state_dict()
+    save("dit_g12_lora", multiplier=0.75,
+         q=msd["blocks.0.self_attn.q.weight"], ffn0=msd["blocks.1.ffn.0.weight"], o=msd["blocks.1.cross_attn.o.weight"],
+         untouched=msd["blocks.0.self_attn.k.weight"])
+
     # (11) sequence-parallel RoPE slice of the reference (non-CoF), rank r of 2
     xs_ = det_uniform("g11.x", (1, L // 2, H, D), 1.0)
     outs = []

@@ -136,6 +136,8 @@ def _install_diffusers_stubs() -> None:
     _mod("diffusers.loaders.single_file_model", FromOriginalModelMixin=FromOriginalModelMixin)
     _mod("diffusers.models")
     _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.models.lora", LoRACompatibleConv=type("LoRACompatibleConv", (nn.Conv2d,), {}),
+         LoRACompatibleLinear=type("LoRACompatibleLinear", (nn.Linear,), {}))
     _mod("diffusers.models.autoencoders")
     _mod("diffusers.models.autoencoders.vae", DecoderOutput=DecoderOutput,
          DiagonalGaussianDistribution=DiagonalGaussianDistribution)
@@ -213,5 +215,9 @@ def load_reference(sp_rank: int | None = None, sp_size: int | None = None) -> Si
     if sp_rank is not None:
         ns.wan_xfuser = _load_by_path("videox_fun.dist.wan_xfuser",
                                       "videox_fun/dist/wan_xfuser.py")
+
+    def lora_utils():
+        return _load_by_path("videox_fun.utils.lora_utils", "videox_fun/utils/lora_utils.py")
+    ns.load_lora_utils = lora_utils
     _CACHE[key] = ns
     return ns

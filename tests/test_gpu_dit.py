@@ -197,3 +197,32 @@ def test_end_to_end_video_in_video_out():
     assert rel_l2(out.latents, lat) < 4e-2
     assert rel_l2(out.ground_videos[0], ref_ground) < 5e-2
     assert rel_l2(out.edit_videos[0], ref_edit) < 5e-2
+
+
+def test_from_pretrained_safetensors_and_lora(tmp_path, model):
+    """Checkpoint ingest as fast_infer.py does it (wan_transformer3d.py:1157-1299): config.json +
+    sharded *.safetensors with the reference's key names; then a LoRA merged on the state dict."""
+    import json
+    from safetensors.torch import save_file
+    from videocof_amd.lora_utils import merge_lora_state_dict
+    sd = deterministic_dit_state_dict(**TINY)
+    keys = sorted(sd)
+    save_file({k: sd[k].contiguous() for k in keys[: len(keys) // 2]}, str(tmp_path / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[len(keys) // 2:]}, str(tmp_path / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    json.dump(dict(model_type="t2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, in_dim=16,
+                   out_dim=16, freq_dim=256, eps=1e-6, _class_name="WanTransformer3DModel", unknown_key=1),
+              open(tmp_path / "config.json", "w"))
+    m = WanTransformer3DModel.from_pretrained(str(tmp_path))
+    lat = det_uniform("fp.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("fp.ctx", (9, 64), 1.0).to(DEV)]
+    t = torch.tensor([321], device=DEV)
+    assert torch.equal(m(lat, t, ctx, 48), model(lat, t, ctx, 48))
+    lora = {"diffusion_model.blocks.0.self_attn.q.lora_down.weight": det_uniform("fp.d", (4, 256), 0.3),
+            "diffusion_model.blocks.0.self_attn.q.lora_up.weight": det_uniform("fp.u", (256, 4), 0.3)}
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    assert merge_lora_state_dict(sd2, lora, 1.0, device=DEV) == 1
+    m2 = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m2.load_state_dict(sd2, device=DEV)
+    out = m2(lat, t, ctx, 48)
+    ref = O.dit_forward(sd2, CFG, lat.cpu(), t.cpu(), [c.cpu() for c in ctx], 48)
+    assert rel_l2(out, ref) < 1e-2 and not torch.equal(out, model(lat, t, ctx, 48))

@@ -350,10 +350,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     // segment C
     auto pv = [&](int t, const bf16x8 (&pf)[4]) {
         const char* vb = vring + (t % kVRing) * kVTileBytes;
+        // tt outer: four independent accumulator chains round-robin (no back-to-back dependent MFMAs)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
+            for (int dt = 0; dt < 4; ++dt) {
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_off[tt]);
                 o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tt], o_acc[dt], 0, 0, 0);
             }

@@ -1,0 +1,93 @@
+"""LoRA merge for reference-format checkpoints (the step before the hot path).
+
+The reference merges LoRAs into the dense ``nn.Linear`` weights before inference
+(``merge_lora``, ``videox_fun/utils/lora_utils.py:371-500``; three merges in
+``fast_infer.py:366-386``): ``W += multiplier * (alpha / r) * up @ down``.  The kernels of this
+package only ever see dense weights, so the merge happens on the *state dict* (reference key names)
+before ``WanTransformer3DModel.load_state_dict`` packs it:
+
+    sd = load_file("diffusion_pytorch_model.safetensors")
+    merge_lora_state_dict(sd, load_file("videocof.safetensors"), 1.0, device="cuda")
+    model.load_state_dict(sd)
+
+Key conventions accepted (the renaming rules of lora_utils.py:379-394):
+  * ComfyUI/Wan:  ``diffusion_model.blocks.0.self_attn.q.lora_down.weight`` (+ ``lora_up``, ``alpha``)
+  * PEFT:         ``blocks.0.self_attn.q.lora_A.default.weight`` / ``lora_B.default.weight``
+  * kohya:        ``lora_unet__blocks_0_self_attn_q.lora_down.weight``
+Text-encoder entries (``lora_te``) and entries without both matrices are skipped, as the reference does
+(:408-411, :472-476).  The matmul runs in fp32 on ``device`` (a one-off weight preparation, not a
+per-token op) and the result is stored back in the weight's dtype.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, Optional
+
+import torch
+
+__all__ = ["merge_lora_state_dict", "unmerge_lora_state_dict"]
+
+
+def _module_index(sd: Dict[str, torch.Tensor]) -> Dict[str, str]:
+    """underscore-flattened module path -> dotted module path, for every 2-D+ '.weight' entry."""
+    idx = {}
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() >= 2:
+            mod = k[:-len(".weight")]
+            idx[mod.replace(".", "_")] = mod
+    return idx
+
+
+def _normalise(key: str):
+    """LoRA tensor name -> (flattened module name, element) or None."""
+    if "lora_te" in key:
+        return None
+    k = key
+    if k.startswith("lora_unet__"):
+        k = k[len("lora_unet__"):]
+    elif k.startswith("lora_unet_"):
+        k = k[len("lora_unet_"):]
+    k = k.replace("diffusion_model.", "")
+    k = k.replace(".lora_A.default.", ".lora_down.").replace(".lora_B.default.", ".lora_up.")
+    k = k.replace(".lora_A.", ".lora_down.").replace(".lora_B.", ".lora_up.")
+    for elem in ("lora_down.weight", "lora_up.weight", "alpha"):
+        if k.endswith("." + elem):
+            return k[:-len(elem) - 1].replace(".", "_"), elem
+    return None
+
+
+@torch.no_grad()
+def merge_lora_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], multiplier: float = 1.0,
+                          device: Optional[str] = None) -> int:
+    """In-place ``sd[w] += multiplier * alpha/r * up @ down`` for every LoRA pair that resolves to a
+    weight of ``sd``.  Returns the number of merged layers."""
+    index = _module_index(sd)
+    groups = defaultdict(dict)
+    for key, val in lora_sd.items():
+        n = _normalise(key)
+        if n is not None:
+            groups[n[0]][n[1]] = val
+    merged = 0
+    for flat, elems in groups.items():
+        mod = index.get(flat)
+        if mod is None or "lora_up.weight" not in elems or "lora_down.weight" not in elems:
+            continue
+        w = sd[mod + ".weight"]
+        dev = torch.device(device) if device is not None else w.device
+        up = elems["lora_up.weight"].to(dev, torch.float32)
+        down = elems["lora_down.weight"].to(dev, torch.float32)
+        scale = float(elems["alpha"]) / up.shape[1] if "alpha" in elems else 1.0            # :479-482
+        if up.dim() == 4:
+            delta = torch.mm(up.flatten(1), down.flatten(1)).reshape(w.shape)
+        else:
+            delta = torch.mm(up, down)
+        if delta.shape != w.shape:
+            raise ValueError(f"LoRA for {mod}: delta {tuple(delta.shape)} does not match weight {tuple(w.shape)}")
+        sd[mod + ".weight"] = (w.to(dev, torch.float32) + multiplier * scale * delta).to(w.dtype).to(w.device)
+        merged += 1
+    return merged
+
+
+def unmerge_lora_state_dict(sd, lora_sd, multiplier: float = 1.0, device: Optional[str] = None) -> int:
+    """Inverse of merge_lora_state_dict (lora_utils.py:503-620)."""
+    return merge_lora_state_dict(sd, lora_sd, -multiplier, device)
