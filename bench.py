@@ -64,17 +64,19 @@ def pmc_traffic(workload, shards):
     bench14b_1step_pmc_summary.json; FETCH_SIZE x2 per the gfx950 correction of the microarch guide).
     Counters cannot be read live from inside the process, so this is null for shapes that were not profiled."""
     if workload != "14b-cof" or shards != 1:
-        return None
+        return None, None
     path = os.path.join(ROOT, "profiles", "r01", "bench14b_1step_pmc_summary.json")
     try:
         with open(path) as f:
             d = json.load(f)["attn_fwd_kernel"]
         fetch = d["fetch"]["avg_counter_KB"] * 1024 * 2
         write = d["write"]["avg_counter_KB"] * 1024
-        return {"bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write,
-                "algorithmic_bytes": 4 * 67080 * 5120 * 2, "source": "profiles/r01/bench14b_1step_pmc_summary.json"}
+        return fetch + write, {"fetch_bytes_x2_corrected": fetch, "write_bytes": write,
+                               "algorithmic_bytes": 4 * 67080 * 5120 * 2,
+                               "note": "L2->fabric requests; includes Infinity-Cache hits (K/V re-streamed per query block)",
+                               "source": "profiles/r01/bench14b_1step_pmc_summary.json"}
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(wl, budget_s=25.0):
@@ -220,9 +222,10 @@ def main():
         Lq = model._last_attn_rows
         flop = 4.0 * Lq * Lk * heads_local * 128
         ach = flop / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1)
         roof = {"kernel": "attn_fwd_v2_kernel<0> (self-attention)", "bound": "mfma", "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": pmc_traffic(args.workload, world if sp else 1), "launches": len(ms),
+                "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
 
     units = world if (world > 1 and not sp) else 1            # dp: every rank denoises its own video
