@@ -232,7 +232,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 // of the source): (a) waves 4..7 running segment C one barrier late so every SIMD pairs a softmax
 // segment with an MFMA-only segment: 1076 vs 1080 TFLOP/s; (b) the 4-barrier "load | MFMA cluster |
 // softmax+load | MFMA cluster" phasing that gives the GEMM +30 %: 929 TFLOP/s; (c) 4-slot rings with one
-// barrier per tile pair: 1080 vs 1120.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
+// barrier per tile pair: 1080 vs 1120; (d) v_pk_fma_f32 / v_pk_add_f32 for the exponent argument and the
+// row sum (half the instruction count): 1043 vs 1090 -- packed f32 ops beside MFMAs cost more than they
+// save, as the CDNA4 guide warns.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
 // ~1200 VALU-pipe cycles against 1024 MFMA-pipe cycles -- with two waves per SIMD the softmax VALU
 // work, not the matrix pipe, bounds the loop, so re-arranging who waits for whom moves nothing.
 // ====================================================================================================
