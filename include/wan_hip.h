@@ -148,6 +148,14 @@ wan_status_t wan_patchify(const void* latent, int in_dtype, void* tokens_bf16, i
 wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
                             int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, void* stream);
 
+/* a17  UniPC updates as one fused pass: out[i] = c0*x0[i] + c1*x1[i] + c2*x2[i] + c3*x3[i] (x1..x3 may be
+ *      NULL), fp32 accumulate, all tensors of one dtype (0 fp32, 1 bf16).
+ *      replaces: the elementwise chains of convert_model_output / multistep_uni_p_bh_update /
+ *      multistep_uni_c_bh_update (fm_solvers_unipc.py:318-320, 458-470, 600-612); the scalar algebra
+ *      stays on the host (float64). */
+wan_status_t wan_lincomb(void* out, int dtype, const void* x0, const void* x1, const void* x2, const void* x3,
+                         float c0, float c1, float c2, float c3, int64_t n, void* stream);
+
 /* ===========================================================================
  * WanVAE (videox_fun/models/wan_vae.py).  Activations are CHANNELS-LAST bf16 [T, H, W, C].
  * ------------------------------------------------------------------------- */

@@ -226,3 +226,30 @@ def test_from_pretrained_safetensors_and_lora(tmp_path, model):
     out = m2(lat, t, ctx, 48)
     ref = O.dit_forward(sd2, CFG, lat.cpu(), t.cpu(), [c.cpu() for c in ctx], 48)
     assert rel_l2(out, ref) < 1e-2 and not torch.equal(out, model(lat, t, ctx, 48))
+
+
+def test_skip_source_prediction_is_parity_neutral(golden, model):
+    """The last block may skip the query rows of the source frames whose prediction the pipeline
+    zeroes (pipeline_wan.py:736): the denoised latents must not change."""
+    g = golden("dit_g8_cof_loop")
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    kw = dict(latents=lat, prompt_embeds=[torch.from_numpy(g["ctx"]).to(DEV)], source_frames=9, reasoning_frames=4,
+              num_inference_steps=4, guidance_scale=1.0, shift=3, repeat_rope=True, cot=True, output_type="latent",
+              weight_dtype=torch.float32)
+    pipe = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    a = pipe(skip_source_prediction=False, **kw).latents
+    b = pipe(skip_source_prediction=True, **kw).latents
+    assert model.skip_source_frames == 0          # restored after the call
+    assert rel_l2(b, a.cpu()) < 1e-6              # same kernels on the rows that matter
+    assert rel_l2(b, g["steps"][3]) < 2e-2
+    # a direct forward with the attribute set returns zeros on the skipped frames
+    model.skip_source_frames = 3
+    try:
+        out = model(lat, torch.tensor([749], device=DEV), [torch.from_numpy(g["ctx"]).to(DEV)], 420,
+                    frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    finally:
+        model.skip_source_frames = 0
+    full = model(lat, torch.tensor([749], device=DEV), [torch.from_numpy(g["ctx"]).to(DEV)], 420,
+                 frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    assert float(out[:, :, :3].abs().max()) == 0.0
+    assert rel_l2(out[:, :, 3:], full[:, :, 3:].cpu()) < 1e-6

@@ -51,6 +51,8 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_void_p]),
     "wan_unpatchify": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_void_p]),
+    "wan_lincomb": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                            c_int64, c_void_p]),
     "wan_conv_cl": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                             POINTER(ConvParams), c_void_p]),
     "wan_rmsnorm_silu_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

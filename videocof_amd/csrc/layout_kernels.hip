@@ -89,3 +89,41 @@ extern "C" wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* o
     WAN_CHECK_LAUNCH("wan_unpatchify");
     return WAN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// UniPC updates are linear combinations of <= 4 latent-sized tensors (host computes the float64
+// coefficients): out = sum_i c_i * x_i in ONE pass, fp32 accumulate, instead of ~10 elementwise
+// launches in the tensors' own dtype (fm_solvers_unipc.py:318-320, 458-470, 600-612).
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void lincomb_kernel(T* __restrict__ out, const T* __restrict__ x0, const T* __restrict__ x1,
+                                                      const T* __restrict__ x2, const T* __restrict__ x3, float c0, float c1,
+                                                      float c2, float c3, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float acc = c0 * (float)x0[i];
+        if (x1) acc += c1 * (float)x1[i];
+        if (x2) acc += c2 * (float)x2[i];
+        if (x3) acc += c3 * (float)x3[i];
+        out[i] = (T)acc;
+    }
+}
+}  // namespace
+
+extern "C" wan_status_t wan_lincomb(void* out, int dtype, const void* x0, const void* x1, const void* x2, const void* x3,
+                                    float c0, float c1, float c2, float c3, int64_t n, void* stream) {
+    WAN_REQUIRE(out && x0, WAN_ERR_INVALID, "wan_lincomb: null tensor");
+    WAN_REQUIRE(dtype == 0 || dtype == 1, WAN_ERR_INVALID, "wan_lincomb: dtype=%d (0 fp32, 1 bf16)", dtype);
+    WAN_REQUIRE(n >= 0, WAN_ERR_INVALID, "wan_lincomb: n=%lld", (long long)n);
+    if (n == 0) return WAN_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL(lincomb_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)out, (const float*)x0, (const float*)x1,
+                           (const float*)x2, (const float*)x3, c0, c1, c2, c3, n);
+    else
+        hipLaunchKernelGGL(lincomb_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)x0,
+                           (const bf16_t*)x1, (const bf16_t*)x2, (const bf16_t*)x3, c0, c1, c2, c3, n);
+    WAN_CHECK_LAUNCH("wan_lincomb");
+    return WAN_OK;
+}

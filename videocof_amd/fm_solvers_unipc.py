@@ -159,6 +159,10 @@ class FlowUniPCMultistepScheduler:
 
     @staticmethod
     def _combine(dtype, terms: List[Tuple[float, Optional[torch.Tensor]]]) -> torch.Tensor:
+        live = [(c, t) for c, t in terms if t is not None and c != 0.0]
+        if live and live[0][1].is_cuda and dtype in (torch.float32, torch.bfloat16) and math.isfinite(sum(c for c, _ in live)):
+            from . import ops                      # fused single-pass HIP kernel (wan_lincomb)
+            return ops.lincomb(live, dtype)
         acc = None
         for c, ten in terms:
             if ten is None or c == 0.0:

@@ -304,3 +304,24 @@ def cl_to_video(x: torch.Tensor, cv: int, out_dtype: torch.dtype, clamp: bool) -
     _lib.check(lib.wan_cl_to_video(_p(x), C, _p(out), 0 if dt == torch.float32 else 1, cv, T * H * W, int(clamp),
                                    _stream()), "wan_cl_to_video")
     return out.to(out_dtype)
+
+
+def lincomb(terms, out_dtype: torch.dtype) -> torch.Tensor:
+    """sum_i c_i * x_i over <= 4 same-shape CUDA tensors in one pass (fp32 accumulate); `terms` is a list
+    of (coefficient, tensor).  Inputs are brought to `out_dtype` (fp32 or bf16) if they differ."""
+    terms = [(float(c), t) for c, t in terms if t is not None and c != 0.0]
+    if not terms or len(terms) > 4:
+        raise ValueError("lincomb needs 1..4 non-zero terms")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"lincomb: dtype {out_dtype} not supported")
+    xs = []
+    for _, t in terms:
+        _need(t, t.dtype, "lincomb.x")
+        xs.append(t.to(out_dtype).contiguous())
+    out = torch.empty_like(xs[0])
+    cs = [c for c, _ in terms] + [0.0] * (4 - len(terms))
+    ps = [_p(x) for x in xs] + [None] * (4 - len(xs))
+    lib = _lib.load()
+    _lib.check(lib.wan_lincomb(_p(out), 0 if out_dtype == torch.float32 else 1, ps[0], ps[1], ps[2], ps[3],
+                               cs[0], cs[1], cs[2], cs[3], out.numel(), _stream()), "wan_lincomb")
+    return out

@@ -118,7 +118,7 @@ class WanPipeline:
                  prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "numpy",
                  return_dict: bool = False, callback_on_step_end: Optional[Callable] = None,
                  max_sequence_length: int = 512, device=None, weight_dtype: torch.dtype = torch.bfloat16,
-                 cache_context: bool = True):
+                 cache_context: bool = True, skip_source_prediction: bool = True):
         if num_videos_per_prompt != 1:
             raise NotImplementedError("num_videos_per_prompt must be 1 (as in fast_infer.py / inference.py)")
         self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
@@ -154,6 +154,10 @@ class WanPipeline:
         prev_cache = getattr(self.transformer, "cache_context", False)
         if hasattr(self.transformer, "cache_context"):
             self.transformer.cache_context = cache_context    # the prompt is fixed across steps
+        prev_skip = getattr(self.transformer, "skip_source_frames", 0)
+        if hasattr(self.transformer, "skip_source_frames"):
+            # noise_pred[:, :, :condition_count] is zeroed below (:736): the last block need not produce it
+            self.transformer.skip_source_frames = condition_count if skip_source_prediction else 0
 
         try:
             for i, t in enumerate(timesteps):                                                   # :694
@@ -184,6 +188,8 @@ class WanPipeline:
         finally:
             if hasattr(self.transformer, "cache_context"):
                 self.transformer.cache_context = prev_cache
+            if hasattr(self.transformer, "skip_source_frames"):
+                self.transformer.skip_source_frames = prev_skip
 
         # -- decode (:757-790)
         ground_video = edit_video = video_out = None

@@ -109,6 +109,11 @@ class WanTransformer3DModel(nn.Module):
         self._sp = None
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
         self._ctx_cache = None
+        # Number of leading latent frames whose prediction the caller discards (WanPipeline zeroes
+        # noise_pred[:, :, :condition_count], pipeline_wan.py:736).  When set (B = 1, no SP) the LAST block and
+        # the head run only on the remaining tokens' query rows -- their keys/values still cover every token --
+        # and the discarded frames come back as zeros.  Parity neutral for the pipeline.
+        self.skip_source_frames = 0
         self._attn_events = None            # bench.py: list collecting (start, end) HIP events per self-attn launch
         self._last_attn_rows = 0
 
@@ -263,6 +268,30 @@ class WanTransformer3DModel(nn.Module):
             ops.gemm(ctx[b * T:(b + 1) * T], blk.w_cv, blk.b_cv, ops.EPI_BF16_T, out=cvt[b])
         return ck.view(B, T, C), cvt
 
+    def _last_block_suffix(self, blk, em, xs, h, qk, vt, att, cq, ff, ctx_kv, rp, r0, L):
+        """The last WanAttentionBlock for B = 1 when only rows >= r0 feed the output: K / V^T are built
+        from every token, everything per-query (q, attention, o, cross-attention, FFN) only for the suffix."""
+        C, H, Ll = self.dim, self.num_heads, xs.shape[0]
+        ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
+        ops.gemm(h, blk.w_qk[C:], blk.b_qk[C:], ops.EPI_BF16, out=qk[:, C:])            # k for all tokens
+        ops.gemm(h[r0:], blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[r0:, :C])      # q for the suffix
+        ops.rmsnorm_rope_(qk[:r0, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp)
+        rp2 = type(rp)(rp.F, rp.Hp, rp.Wp, rp.mode, rp.f_src, rp.ground_end, r0, Ll - r0, rp.max_pos)
+        ops.rmsnorm_rope_(qk[r0:, :C], blk.nq, qk[r0:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp2)
+        ops.gemm(h[:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[0])
+        n = Ll - r0
+        ops.attention_fwd(qk[r0:, :C].unsqueeze(0), qk[:, C:].unsqueeze(0), vt, H, k_len=L, out=att[r0:].unsqueeze(0))
+        ops.gemm(att[r0:], blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs[r0:], gate=em[2], rows_per_batch=n)
+        ops.ln_modulate(xs[r0:], blk.n3w, blk.n3b, False, n, self.eps, out=h[r0:])
+        ops.gemm(h[r0:], blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq[r0:])
+        ops.rmsnorm_rope_(cq[r0:], blk.ncq, None, None, self.d, self.eps)
+        ck, cvt = ctx_kv
+        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0))
+        ops.gemm(att[r0:], blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs[r0:])
+        ops.ln_modulate(xs[r0:], em[4], em[3], True, n, self.eps, out=h[r0:])
+        ops.gemm(h[r0:], blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff[r0:])
+        ops.gemm(ff[r0:], blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs[r0:], gate=em[5], rows_per_batch=n)
+
     def _event_pair(self):
         if self._attn_events is None:
             return None
@@ -365,8 +394,16 @@ class WanTransformer3DModel(nn.Module):
             vt = torch.zeros(B, C, Ll, device=dev, dtype=torch.bfloat16)
         qk3 = qk.view(B, Ll, 2 * C)
 
+        # rows whose output is needed after the last block (all of them unless skip_source_frames is set)
+        r0 = 0
+        if self.skip_source_frames and B == 1 and P == 1:
+            r0 = min(int(self.skip_source_frames), grid[0]) * grid[1] * grid[2]
         for li, blk in enumerate(self.blocks):
             em = emod[li]
+            if r0 and li == self.num_layers - 1:
+                self._last_block_suffix(blk, em, xs, h, qk, vt, att, cq, ff, ctx_kv[li] if ctx_kv[li] is not None
+                                        else self._context_kv(blk, ctx, B), rp, r0, L)
+                break
             # ---- self attention (:495-499)
             ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
             ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
@@ -404,8 +441,13 @@ class WanTransformer3DModel(nn.Module):
             ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
 
         # -- head (:535-548) + unpatchify (:1108-1131)
-        ops.ln_modulate(xs, ehead[1], ehead[0], True, Ll, self.eps, out=h)
-        yt = ops.gemm(h, w["head_w"], w["head_b"], ops.EPI_F32).view(B, Ll, -1)
+        if r0:
+            yt = torch.zeros(1, Ll, w["head_w"].shape[0], device=dev, dtype=torch.float32)
+            ops.ln_modulate(xs[r0:], ehead[1], ehead[0], True, Ll - r0, self.eps, out=h[r0:])
+            ops.gemm(h[r0:], w["head_w"], w["head_b"], ops.EPI_F32, out=yt[0, r0:])
+        else:
+            ops.ln_modulate(xs, ehead[1], ehead[0], True, Ll, self.eps, out=h)
+            yt = ops.gemm(h, w["head_w"], w["head_b"], ops.EPI_F32).view(B, Ll, -1)
         if P > 1:
             yt = self._sp.all_gather_tokens(yt)                                        # :1085-1086
         out_dtype = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
