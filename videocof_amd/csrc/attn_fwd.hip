@@ -222,9 +222,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 //   A  finish the row max of S(j) (its per-lane partial max was computed as filler of the previous
 //      tile), one lane^32 exchange, and the rare rescale of O (deferred: while the running max grows
 //      by less than 2^kDeferLog2 the old max is kept and O / l are not touched -- guide T13);
-//   B  the 16 MFMAs of S(j+1) = K(j+1).Q^T in the SAME basic block as the exp2 / convert work of S(j),
-//      so the scheduler interleaves transcendentals with independent matrix work;
-//   C  the 16 MFMAs of O^T += V^T(j).P^T(j).
+//   B  the 16 MFMAs of S(j+1) = K(j+1).Q^T in the SAME basic block as the exp2 / convert work of the first
+//      key-tile of S(j), so the scheduler interleaves transcendentals with independent matrix work;
+//   C  the 16 MFMAs of O^T += V^T(j).P^T(j) with the exp2 / convert work of the second key-tile of S(j)
+//      as filler of its first two k-steps (the VALU stream is split evenly over the two MFMA segments).
 // S ping-pongs between two register sets (loop unrolled by two); the ragged last tile is peeled so the
 // steady-state loop carries no masking code.  K ring: 2 slots (K(j+1), K(j+2)); V^T ring: 2 slots.
 //
@@ -234,7 +235,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 // softmax+load | MFMA cluster" phasing that gives the GEMM +30 %: 929 TFLOP/s; (c) 4-slot rings with one
 // barrier per tile pair: 1080 vs 1120; (d) v_pk_fma_f32 / v_pk_add_f32 for the exponent argument and the
 // row sum (half the instruction count): 1043 vs 1090 -- packed f32 ops beside MFMAs cost more than they
-// save, as the CDNA4 guide warns.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
+// save, as the CDNA4 guide warns; (e) a 4-wave x 64-row one-wave-per-SIMD variant (K/V fragments shared by
+// two query blocks, O in AGPRs): hipcc spills (576 B/lane, 1500 v_accvgpr copies) and runs at 392 TFLOP/s --
+// that structure needs hand-managed AGPRs (inline asm), not attempted this round.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
 // ~1200 VALU-pipe cycles against 1024 MFMA-pipe cycles -- with two waves per SIMD the softmax VALU
 // work, not the matrix pipe, bounds the loop, so re-arranging who waits for whom moves nothing.
 // ====================================================================================================
@@ -349,22 +352,23 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
         return __builtin_bit_cast(bf16x8, w);
     };
-    // segment C
-    auto pv = [&](int t, const bf16x8 (&pf)[4]) {
+    // segment C: O^T += V^T(t).P^T(t).  With BALANCED the exp2/convert work of the second key-tile
+    // (groups 2,3) runs here as filler of the first two k-steps instead of all of it in segment B.
+    auto pv = [&](int t, bf16x8 (&pf)[4], const f32x16* sc_late, float mc, float* psum_late) {
         const char* vb = vring + (t % kVRing) * kVTileBytes;
-        // tt outer: four independent accumulator chains round-robin (no back-to-back dependent MFMAs)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_off[tt]);
                 o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tt], o_acc[dt], 0, 0, 0);
             }
+            if (sc_late != nullptr && tt < 2) pf[2 + tt] = p_group(*sc_late, tt, mc, *psum_late);
+        }
     };
-    // segment B: S(t+1) -> sn from K(t+1), P(t) -> pf from sc
-    auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t, float mc, bf16x8 (&pf)[4]) {
+    // segment B: S(t+1) -> sn from K(t+1); P(t) groups 0,1 (key-tile 0) -> pf; groups 2,3 follow in segment C
+    auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t, float mc, bf16x8 (&pf)[4], float& psum) {
         const char* kb = kring + ((t + 1) & 1) * kKTileBytes;
-        float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -377,9 +381,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * 256 + k_off[ks]);
                 sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
             }
-            if ((ks & 1) == 1) pf[ks >> 1] = p_group(sc[ks >> 2], (ks >> 1) & 1, mc, psum);
+            if (ks == 3) pf[0] = p_group(sc[0], 0, mc, psum);
+            if (ks == 7) pf[1] = p_group(sc[0], 1, mc, psum);
         }
-        l_run += psum;
     };
     auto prefetch = [&](int t) {        // issued at the top of interval t
         if (t + 2 < nkv) stage_k(t + 2);    // slot of K(t), last read in interval t-1
@@ -414,15 +418,15 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     bool last_in_s1 = false;
     for (; it + 2 <= nfull; it += 2) {
         prefetch(it);
-        { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
+        { const float mc = seg_a(mx_part); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
         fence();
         prefetch(it + 1);
-        { const float mc = seg_a(mx_part); seg_b(s1, s0, it + 1, mc, pf); pv(it + 1, pf); mx_part = rowmax32(s0); }
+        { const float mc = seg_a(mx_part); float ps = 0.f; seg_b(s1, s0, it + 1, mc, pf, ps); pv(it + 1, pf, &s1[1], mc, &ps); l_run += ps; mx_part = rowmax32(s0); }
         fence();
     }
     if (it < nfull) {
         prefetch(it);
-        { const float mc = seg_a(mx_part); seg_b(s0, s1, it, mc, pf); pv(it, pf); mx_part = rowmax32(s1); }
+        { const float mc = seg_a(mx_part); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
         fence();
         ++it;
         last_in_s1 = true;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) pf[2 * kt + t2] = p_group(sl[kt], t2, mc, psum);
         l_run += psum;
-        pv(it, pf);
+        pv(it, pf, nullptr, 0.f, nullptr);
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
