@@ -237,7 +237,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 // row sum (half the instruction count): 1043 vs 1090 -- packed f32 ops beside MFMAs cost more than they
 // save, as the CDNA4 guide warns; (e) a 4-wave x 64-row one-wave-per-SIMD variant (K/V fragments shared by
 // two query blocks, O in AGPRs): hipcc spills (576 B/lane, 1500 v_accvgpr copies) and runs at 392 TFLOP/s --
-// that structure needs hand-managed AGPRs (inline asm), not attempted this round.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
+// that structure needs hand-managed AGPRs (inline asm), not attempted this round; (f) taking the softmax
+// denominator from the matrix pipe (one extra MFMA per k-step with an all-ones operand instead of 32
+// VALU adds per tile): 1047 vs 1091 -- the loop is co-limited, MFMA time is not free.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
 // ~1200 VALU-pipe cycles against 1024 MFMA-pipe cycles -- with two waves per SIMD the softmax VALU
 // work, not the matrix pipe, bounds the loop, so re-arranging who waits for whom moves nothing.
 // ====================================================================================================
