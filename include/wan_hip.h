@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 1
+#define WAN_ABI_VERSION 2
 
 typedef enum {
     WAN_OK = 0,
@@ -67,6 +67,9 @@ wan_status_t wan_ln_modulate(const float* x, const float* scale, const float* sh
  *     tokens >= F*Hp*Wp are normalised but not rotated (wan_transformer3d.py:202).
  *     mode 0: pos_t = f;  mode 1 (paired): f < f_src ? f : f - f_src;
  *     mode 2 (CoF): f < f_src ? f+1 : (f < ground_end ? 0 : f - ground_end + 1).
+ *     x0_scale multiplies the x0 result in fp32 before its single bf16 rounding (x1 is not scaled).
+ *     Pass WAN_ATTN_QSCALE(softmax_scale) to hand q to wan_attention_fwd(WAN_ATTN_Q_PRESCALED)
+ *     -- the `q * softmax_scale` of flash attention folded into the norm -- or 1.0f for none.
  * ------------------------------------------------------------------------- */
 typedef struct {
     int F, Hp, Wp;          /* patch grid (frames, rows, cols) */
@@ -81,7 +84,7 @@ typedef struct {
 wan_status_t wan_rmsnorm_rope(void* x0_bf16, const float* w0, void* x1_bf16, const float* w1,
                               int64_t ld, int64_t rows, int dim, int head_dim, float eps,
                               const float* rope_cos, const float* rope_sin,
-                              const wan_rope_params* rp, void* stream);
+                              const wan_rope_params* rp, float x0_scale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a8/a10/a12  nn.Linear on the MFMA cores:  acc[m,n] = sum_k A[m,k] * W[n,k]   (fp32 accumulate)
@@ -123,13 +126,18 @@ wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ld
  *         ldvt % 8 == 0, and columns [Lk, roundup(Lk,64)) must hold finite values (zeros)
  *     out bf16 [B][Lq][H*128]
  *     Keys >= Lk are masked (k_lens semantics of the flash-attn branch, attention_utils.py:95-100).
+ *     flags: WAN_ATTN_Q_PRESCALED -- q already carries softmax_scale*log2(e) (written that way by
+ *     wan_rmsnorm_rope's x0_scale); softmax_scale is then ignored and the kernel keeps the running
+ *     max inside the MFMA accumulator (no per-score multiply-add; ~7 % faster).  0 = plain q.
  * ------------------------------------------------------------------------- */
 wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                const void* k, int64_t ldk, int64_t k_bstride,
                                const void* vt, int64_t ldvt, int64_t vt_bstride,
                                void* out, int64_t ldo, int64_t o_bstride,
                                int batch, int Lq, int Lk, int num_heads, int head_dim,
-                               float softmax_scale, void* stream);
+                               float softmax_scale, int flags, void* stream);
+#define WAN_ATTN_Q_PRESCALED 1
+#define WAN_ATTN_QSCALE(softmax_scale) ((softmax_scale) * 1.4426950408889634f)
 
 /* [rows, cols] bf16 (row stride ld) -> [cols, ldt] bf16 transposed; pad columns [rows, ldt) are zeroed.
  * Used when a caller hands attention() a row-major V (the reference's [B,L,N,D] layout). */

@@ -20,7 +20,7 @@ def header_symbols():
 def test_library_present_and_loads():
     assert os.path.isfile(_lib.LIB_PATH), "run `make` / __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.wan_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.wan_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_every_header_symbol_is_exported_and_bound():
@@ -48,7 +48,7 @@ def test_argument_errors_map_to_python_exceptions():
     assert st == _lib.WAN_ERR_INVALID
     with pytest.raises(ValueError, match="null tensor"):
         _lib.check(st, "wan_ln_modulate")
-    st = lib.wan_attention_fwd(1, 128, 0, 1, 128, 0, 1, 64, 0, 1, 128, 0, 1, 8, 8, 1, 64, 0.1, None)
+    st = lib.wan_attention_fwd(1, 128, 0, 1, 128, 0, 1, 64, 0, 1, 128, 0, 1, 8, 8, 1, 64, 0.1, 0, None)
     assert st == _lib.WAN_ERR_UNSUPPORTED      # head_dim 64 is not built
     with pytest.raises(RuntimeError, match="head_dim"):
         _lib.check(st, "wan_attention_fwd")

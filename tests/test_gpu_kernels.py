@@ -37,7 +37,7 @@ def rope_dev():
 
 def test_extension_is_loaded():
     lib = _lib.load()
-    assert lib.wan_abi_version() == 1
+    assert lib.wan_abi_version() == _lib.ABI_VERSION == 2
     maps = open("/proc/self/maps").read()
     assert "libwan_hip.so" in maps
 
@@ -197,6 +197,70 @@ def test_attention_online_softmax_rescale_branch():
     ref = _attn_ref(q, k, v)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("Lq,Lk,H,qs,spike", [(300, 420, 2, 1.0, False), (257, 8, 1, 1.0, False), (96, 640, 1, 1.0, True),
+                                              (33, 1000, 1, 6.0, False), (520, 577, 2, 3.0, True)])
+def test_attention_prescaled_q_path(Lq, Lk, H, qs, spike):
+    """WAN_ATTN_Q_PRESCALED: q carries softmax_scale*log2(e) and the running max lives in the MFMA
+    accumulator.  Same function as the plain path: compare with the oracle on the un-scaled q, incl. the
+    rescale branch (late spike), a first tile far BELOW zero (scores ~ -60) and a ragged last tile."""
+    g = torch.Generator().manual_seed(Lq + 3 * Lk)
+    q = torch.randn(1, Lq, H, 128, generator=g) * qs
+    k = bf(torch.randn(1, Lk, H, 128, generator=g))
+    v = bf(torch.randn(1, Lk, H, 128, generator=g) + torch.arange(128) * 0.01)
+    if spike:
+        k[0, Lk - 140, 0] = bf(q[0, :, 0].mean(0) * 40)                 # huge score late in the stream
+        k[0, :64] = bf(-q[0, :64].mean(0, keepdim=True).expand(64, H, 128) * 30)    # tile 0: very negative scores
+    c = ops.q_prescale(128)
+    q_pre = bf(q * c)                                                   # what wan_rmsnorm_rope(x0_scale=c) stores
+    q_eff = q_pre.float() / c                                           # the q the kernel effectively sees
+    C = H * 128
+    out = ops.attention_fwd(q_pre.view(1, Lq, C).to(DEV), k.view(1, Lk, C).to(DEV),
+                            ops.transpose_pad(v.view(Lk, C).to(DEV))[None], H, q_prescaled=True)
+    ref = _attn_ref(q_eff, k, v).view(1, Lq, C)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 6e-3
+    plain = ops.attention_fwd(bf(q).view(1, Lq, C).to(DEV), k.view(1, Lk, C).to(DEV),
+                              ops.transpose_pad(v.view(Lk, C).to(DEV))[None], H)
+    assert rel_l2(plain, _attn_ref(bf(q), k, v).view(1, Lq, C)) < 6e-3
+    with pytest.raises(ValueError, match="unknown flags"):
+        from videocof_amd import _lib
+        _lib.check(_lib.load().wan_attention_fwd(1, C, 0, 1, C, 0, 1, 64, 0, 1, C, 0, 1, 8, 8, H, 128, 0.1, 6, None),
+                   "wan_attention_fwd")
+
+
+def test_rmsnorm_x0_scale_scales_only_x0(rope_dev):
+    g = torch.Generator().manual_seed(9)
+    rows, C = 112, 256
+    x = bf(torch.randn(rows, 2 * C, generator=g))
+    w = torch.rand(C, generator=g) + 0.5
+    rp = RopeParams(7, 4, 4, 2, 3, 4, 0, rows, 1024)
+    a = x.to(DEV).clone(); b = x.to(DEV).clone()
+    ops.rmsnorm_rope_(a[:, :C], w.to(DEV), a[:, C:], w.to(DEV), 128, 1e-6, rope_dev, rp)
+    c = ops.q_prescale(128)
+    ops.rmsnorm_rope_(b[:, :C], w.to(DEV), b[:, C:], w.to(DEV), 128, 1e-6, rope_dev, rp, x0_scale=c)
+    assert torch.equal(a[:, C:], b[:, C:])                                      # k untouched
+    ang = O.rope_angles(128)
+    ref = O.rope_apply(O.rms_norm(x[:, :C].float(), w, 1e-6).view(rows, 2, 128), (7, 4, 4), ang, 3, (3, 4)).reshape(rows, C) * c
+    assert rel_l2(b[:, :C], ref) < 4e-3
+    assert rel_l2(b[:, :C].float().cpu() / c, a[:, :C].float().cpu()) < 4e-3
+    with pytest.raises(ValueError, match="x0_scale"):
+        ops.rmsnorm_rope_(b[:, :C], w.to(DEV), None, None, 128, 1e-6, x0_scale=0.0)
+
+
+def test_attention_is_bitwise_reproducible():
+    """Run-to-run equality on identical inputs, both q conventions.  (A hand-placed v_max3 on MFMA results
+    once slipped past the hazard recogniser: results stayed within tolerance but differed run to run.)"""
+    g = torch.Generator(device=DEV).manual_seed(4)
+    for Lq, Lk, H in [(420, 420, 2), (840, 1000, 1), (4096, 8192, 4)]:
+        C = H * 128
+        q = torch.randn(1, Lq, C, device=DEV, generator=g).bfloat16()
+        k = torch.randn(1, Lk, C, device=DEV, generator=g).bfloat16()
+        vt = ops.transpose_pad(torch.randn(Lk, C, device=DEV, generator=g).bfloat16())[None]
+        for pre in (False, True):
+            outs = [ops.attention_fwd(q, k, vt, H, q_prescaled=pre).clone() for _ in range(4)]
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (Lq, Lk, H, pre)
 
 
 def test_attention_rejects_unbuilt_options():

@@ -137,8 +137,9 @@ static void check_rmsnorm_rope() {
             for (auto& v : wq) v += 1.f; for (auto& v : wk) v += 1.f;
             Dev<bf16> dx(to_bf(x)); Dev<float> dwq(wq), dwk(wk);
             wan_rope_params rp = {F, Hp, Wp, mode % 3, 3, 4, 0, rows, maxpos};
+            const float qs = (mode & 1) ? WAN_ATTN_QSCALE(0.0883883f) : 1.0f;   // x0 only
             WAN(wan_rmsnorm_rope(dx.p, dwq.p, dx.p + dim, dwk.p, ld, rows, dim, hd, 1e-6f,
-                                 mode == 3 ? nullptr : dct.p, mode == 3 ? nullptr : dst.p, &rp, nullptr));
+                                 mode == 3 ? nullptr : dct.p, mode == 3 ? nullptr : dst.p, &rp, qs, nullptr));
             HIP(hipDeviceSynchronize());
             auto got = bf_to_f(dx.host());
             std::vector<double> ref(x.size());
@@ -153,7 +154,8 @@ static void check_rmsnorm_rope() {
                     if (mode == 1) pt = f < 3 ? f : f - 3;
                     if (mode == 2) pt = f < 3 ? f + 1 : (f < 4 ? 0 : f - 4 + 1);
                     for (int c = 0; c < dim; c += 2) {
-                        double a = xr[c] * rstd * w[c], b = xr[c + 1] * rstd * w[c + 1];
+                        const double sc = which == 0 ? qs : 1.0;
+                        double a = xr[c] * rstd * w[c] * sc, b = xr[c + 1] * rstd * w[c + 1] * sc;
                         if (mode != 3 && r < L) {
                             const int p = (c % hd) / 2;
                             const int pos = p < 22 ? pt : (p < 43 ? hh : ww);
@@ -265,8 +267,9 @@ static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, c
 }
 
 static void check_attn() {
-  for (const char* var : {"1", "2"}) {
-    setenv("WAN_ATTN_VARIANT", var, 1);
+  for (const char* var : {"1", "2", "3"}) {      // 3 = variant 2 with WAN_ATTN_Q_PRESCALED
+    const bool pre = var[0] == '3';
+    setenv("WAN_ATTN_VARIANT", pre ? "2" : var, 1);
     printf("wan_attention_fwd variant %s (+ wan_transpose_bf16)\n", var);
     struct Shape { int Lq, Lk, H; float qs; };
     for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}}) {
@@ -279,7 +282,13 @@ static void check_attn() {
         HIP(hipMemset(dvt.p, 0xff, dvt.n * 2));   // poison: transpose must zero the pad
         WAN(wan_transpose_bf16(dv.p, C, dvt.p, ldvt, Lk, C, nullptr));
         const float scale = 1.f / sqrtf(128.f);
-        WAN(wan_attention_fwd(dq.p, C, 0, dk.p, C, 0, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, scale, nullptr));
+        if (pre) {   // q handed over pre-multiplied by scale*log2(e); the reference sees the same rounded values
+            const float cc = WAN_ATTN_QSCALE(scale);
+            for (auto& x : q) x = bf2f(f2bf(x * cc));
+            HIP(hipMemcpy(dq.p, to_bf(q).data(), q.size() * 2, hipMemcpyHostToDevice));
+            for (auto& x : q) x /= cc;
+        }
+        WAN(wan_attention_fwd(dq.p, C, 0, dk.p, C, 0, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, scale, pre ? WAN_ATTN_Q_PRESCALED : 0, nullptr));
         HIP(hipDeviceSynchronize());
         std::vector<double> ref; attn_ref(q, k, v, Lq, Lk, H, scale, ref);
         auto got = bf_to_f(dout.host());
@@ -332,7 +341,7 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         Dev<bf16> qk((size_t)L * 2 * C); qk.zero(); w.zero();
         wan_rope_params rp = {43, 30, 52, 2, 21, 22, 0, L, 1024};
         if (!big) { rp.F = 21; rp.mode = 0; }
-        ms = time_ms([&] { WAN(wan_rmsnorm_rope(qk.p, w.p, qk.p + C, w.p, 2 * C, L, C, 128, 1e-6f, dct.p, dst.p, &rp, nullptr)); });
+        ms = time_ms([&] { WAN(wan_rmsnorm_rope(qk.p, w.p, qk.p + C, w.p, 2 * C, L, C, 128, 1e-6f, dct.p, dst.p, &rp, 1.0f, nullptr)); });
         printf("  rmsnorm_rope q+k L=%d C=%d: %.3f ms  %.0f GB/s (8C B/row)\n", L, C, ms, 8.0 * C * L / ms / 1e6);
     }
     struct G { int M, N, K; int epi; const char* what; };
@@ -370,10 +379,10 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(q); fill(k); fill(vt);
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
-        for (const char* var : {"1", "2"}) {
+        for (const char* var : {"1", "2", "3"}) {
             if (!attn_only && strcmp(var, "2")) continue;
-            setenv("WAN_ATTN_VARIANT", var, 1);
-            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, nullptr)); }, 3, 1);
+            setenv("WAN_ATTN_VARIANT", var[0] == '3' ? "2" : var, 1);
+            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
         }
         unsetenv("WAN_ATTN_VARIANT");

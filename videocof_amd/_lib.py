@@ -13,7 +13,9 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
+ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
+LOG2E = 1.4426950408889634
 
 WAN_OK, WAN_ERR_INVALID, WAN_ERR_UNSUPPORTED, WAN_ERR_LAUNCH = 0, 1, 2, 3
 EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32, EPI_BF16_T = 0, 1, 2, 3, 4
@@ -40,12 +42,12 @@ SIGNATURES = {
     "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64,
                                 c_float, c_void_p]),
     "wan_rmsnorm_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
-                                 c_float, c_void_p, c_void_p, POINTER(RopeParams), c_void_p]),
+                                 c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_void_p]),
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                               c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "wan_attention_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
-                                  c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                                  c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "wan_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "wan_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_void_p]),

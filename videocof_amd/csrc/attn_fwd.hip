@@ -248,17 +248,26 @@ constexpr int kDefaultAttnVariant = 2;
 constexpr int kVRing = 2;
 constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 64 KiB
 
+// 32 scores -> 1.  Written as max(max(m, a), b) so that the DAG combiner has exactly one way to fuse each
+// step into v_max3_f32 (15 v_max3 + 1 v_max); max(m, max(a, b)) makes it fuse the wrong pair and emit 31 ops.
+// No inline asm here: an asm v_max3 reading MFMA results is invisible to the hazard recogniser (measured:
+// missing wait states, run-to-run different maxima).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
-    float m0 = fmaxf(s[0][0], s[0][1]), m1 = fmaxf(s[1][0], s[1][1]);
+    float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[1][0], s[1][1], s[1][2]);
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) {
-        m0 = fmaxf(m0, fmaxf(s[0][r], s[0][r + 1]));
-        m1 = fmaxf(m1, fmaxf(s[1][r], s[1][r + 1]));
+    for (int r = 3; r < 15; r += 2) {
+        m0 = max3f(m0, s[0][r], s[0][r + 1]);
+        m1 = max3f(m1, s[1][r], s[1][r + 1]);
     }
-    return fmaxf(m0, m1);
+    return max3f(max3f(m0, s[0][15], s[1][15]), m1, m1);
 }
 
-template <int VARIANT>
+// PRE: q arrives pre-multiplied by softmax_scale*log2(e) (in fp32, before its one bf16 rounding -- see
+// wan_rmsnorm_rope's x0_scale).  The running max then rides in the MFMA accumulator: S' = K.Q^T + (-m)
+// starts from a 16-register splat of -m instead of the inline constant 0, so p = exp2(S') needs no
+// per-score fma: 32 fewer VALU per wave and tile (+6..8 % end to end on this VALU-co-limited loop).
+template <int VARIANT, bool PRE>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -325,30 +334,57 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
     const float c = a.scale_log2e;
     const int nkv = (a.Lk + kKV - 1) / kKV;
 
-    // segment A: finish the row max, decide / apply the rescale; returns m*c
-    auto seg_a = [&](float mx_part) -> float {
+    // segment A: finish the row max, decide / apply the rescale; returns m*c (unused with PRE)
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    bool first = true;
+    auto seg_a = [&](float mx_part, f32x16 (&sc)[2]) -> float {
         const float mx = fmaxf(mx_part, __shfl_xor(mx_part, 32, 64));
-        if (!__all((mx - m_run) * c <= kDeferLog2)) {     // wave-uniform; rare after the first tiles
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
+        if constexpr (PRE) {
+            // scores are already relative to m_run and in log2 units
+            if (first || !__all(mx <= kDeferLog2)) {           // wave-uniform; rare after the first tiles
+                const float delta = first ? mx : fmaxf(mx, 0.f);
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                first = false;
+                m_run += delta;
+                l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)                 // this tile was accumulated on the old -m
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kt][r] -= delta;
+                const float nm = -m_run;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = nm;
+            }
+            return 0.f;
+        } else {
+            if (!__all((mx - m_run) * c <= kDeferLog2)) {     // wave-uniform; rare after the first tiles
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+            }
+            return m_run * c;
         }
-        return m_run * c;
     };
     auto p_group = [&](const f32x16& sv, int t2, float mc, float& psum) -> bf16x8 {
         float p[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 * t2 + j], c, -mc));
+            p[j] = PRE ? __builtin_amdgcn_exp2f(sv[8 * t2 + j]) : __builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 * t2 + j], c, -mc));
             psum += p[j];
         }
         u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
@@ -372,9 +408,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t, float mc, bf16x8 (&pf)[4], float& psum) {
         const char* kb = kring + ((t + 1) & 1) * kKTileBytes;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt) {
+            if constexpr (PRE) sn[kt] = negm;
+            else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const bf16x8 qv = q_frag(ks);
@@ -420,15 +460,15 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     bool last_in_s1 = false;
     for (; it + 2 <= nfull; it += 2) {
         prefetch(it);
-        { const float mc = seg_a(mx_part); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
+        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
         fence();
         prefetch(it + 1);
-        { const float mc = seg_a(mx_part); float ps = 0.f; seg_b(s1, s0, it + 1, mc, pf, ps); pv(it + 1, pf, &s1[1], mc, &ps); l_run += ps; mx_part = rowmax32(s0); }
+        { const float mc = seg_a(mx_part, s1); float ps = 0.f; seg_b(s1, s0, it + 1, mc, pf, ps); pv(it + 1, pf, &s1[1], mc, &ps); l_run += ps; mx_part = rowmax32(s0); }
         fence();
     }
     if (it < nfull) {
         prefetch(it);
-        { const float mc = seg_a(mx_part); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
+        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
         fence();
         ++it;
         last_in_s1 = true;
@@ -449,7 +489,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
                 }
             mx_part = rowmax32(sl);
         }
-        const float mc = seg_a(mx_part);
+        const float mc = seg_a(mx_part, sl);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -503,8 +543,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
                                           const void* vt, int64_t ldvt, int64_t vt_bstride,
                                           void* out, int64_t ldo, int64_t o_bstride,
                                           int batch, int Lq, int Lk, int num_heads, int head_dim,
-                                          float softmax_scale, void* stream) {
+                                          float softmax_scale, int flags, void* stream) {
     WAN_REQUIRE(q && k && vt && out, WAN_ERR_INVALID, "wan_attention_fwd: null tensor");
+    WAN_REQUIRE((flags & ~WAN_ATTN_Q_PRESCALED) == 0, WAN_ERR_INVALID, "wan_attention_fwd: unknown flags 0x%x", flags);
     WAN_REQUIRE(head_dim == kD, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: head_dim=%d (only 128 is built)", head_dim);
     WAN_REQUIRE(batch > 0 && Lq >= 0 && Lk > 0 && num_heads > 0, WAN_ERR_INVALID,
                 "wan_attention_fwd: batch=%d Lq=%d Lk=%d heads=%d", batch, Lq, Lk, num_heads);
@@ -520,9 +561,10 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (Lq == 0) return WAN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
-                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1>)};
-        for (int i = 0; i < 4; ++i) {
+        const void* fns[6] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
+                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
+                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>)};
+        for (int i = 0; i < 6; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? kLdsBytes : kLdsBytesV2);
             if (e != hipSuccess) {
                 wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
@@ -537,7 +579,8 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.vt = (const bf16_t*)vt; a.ldvt = ldvt; a.vt_bs = vt_bstride;
     a.o = (bf16_t*)out; a.ldo = ldo; a.o_bs = o_bstride;
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
-    a.scale_log2e = softmax_scale * 1.4426950408889634f;
+    const bool pre = (flags & WAN_ATTN_Q_PRESCALED) != 0;
+    a.scale_log2e = pre ? 1.0f : softmax_scale * 1.4426950408889634f;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     // developer A/B switch (not a product option): WAN_ATTN_VARIANT = 1 plain, 2 software-pipelined (default)
@@ -548,8 +591,13 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         if (self) hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, st, a);
         else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, st, a);
     } else {
-        if (self) hipLaunchKernelGGL(attn_fwd_v2_kernel<0>, grid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL(attn_fwd_v2_kernel<1>, grid, block, kLdsBytesV2, st, a);
+        if (pre) {
+            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
+            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
+        } else {
+            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
+            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
+        }
     }
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;

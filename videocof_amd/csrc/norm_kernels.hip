@@ -77,7 +77,7 @@ template <int NV>   // 16-byte chunks (8 bf16) per thread
 __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ x0, const float* __restrict__ w0, bf16_t* __restrict__ x1,
     const float* __restrict__ w1, int64_t ld, int dim, int head_dim, float eps,
-    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp) {
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp, float x0_scale) {
     __shared__ float red[kWaves];
     __shared__ __attribute__((aligned(16))) float2 cs[128];   // (cos, sin) of this token's head_dim/2 pairs
     const int64_t row = blockIdx.x;
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
             }
         }
     }
-    const float rstd = rsqrtf(block_sum<kWaves>(ss, red) / (float)dim + eps);   // also orders cs[] writes
+    const float rstd = rsqrtf(block_sum<kWaves>(ss, red) / (float)dim + eps)    // also orders cs[] writes
+                       * (blockIdx.y == 0 ? x0_scale : 1.f);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * kThreads;
@@ -174,8 +175,9 @@ extern "C" wan_status_t wan_ln_modulate(const float* x, const float* scale, cons
 extern "C" wan_status_t wan_rmsnorm_rope(void* x0, const float* w0, void* x1, const float* w1,
                                          int64_t ld, int64_t rows, int dim, int head_dim, float eps,
                                          const float* rope_cos, const float* rope_sin,
-                                         const wan_rope_params* rp, void* stream) {
+                                         const wan_rope_params* rp, float x0_scale, void* stream) {
     WAN_REQUIRE(x0 && w0, WAN_ERR_INVALID, "wan_rmsnorm_rope: null tensor");
+    WAN_REQUIRE(x0_scale == x0_scale && x0_scale != 0.f, WAN_ERR_INVALID, "wan_rmsnorm_rope: x0_scale must be a non-zero number (1 = none)");
     WAN_REQUIRE((x1 == nullptr) == (w1 == nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope: x1/w1 must both be set or both NULL");
     WAN_REQUIRE(dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= dim, WAN_ERR_INVALID,
                 "wan_rmsnorm_rope: dim=%d ld=%lld must be multiples of 8, ld >= dim", dim, (long long)ld);
@@ -200,7 +202,7 @@ extern "C" wan_status_t wan_rmsnorm_rope(void* x0, const float* w0, void* x1, co
     hipStream_t s = (hipStream_t)stream;
     const int nv = (dim / 8 + kThreads - 1) / kThreads;
     dim3 grid((unsigned)rows, x1 ? 2 : 1), block(kThreads);
-#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d); break;
+#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale); break;
     switch (nv) { RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) }
 #undef RR_CASE
     WAN_CHECK_LAUNCH("wan_rmsnorm_rope");

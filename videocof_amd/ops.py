@@ -65,8 +65,10 @@ def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[
 
 def rmsnorm_rope_(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor], w1: Optional[torch.Tensor],
                   head_dim: int, eps: float, rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                  rope_params: Optional[RopeParams] = None) -> None:
-    """In-place RMSNorm(+RoPE) of one or two bf16 [rows, dim] views sharing a row stride."""
+                  rope_params: Optional[RopeParams] = None, x0_scale: float = 1.0) -> None:
+    """In-place RMSNorm(+RoPE) of one or two bf16 [rows, dim] views sharing a row stride.
+    ``x0_scale`` multiplies the x0 result before its bf16 rounding (``q_prescale(softmax_scale)`` to
+    feed ``attention_fwd(..., q_prescaled=True)``)."""
     _need(x0, torch.bfloat16, "rmsnorm_rope.x0")
     _need(w0, torch.float32, "rmsnorm_rope.w0")
     rows, dim = x0.shape
@@ -89,7 +91,13 @@ def rmsnorm_rope_(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor]
     _lib.check(lib.wan_rmsnorm_rope(_p(x0), _p(w0), _p(x1), _p(w1), ld, rows, dim, head_dim, float(eps),
                                     _p(cos), _p(sin),
                                     ctypes.byref(rope_params) if rope_params is not None else None,
-                                    _stream()), "wan_rmsnorm_rope")
+                                    float(x0_scale), _stream()), "wan_rmsnorm_rope")
+
+
+def q_prescale(head_dim: int, softmax_scale: Optional[float] = None) -> float:
+    """The factor q must carry for ``attention_fwd(q_prescaled=True)``: softmax_scale * log2(e)."""
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(head_dim)
+    return float(scale) * _lib.LOG2E
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
@@ -143,9 +151,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogu
 
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads: int, k_len: Optional[int] = None,
-                  softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
+                  q_prescaled: bool = False) -> torch.Tensor:
     """q bf16 [B,Lq,H*128], k bf16 [B,Lk,H*128], vt bf16 [B,H*128,ldvt] (V transposed, ldvt >=
-    roundup(k_len,64), finite padding) -> bf16 [B,Lq,H*128].  Keys >= k_len are masked."""
+    roundup(k_len,64), finite padding) -> bf16 [B,Lq,H*128].  Keys >= k_len are masked.
+    ``q_prescaled``: q already carries softmax_scale*log2(e) (see ``rmsnorm_rope_``'s x0_scale)."""
     for nm, t in (("q", q), ("k", k), ("vt", vt)):
         _need(t, torch.bfloat16, "attention." + nm)
         if t.dim() != 3:
@@ -164,7 +174,8 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
     lib = _lib.load()
     _lib.check(lib.wan_attention_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
                                      _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
-                                     B, Lq, Lk, num_heads, head_dim, float(scale), _stream()), "wan_attention_fwd")
+                                     B, Lq, Lk, num_heads, head_dim, float(scale),
+                                     _lib.ATTN_Q_PRESCALED if q_prescaled else 0, _stream()), "wan_attention_fwd")
     return out
 
 

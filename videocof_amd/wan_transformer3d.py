@@ -91,6 +91,9 @@ class WanTransformer3DModel(nn.Module):
         self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
         self.eps = eps
         self.d = dim // num_heads
+        # q leaves the RMSNorm(+RoPE) kernel already multiplied by softmax_scale*log2(e) (fp32, before its
+        # bf16 rounding) so the attention kernel needs no per-score multiply-add (wan_hip.h, WAN_ATTN_Q_PRESCALED)
+        self._qs = ops.q_prescale(self.d)
         d = self.d
         # complex table kept for API parity (:692-699); kernels use fp32 cos/sin of the same fp64 angles
         self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
@@ -277,16 +280,16 @@ class WanTransformer3DModel(nn.Module):
         ops.gemm(h[r0:], blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[r0:, :C])      # q for the suffix
         ops.rmsnorm_rope_(qk[:r0, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp)
         rp2 = type(rp)(rp.F, rp.Hp, rp.Wp, rp.mode, rp.f_src, rp.ground_end, r0, Ll - r0, rp.max_pos)
-        ops.rmsnorm_rope_(qk[r0:, :C], blk.nq, qk[r0:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp2)
+        ops.rmsnorm_rope_(qk[r0:, :C], blk.nq, qk[r0:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp2, x0_scale=self._qs)
         ops.gemm(h[:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[0])
         n = Ll - r0
-        ops.attention_fwd(qk[r0:, :C].unsqueeze(0), qk[:, C:].unsqueeze(0), vt, H, k_len=L, out=att[r0:].unsqueeze(0))
+        ops.attention_fwd(qk[r0:, :C].unsqueeze(0), qk[:, C:].unsqueeze(0), vt, H, k_len=L, out=att[r0:].unsqueeze(0), q_prescaled=True)
         ops.gemm(att[r0:], blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs[r0:], gate=em[2], rows_per_batch=n)
         ops.ln_modulate(xs[r0:], blk.n3w, blk.n3b, False, n, self.eps, out=h[r0:])
         ops.gemm(h[r0:], blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq[r0:])
-        ops.rmsnorm_rope_(cq[r0:], blk.ncq, None, None, self.d, self.eps)
+        ops.rmsnorm_rope_(cq[r0:], blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
         ck, cvt = ctx_kv
-        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0))
+        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0), q_prescaled=True)
         ops.gemm(att[r0:], blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs[r0:])
         ops.ln_modulate(xs[r0:], em[4], em[3], True, n, self.eps, out=h[r0:])
         ops.gemm(h[r0:], blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff[r0:])
@@ -407,12 +410,12 @@ class WanTransformer3DModel(nn.Module):
             # ---- self attention (:495-499)
             ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
             ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
-            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp)
+            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
             if P == 1:
                 for b in range(B):
                     ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
                 ev = self._event_pair()
-                ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C))
+                ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True)
                 self._event_done(ev, B * Ll)
                 o_in = att
             else:
@@ -424,16 +427,16 @@ class WanTransformer3DModel(nn.Module):
                 fv = sp.scatter_heads_t(vt, ld=ops.round_up(seq_len, 64), async_op=True)
                 q_full, k_full, vt_full = fq().contiguous(), fk().contiguous(), fv()
                 ev = self._event_pair()
-                o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L)
+                o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L, q_prescaled=True)
                 self._event_done(ev, B * seq_len)
                 o_in = sp.gather_heads(o_full).reshape(M, C)
             ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
             # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
             ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
             ops.gemm(h, blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq)
-            ops.rmsnorm_rope_(cq, blk.ncq, None, None, self.d, self.eps)
+            ops.rmsnorm_rope_(cq, blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
             ck, cvt = ctx_kv[li] if ctx_kv[li] is not None else self._context_kv(blk, ctx, B)
-            ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C))
+            ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C), q_prescaled=True)
             ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
             # ---- FFN (:507-511)
             ops.ln_modulate(xs, em[4], em[3], True, Ll, self.eps, out=h)
