@@ -242,6 +242,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 // VALU adds per tile): 1047 vs 1091 -- the loop is co-limited, MFMA time is not free.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
 // ~1200 VALU-pipe cycles against 1024 MFMA-pipe cycles -- with two waves per SIMD the softmax VALU
 // work, not the matrix pipe, bounds the loop, so re-arranging who waits for whom moves nothing.
+// (g) a sched_group_barrier weave (1 MFMA : 1 ds_read : 4 VALU across the whole interval) changes the emitted
+// order thoroughly and the time not at all (78.07 vs 78.15 ms).  What does move the loop is REMOVING VALU work:
+// the PRE form below (-32 v_fma per wave and tile) gained 7-8 %, the 15 x v_max3 row max ~1 %.  Time per
+// interval tracks (MFMA cycles + VALU cycles) of the two waves of a SIMD, not their maximum.
 // ====================================================================================================
 constexpr float kDeferLog2 = 6.0f;
 constexpr int kDefaultAttnVariant = 2;
