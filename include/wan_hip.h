@@ -212,6 +212,43 @@ wan_status_t wan_video_to_cl(const void* video, int in_dtype, void* out_bf16, in
 wan_status_t wan_cl_to_video(const void* x_bf16, int64_t ld, void* out, int out_dtype, int Cv, int64_t npix,
                              int clamp, void* stream);
 
+/* ===========================================================================
+ * the umT5 text encoder (videox_fun/models/wan_text_encoder.py:256-304), the step
+ * before the denoising path.  Its Linear layers are wan_gemm_bf16; the rest:
+ * ------------------------------------------------------------------------- */
+
+/* Strided-batched nn.Linear-style product: for z in [0, batch):
+ *     out_z[m, n] = sum_k A_z[m, k] * W_z[n, k],  X_z = X + z * strideX (elements)
+ * replaces: torch.einsum('binc,bjnc->bnij', q, k) and einsum('bnij,bjnc->binc', attn, v)
+ *           of T5Attention.forward (wan_text_encoder.py:102-105), one problem per head.
+ * epilogue: WAN_EPI_BF16 or WAN_EPI_F32, no bias.  K % 64 == 0, N % 4 == 0, strides of A/W % 8 == 0. */
+wan_status_t wan_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,
+                                   int64_t strideW, void* out, int64_t ldo, int64_t strideO,
+                                   int M, int N, int K, int batch, int epilogue, void* stream);
+
+/* nn.Embedding gather (wan_text_encoder.py:286-287): out fp32 [rows, dim] = table_bf16[ids[r], :].
+ * ids are clamped into [0, vocab) for memory safety; the caller validates the range. */
+wan_status_t wan_embedding_rows(const int64_t* ids, const void* table_bf16, int64_t vocab, float* out,
+                                int64_t rows, int dim, void* stream);
+
+/* T5LayerNorm (wan_text_encoder.py:48-60): out = x * rsqrt(mean(x^2) + eps) * w, x fp32 [rows, dim],
+ * w fp32 [dim]; out_dtype 0 fp32, 1 bf16.  dim % 4 == 0, dim <= 8192. */
+wan_status_t wan_rmsnorm_rows(const float* x, const float* w, void* out, int out_dtype, int64_t rows, int dim,
+                              float eps, void* stream);
+
+/* T5Attention score softmax (wan_text_encoder.py:93-104) with the relative-position bias of
+ * T5RelativeEmbedding (:226-260) evaluated in place:
+ *     probs[h, i, j] = softmax_j(scores[h, i, j] + bucket_table[bucket_lut[j - i + Lq - 1], h]),  j < k_len
+ * and 0 for k_len <= j < npad (attention_mask == 0 keys, :98-99, and the K padding of the P.V product).
+ * scores fp32 [H*Lq, lds]; bucket_table fp32 [num_buckets, H] (pos_embedding.embedding.weight);
+ * bucket_lut int32 [Lq + Lk - 1] = _relative_position_bucket(j - i) (:245-264); probs bf16 [H*Lq, ldp]. */
+wan_status_t wan_t5_softmax_bias(const float* scores, int64_t lds, const float* bucket_table,
+                                 const int* bucket_lut, void* probs_bf16, int64_t ldp, int num_heads,
+                                 int Lq, int Lk, int k_len, int npad, void* stream);
+
+/* gated-GELU feed-forward product fc1(x) * gelu(gate(x)) (wan_text_encoder.py:125-126): out = a * b, bf16, n % 8 == 0. */
+wan_status_t wan_mul_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,5 +219,9 @@ def load_reference(sp_rank: int | None = None, sp_size: int | None = None) -> Si
     def lora_utils():
         return _load_by_path("videox_fun.utils.lora_utils", "videox_fun/utils/lora_utils.py")
     ns.load_lora_utils = lora_utils
+
+    def text_encoder():
+        return _load_by_path("videox_fun.models.wan_text_encoder", "videox_fun/models/wan_text_encoder.py")
+    ns.load_text_encoder = text_encoder
     _CACHE[key] = ns
     return ns

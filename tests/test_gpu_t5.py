@@ -1,0 +1,171 @@
+"""-m gpu: the umT5 text encoder through the C ABI, against the CPU oracle
+(oracle/t5_oracle.py) and the fixture captured from the reference's WanT5EncoderModel.
+
+Tolerances: row kernels rel-L2 4e-3 (one bf16 rounding); fp32 outputs 1e-5; the whole encoder (bf16
+weights and activations, fp32 residual stream) rel-L2 1.5e-2 / cosine 0.9998 against the fp32 reference.
+"""
+import pytest
+import torch
+
+from oracle import t5_oracle as T
+from oracle.gen_golden_t5 import TINY
+from videocof_amd import ops
+from videocof_amd.wan_text_encoder import WanT5EncoderModel, relative_position_buckets
+from videocof_amd.weights import deterministic_t5_state_dict, random_t5_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().flatten(), torch.as_tensor(b).double().cpu().flatten()
+    return float(a @ b / (a.norm() * b.norm()))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def test_embedding_rows_and_range_check():
+    g = torch.Generator().manual_seed(0)
+    table = bf(torch.randn(97, 256, generator=g))
+    ids = torch.randint(0, 97, (50,), generator=g)
+    out = ops.embedding_rows(ids.to(DEV), table.to(DEV))
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), table[ids].float())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.embedding_rows(ids, table)
+
+
+@pytest.mark.parametrize("rows,dim", [(37, 256), (5, 4096), (3, 8192), (64, 1000)])
+def test_rmsnorm_rows_vs_oracle(rows, dim):
+    g = torch.Generator().manual_seed(rows + dim)
+    x = torch.randn(rows, dim, generator=g) * 3
+    w = torch.rand(dim, generator=g) + 0.5
+    ref = T.t5_layer_norm(x, w)
+    out = ops.rmsnorm_rows(x.to(DEV), w.to(DEV), 1e-6)
+    assert out.dtype == torch.bfloat16 and rel_l2(out, ref) < 4e-3
+    out32 = ops.rmsnorm_rows(x.to(DEV), w.to(DEV), 1e-6, out_dtype=torch.float32)
+    assert rel_l2(out32, ref) < 1e-5
+
+
+def test_mul_bf16():
+    g = torch.Generator().manual_seed(2)
+    a, b = bf(torch.randn(77, 320, generator=g)), bf(torch.randn(77, 320, generator=g))
+    out = ops.mul_bf16(a.to(DEV), b.to(DEV))
+    assert torch.equal(out.cpu(), bf(a.float() * b.float()))
+    with pytest.raises(ValueError, match="multiple of 8"):
+        ops.mul_bf16(a[:1, :4].contiguous().to(DEV), b[:1, :4].contiguous().to(DEV))
+
+
+@pytest.mark.parametrize("H,L,D,K2", [(2, 72, 64, 128), (64, 512, 64, 512), (3, 132, 64, 192)])
+def test_gemm_batched_heads(H, L, D, K2):
+    """Both uses inside T5 attention: S_h = q_h k_h^T (operands interleaved by head inside packed rows) and
+    o_h = P_h v_h (W = rows of V^T)."""
+    g = torch.Generator().manual_seed(H * L)
+    A = H * D
+    qk = bf(torch.randn(L, 2 * A, generator=g)).to(DEV)
+    S = torch.empty(H, L, L, device=DEV)
+    ops.gemm_batched(qk[:, :D], D, qk[:, A:A + D], D, S[0], L * L, L, L, D, H, ops.EPI_F32)
+    q = qk[:, :A].float().view(L, H, D)
+    k = qk[:, A:].float().view(L, H, D)
+    ref = torch.einsum("inc,jnc->nij", q, k)
+    assert rel_l2(S, ref) < 1e-5
+    Lp = ops.round_up(L, 64)
+    P = torch.zeros(H, L, Lp, device=DEV, dtype=torch.bfloat16)
+    P[:, :, :L] = bf(torch.rand(H, L, L, generator=g)).to(DEV)
+    vt = torch.zeros(A, Lp, device=DEV, dtype=torch.bfloat16)
+    vt[:, :L] = bf(torch.randn(A, L, generator=g)).to(DEV)
+    o = torch.zeros(L, A, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_batched(P[0], L * Lp, vt[:D], D * Lp, o[:, :D], D, L, D, Lp, H, ops.EPI_BF16)
+    ref_o = torch.einsum("nij,ncj->inc", P[:, :, :L].float(), vt[:, :L].float().view(H, D, L)).reshape(L, A)
+    assert rel_l2(o, ref_o) < 4e-3
+    with pytest.raises(ValueError, match="past the end"):
+        ops.gemm_batched(P[0], L * Lp, vt[:D], D * Lp, o[:, :D], D, L, D, Lp, H + 1, ops.EPI_BF16)
+    with pytest.raises(RuntimeError, match="epilogue"):
+        ops.gemm_batched(P[0], L * Lp, vt[:D], D * Lp, o[:, :D], D, L, D, Lp, H, ops.EPI_GELU_BF16)
+
+
+@pytest.mark.parametrize("H,L,klen", [(2, 72, 37), (2, 72, 72), (64, 512, 19), (5, 600, 333)])
+def test_t5_softmax_bias_vs_oracle(H, L, klen):
+    g = torch.Generator().manual_seed(L + klen)
+    S = torch.randn(H, L, L, generator=g) * 3
+    table = torch.randn(32, H, generator=g)
+    lut = relative_position_buckets(L, 32)
+    Lp = ops.round_up(L, 64)
+    P = ops.t5_softmax_bias(S.to(DEV), table.to(DEV), lut.to(DEV), H, klen, Lp)
+    rel = torch.arange(L)[None, :] - torch.arange(L)[:, None]
+    bias = table[T.relative_position_bucket(rel, 32)].permute(2, 0, 1)
+    bias = bias.masked_fill((torch.arange(L) >= klen)[None, None, :], torch.finfo(torch.float32).min)
+    ref = torch.softmax(S + bias, dim=-1)
+    assert P.shape == (H, L, Lp) and float(P[:, :, klen:].abs().max() if klen < Lp else 0) == 0.0
+    assert rel_l2(P[:, :, :L], ref) < 4e-3
+    assert float((P[:, :, :L].float().sum(-1).cpu() - 1).abs().max()) < 1e-2
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    m = WanT5EncoderModel(shared_pos=False, dropout=0.0, **TINY)
+    m.load_state_dict(deterministic_t5_state_dict(**TINY), device=DEV)
+    return m
+
+
+def test_g13_encoder_vs_reference_fixture(golden, tiny_model):
+    g = golden("t5_g13_encoder")
+    ids, mask = torch.from_numpy(g["ids"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    out = tiny_model(ids, mask)[0]
+    assert out.shape == (3, 72, TINY["dim"]) and out.dtype == torch.bfloat16
+    lens = [37, 11, 72]
+    for b, n in enumerate(lens):      # the rows the pipeline keeps (pipeline_wan.py:181)
+        assert rel_l2(out[b, :n], g["out"][b, :n]) < 1.5e-2 and cosine(out[b, :n], g["out"][b, :n]) > 0.9998
+    # padded query rows carry what the reference computes there (they see the valid keys only)
+    assert rel_l2(out, g["out"]) < 1.5e-2
+    out_nm = tiny_model(ids[:1], None)[0]
+    assert rel_l2(out_nm, g["out_nomask"]) < 1.5e-2
+    assert rel_l2(out_nm[0, :37], g["out"][0, :37]) > 1e-3          # the mask matters
+
+
+def test_encoder_input_validation(tiny_model):
+    ids = torch.zeros(1, 16, dtype=torch.long, device=DEV)
+    with pytest.raises(IndexError):
+        tiny_model(ids + 1000)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tiny_model(ids.cpu())
+    m = torch.ones(1, 16, dtype=torch.long, device=DEV)
+    m[0, 3] = 0
+    with pytest.raises(NotImplementedError, match="prefix"):
+        tiny_model(ids, m)
+    with pytest.raises(NotImplementedError, match="shared_pos"):
+        WanT5EncoderModel(shared_pos=True, **TINY)
+    with pytest.raises(KeyError, match="missing"):
+        WanT5EncoderModel(shared_pos=False, **TINY).load_state_dict({}, device=DEV)
+
+
+def test_encoder_mid_size_vs_oracle_and_batch_independence():
+    """dim 512 / 8 heads / 512-token padding as the pipeline uses it: vs the fp32 oracle evaluated on the same
+    bf16-rounded weights; a sample's valid rows must not depend on its batch neighbours."""
+    cfg = dict(vocab=1000, dim=512, dim_attn=512, dim_ffn=1280, num_heads=8, num_layers=3, num_buckets=32)
+    sd = random_t5_state_dict("cpu", seed=1, **cfg)
+    m = WanT5EncoderModel(shared_pos=False, **cfg)
+    m.load_state_dict(sd, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    L, lens = 512, [300, 41]
+    ids = torch.randint(1, 1000, (2, L), generator=g)
+    mask = torch.zeros(2, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    out = m(ids.to(DEV), mask.to(DEV))[0]
+    ref = T.T5EncoderOracle(sd, 8, 3, 32).forward(ids, mask)
+    for b, n in enumerate(lens):
+        assert rel_l2(out[b, :n], ref[b, :n]) < 1.5e-2 and cosine(out[b, :n], ref[b, :n]) > 0.9998
+    solo = m(ids[1:].to(DEV), mask[1:].to(DEV))[0]
+    assert torch.equal(solo[0, :41], out[1, :41])
+    # a length that is not a multiple of 4 (internally padded with masked positions), no mask given
+    short = m(ids[:1, :30].to(DEV))[0]
+    assert short.shape == (1, 30, 512)
+    assert rel_l2(short, T.T5EncoderOracle(sd, 8, 3, 32).forward(ids[:1, :30])) < 1.5e-2

@@ -55,6 +55,13 @@ SIGNATURES = {
                                c_int, c_int, c_int, c_void_p]),
     "wan_lincomb": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                             c_int64, c_void_p]),
+    "wan_gemm_bf16_batched": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_embedding_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "wan_rmsnorm_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p]),
+    "wan_t5_softmax_bias": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p]),
+    "wan_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_conv_cl": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                             POINTER(ConvParams), c_void_p]),
     "wan_rmsnorm_silu_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

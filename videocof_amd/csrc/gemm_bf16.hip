@@ -42,6 +42,7 @@ struct GemmArgs {
     const float* gate; int64_t rows_per_batch;
     int M, N, K;
     int tiles_m, tiles_n;
+    int64_t sA, sW, sO;      // element strides between the problems of a batched launch (blockIdx.y)
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -70,6 +71,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     int tm, tn;
     tile_coords(g, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    if (gridDim.y > 1) {         // wan_gemm_bf16_batched: problem blockIdx.y
+        g.A += blockIdx.y * g.sA;
+        g.W += blockIdx.y * g.sW;
+        g.out = (char*)g.out + blockIdx.y * g.sO * ((EPI == WAN_EPI_F32 || EPI == WAN_EPI_RESID_F32) ? 4 : 2);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 template <int EPI>
-wan_status_t launch(const GemmArgs& g, hipStream_t s) {
+wan_status_t launch(const GemmArgs& g, hipStream_t s, int batch = 1) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
@@ -223,7 +229,7 @@ wan_status_t launch(const GemmArgs& g, hipStream_t s) {
         }
         attr_set = true;
     }
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kThreads);
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch), block(kThreads);
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, kLdsBytes, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16");
     return WAN_OK;
@@ -260,6 +266,7 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    g.sA = g.sW = g.sO = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case WAN_EPI_BF16: return launch<WAN_EPI_BF16>(g, s);
@@ -269,4 +276,29 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
         case WAN_EPI_BF16_T: return launch<WAN_EPI_BF16_T>(g, s);
         default: wan_set_error("wan_gemm_bf16: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
     }
+}
+
+extern "C" wan_status_t wan_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,
+                                              int64_t strideW, void* out, int64_t ldo, int64_t strideO,
+                                              int M, int N, int K, int batch, int epilogue, void* stream) {
+    WAN_REQUIRE(A && W && out, WAN_ERR_INVALID, "wan_gemm_bf16_batched: null tensor");
+    WAN_REQUIRE(M >= 0 && N > 0 && K > 0 && batch >= 0 && batch <= 65535, WAN_ERR_INVALID,
+                "wan_gemm_bf16_batched: M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    WAN_REQUIRE(K % BK == 0 && N % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_bf16_batched: K=%d %% 64 and N=%d %% 4 must be 0", K, N);
+    WAN_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && strideA % 8 == 0 && strideW % 8 == 0, WAN_ERR_INVALID,
+                "wan_gemm_bf16_batched: lda=%lld ldw=%lld strideA=%lld strideW=%lld must be multiples of 8, ld >= K",
+                (long long)lda, (long long)ldw, (long long)strideA, (long long)strideW);
+    WAN_REQUIRE(ldo >= N && ldo % 4 == 0 && strideO % 4 == 0, WAN_ERR_INVALID,
+                "wan_gemm_bf16_batched: ldo=%lld strideO=%lld", (long long)ldo, (long long)strideO);
+    WAN_REQUIRE(epilogue == WAN_EPI_BF16 || epilogue == WAN_EPI_F32, WAN_ERR_UNSUPPORTED,
+                "wan_gemm_bf16_batched: epilogue %d (only WAN_EPI_BF16 / WAN_EPI_F32)", epilogue);
+    if (M == 0 || batch == 0) return WAN_OK;
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = nullptr;
+    g.out = out; g.ldo = ldo; g.gate = nullptr; g.rows_per_batch = 1;
+    g.M = M; g.N = N; g.K = K;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    g.sA = strideA; g.sW = strideW; g.sO = strideO;
+    hipStream_t s = (hipStream_t)stream;
+    return epilogue == WAN_EPI_BF16 ? launch<WAN_EPI_BF16>(g, s, batch) : launch<WAN_EPI_F32>(g, s, batch);
 }

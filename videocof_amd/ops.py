@@ -336,3 +336,96 @@ def lincomb(terms, out_dtype: torch.dtype) -> torch.Tensor:
     _lib.check(lib.wan_lincomb(_p(out), 0 if out_dtype == torch.float32 else 1, ps[0], ps[1], ps[2], ps[3],
                                cs[0], cs[1], cs[2], cs[3], out.numel(), _stream()), "wan_lincomb")
     return out
+
+
+# ------------------------------------------------------------------ umT5 text encoder rows
+def _avail(t: torch.Tensor) -> int:
+    """Elements from t's first element to the end of its storage."""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+def gemm_batched(a: torch.Tensor, stride_a: int, w: torch.Tensor, stride_w: int, out: torch.Tensor, stride_o: int,
+                 M: int, N: int, K: int, batch: int, epilogue: int) -> torch.Tensor:
+    """`batch` independent products out_z[m,n] = sum_k a_z[m,k] * w_z[n,k] (one per attention head).
+    a / w / out are 2-D views (unit inner stride) of problem 0; problem z starts `stride_*` elements later
+    in the same storage.  EPI_BF16 or EPI_F32."""
+    _need(a, torch.bfloat16, "gemm_batched.a")
+    _need(w, torch.bfloat16, "gemm_batched.w")
+    _need(out, torch.float32 if epilogue == EPI_F32 else torch.bfloat16, "gemm_batched.out")
+    for nm, t in (("a", a), ("w", w), ("out", out)):
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm_batched.{nm} must be a 2-D view with unit inner stride")
+    lda, ldw, ldo = a.stride(0), w.stride(0), out.stride(0)
+    if min(batch, M, N, K) < 1 or min(stride_a, stride_w, stride_o) < 0:
+        raise ValueError("gemm_batched: empty problem or negative stride")
+    if (_avail(a) < (batch - 1) * stride_a + (M - 1) * lda + K or _avail(w) < (batch - 1) * stride_w + (N - 1) * ldw + K
+            or _avail(out) < (batch - 1) * stride_o + (M - 1) * ldo + N):
+        raise ValueError("gemm_batched: the strided problem runs past the end of an operand's storage")
+    lib = _lib.load()
+    _lib.check(lib.wan_gemm_bf16_batched(_p(a), lda, stride_a, _p(w), ldw, stride_w, _p(out), ldo, stride_o,
+                                         M, N, K, batch, epilogue, _stream()), "wan_gemm_bf16_batched")
+    return out
+
+
+def embedding_rows(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """ids int64 [n] -> fp32 [n, dim] rows of the bf16 table [vocab, dim]."""
+    _need(ids, torch.int64, "embedding.ids")
+    _need(table, torch.bfloat16, "embedding.table")
+    if ids.dim() != 1 or table.dim() != 2 or not (ids.is_contiguous() and table.is_contiguous()):
+        raise ValueError("embedding: ids must be contiguous [n] and table contiguous [vocab, dim]")
+    out = torch.empty(ids.numel(), table.shape[1], device=ids.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.wan_embedding_rows(_p(ids), _p(table), table.shape[0], _p(out), ids.numel(), table.shape[1],
+                                      _stream()), "wan_embedding_rows")
+    return out
+
+
+def rmsnorm_rows(x: torch.Tensor, w: torch.Tensor, eps: float, out_dtype: torch.dtype = torch.bfloat16,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T5LayerNorm of fp32 rows [rows, dim] -> bf16 (GEMM input) or fp32."""
+    _need(x, torch.float32, "rmsnorm_rows.x")
+    _need(w, torch.float32, "rmsnorm_rows.w")
+    if x.dim() != 2 or not x.is_contiguous() or w.numel() != x.shape[1]:
+        raise ValueError("rmsnorm_rows: x must be contiguous [rows, dim] and w [dim]")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("rmsnorm_rows: out_dtype must be float32 or bfloat16")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    _need(out, out_dtype, "rmsnorm_rows.out")
+    lib = _lib.load()
+    _lib.check(lib.wan_rmsnorm_rows(_p(x), _p(w), _p(out), 0 if out_dtype == torch.float32 else 1, x.shape[0],
+                                    x.shape[1], float(eps), _stream()), "wan_rmsnorm_rows")
+    return out
+
+
+def t5_softmax_bias(scores: torch.Tensor, table: torch.Tensor, lut: torch.Tensor, num_heads: int, k_len: int,
+                    npad: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scores fp32 [H, L, L] -> probs bf16 [H, L, npad] = softmax_j(scores + rel-pos bias), keys >= k_len masked."""
+    _need(scores, torch.float32, "t5_softmax.scores")
+    _need(table, torch.float32, "t5_softmax.table")
+    _need(lut, torch.int32, "t5_softmax.lut")
+    H, Lq, Lk = scores.shape
+    if H != num_heads or not scores.is_contiguous() or table.shape != (table.shape[0], H) or not table.is_contiguous():
+        raise ValueError("t5_softmax: scores must be contiguous [H, Lq, Lk], table contiguous [num_buckets, H]")
+    if lut.numel() != Lq + Lk - 1:
+        raise ValueError("t5_softmax: lut must have Lq + Lk - 1 entries")
+    if out is None:
+        out = torch.empty(H, Lq, npad, device=scores.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "t5_softmax.out")
+    lib = _lib.load()
+    _lib.check(lib.wan_t5_softmax_bias(_p(scores), Lk, _p(table), _p(lut), _p(out), out.stride(1), H, Lq, Lk,
+                                       int(k_len), int(npad), _stream()), "wan_t5_softmax_bias")
+    return out
+
+
+def mul_bf16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(a, torch.bfloat16, "mul.a")
+    _need(b, torch.bfloat16, "mul.b")
+    if a.shape != b.shape or not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("mul_bf16: operands must be contiguous and of equal shape")
+    if out is None:
+        out = torch.empty_like(a)
+    _need(out, torch.bfloat16, "mul.out")
+    lib = _lib.load()
+    _lib.check(lib.wan_mul_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "wan_mul_bf16")
+    return out

@@ -215,3 +215,67 @@ def random_vae_state_dict(device, seed: int = 0, **cfg) -> Dict[str, torch.Tenso
             fan_in = int(np.prod(shape[1:]))
             sd[name] = (torch.rand(shape, device=device, generator=g) * 2 - 1) * (3.0 / fan_in) ** 0.5
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# umT5 encoder (videox_fun/models/wan_text_encoder.py:266-279), shared_pos=False: parameter names as in
+# WanT5EncoderModel.state_dict()
+# ----------------------------------------------------------------------------------------------
+def t5_param_shapes(vocab: int, dim: int, dim_attn: int, dim_ffn: int, num_heads: int, num_layers: int,
+                    num_buckets: int) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {"token_embedding.weight": (vocab, dim), "norm.weight": (dim,)}
+    for i in range(num_layers):
+        p = f"blocks.{i}."
+        s[p + "norm1.weight"] = (dim,)
+        s[p + "attn.q.weight"] = (dim_attn, dim)
+        s[p + "attn.k.weight"] = (dim_attn, dim)
+        s[p + "attn.v.weight"] = (dim_attn, dim)
+        s[p + "attn.o.weight"] = (dim, dim_attn)
+        s[p + "norm2.weight"] = (dim,)
+        s[p + "ffn.gate.0.weight"] = (dim_ffn, dim)
+        s[p + "ffn.fc1.weight"] = (dim_ffn, dim)
+        s[p + "ffn.fc2.weight"] = (dim, dim_ffn)
+        s[p + "pos_embedding.embedding.weight"] = (num_buckets, num_heads)
+    return s
+
+
+def _t5_scale(name: str, shape, dim: int, dim_attn: int, dim_ffn: int) -> float:
+    """Uniform half-width giving the std of init_weights (wan_text_encoder.py:21-35), but with a q scale
+    that keeps un-scaled T5 scores O(1) and a position table large enough to matter in the tests."""
+    if name.endswith("attn.q.weight"):
+        return (3.0 / dim) ** 0.5 * (dim_attn // 1) ** -0.25
+    if name.endswith(("attn.k.weight", "attn.v.weight", "ffn.gate.0.weight", "ffn.fc1.weight")):
+        return (3.0 / dim) ** 0.5
+    if name.endswith("attn.o.weight"):
+        return (3.0 / dim_attn) ** 0.5
+    if name.endswith("ffn.fc2.weight"):
+        return (3.0 / dim_ffn) ** 0.5
+    if name.endswith("pos_embedding.embedding.weight"):
+        return 1.5
+    if name == "token_embedding.weight":
+        return 1.7
+    raise KeyError(name)
+
+
+def deterministic_t5_state_dict(**cfg) -> Dict[str, torch.Tensor]:
+    sd = {}
+    for name, shape in t5_param_shapes(**cfg).items():
+        if name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
+            sd[name] = det_uniform("t5." + name, shape, 0.25, 1.0)
+        else:
+            sd[name] = det_uniform("t5." + name, shape, _t5_scale(name, shape, cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"]))
+    return sd
+
+
+@torch.no_grad()
+def random_t5_state_dict(device, dtype=torch.bfloat16, seed: int = 0, **cfg) -> Dict[str, torch.Tensor]:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sd = {}
+    for name, shape in t5_param_shapes(**cfg).items():
+        if name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
+            sd[name] = torch.ones(shape, device=device, dtype=dtype)
+        else:
+            hw = _t5_scale(name, shape, cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"])
+            sd[name] = ((torch.rand(shape, device=device, generator=g, dtype=torch.float32) * 2 - 1) * hw).to(dtype)
+    return sd
