@@ -169,3 +169,53 @@ def test_encoder_mid_size_vs_oracle_and_batch_independence():
     short = m(ids[:1, :30].to(DEV))[0]
     assert short.shape == (1, 30, 512)
     assert rel_l2(short, T.T5EncoderOracle(sd, 8, 3, 32).forward(ids[:1, :30])) < 1.5e-2
+
+
+class _ToyTokenizer:
+    """Same call contract as the HuggingFace tokenizer the reference uses (pipeline_wan.py:154-163):
+    padding to max_length with id 0, attention_mask, an end-of-sequence token."""
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def __call__(self, prompt, padding=None, max_length=512, truncation=True, add_special_tokens=True, return_tensors="pt"):
+        assert padding == "max_length" and return_tensors == "pt"
+        ids = torch.zeros(len(prompt), max_length, dtype=torch.long)
+        mask = torch.zeros(len(prompt), max_length, dtype=torch.long)
+        for b, p in enumerate(prompt):
+            toks = [2 + (sum(map(ord, w)) % (self.vocab - 2)) for w in p.split()][: max_length - 1] + [1]
+            ids[b, :len(toks)] = torch.tensor(toks)
+            mask[b, :len(toks)] = 1
+        from types import SimpleNamespace
+        return SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+
+def test_pipeline_encodes_prompt_strings_with_the_hip_encoder():
+    """WanPipeline(tokenizer, text_encoder, ...): prompt strings -> umT5 on the GPU -> DiT context
+    (pipeline_wan.py:140-181, 595-608) == the same call fed with the oracle's embeddings of the same tokens."""
+    from oracle import wan_oracle as O
+    from videocof_amd import FlowUniPCMultistepScheduler, WanPipeline, WanTransformer3DModel
+    from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+    tcfg = dict(vocab=211, dim=64, dim_attn=64, dim_ffn=128, num_heads=1, num_layers=2, num_buckets=32)
+    tsd = deterministic_t5_state_dict(**tcfg)
+    t5 = WanT5EncoderModel(shared_pos=False, **tcfg)
+    t5.load_state_dict(tsd, device=DEV)
+    tok = _ToyTokenizer(211)
+    dit = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    dit.load_state_dict(deterministic_dit_state_dict(dim=256, ffn_dim=512, num_layers=2, text_dim=64), device=DEV)
+    pipe = WanPipeline(tokenizer=tok, text_encoder=t5, transformer=dit, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    src = det_uniform("t5p.src", (1, 16, 3, 12, 20), 1.0).to(DEV)
+    lat = torch.cat([src, det_uniform("t5p.noise", (1, 16, 4, 12, 20), 1.7).to(DEV)], dim=2)    # src | ground | tgt
+    prompt, neg = "remove the red cup from the wooden table", "blurry, low quality"
+    kw = dict(latents=lat, height=96, width=160, source_frames=9, reasoning_frames=4,
+              num_inference_steps=3, guidance_scale=5.0, shift=5.0, repeat_rope=True, cot=True,
+              weight_dtype=torch.float32, output_type="latent")
+    got = pipe(prompt=prompt, negative_prompt=neg, **kw).latents
+    enc = tok([prompt, neg], padding="max_length", max_length=512)
+    ref_emb = T.T5EncoderOracle(tsd, 1, 2, 32).forward(enc.input_ids, enc.attention_mask)
+    n = enc.attention_mask.sum(1).tolist()
+    assert n == [9, 4]
+    embeds = pipe.encode_prompt(prompt, neg, True, None, None, torch.device(DEV))
+    assert [tuple(e.shape) for e in embeds[0]] == [(9, 64)] and [tuple(e.shape) for e in embeds[1]] == [(4, 64)]
+    assert rel_l2(embeds[0][0], ref_emb[0, :9]) < 1.5e-2 and rel_l2(embeds[1][0], ref_emb[1, :4]) < 1.5e-2
+    want = pipe(prompt_embeds=[ref_emb[0, :9].to(DEV)], negative_prompt_embeds=[ref_emb[1, :4].to(DEV)], **kw).latents
+    assert rel_l2(got, want) < 2e-2

@@ -14,10 +14,11 @@ edit_videos)``.  The denoise loop reproduces the reference's glue exactly:
               latents = scheduler.step(v, t, latents)[0]                    (:740)
     decode only the grounding and edit segments                             (:760-777)
 
-The umT5 text encoder is outside the hot path: pass
-``prompt_embeds`` / ``negative_prompt_embeds`` (lists of ``[len<=512, 4096]``
-tensors) or construct the pipeline with a ``text_encoder`` callable
-``(list[str]) -> list[Tensor]``.
+Prompts: with a ``tokenizer`` (a HuggingFace tokenizer object, e.g. ``AutoTokenizer`` of
+``google/umt5-xxl``) and a ``videocof_amd.WanT5EncoderModel`` the strings are encoded on the GPU as in
+``_get_t5_prompt_embeds`` (:140-181); alternatively pass ``prompt_embeds`` /
+``negative_prompt_embeds`` (lists of ``[len<=512, 4096]`` tensors), or a plain callable
+``text_encoder(list[str]) -> list[Tensor]`` without a tokenizer.
 """
 from __future__ import annotations
 
@@ -56,11 +57,27 @@ class WanPipeline:
     interrupt = property(lambda self: self._interrupt)
 
     # -------------------------------------------------------------- prompt handling (:595-608)
-    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device):
+    def _get_t5_prompt_embeds(self, prompt, max_sequence_length: int = 512, device=None):
+        """tokenizer(padding="max_length", max_length=512, truncation) -> text_encoder(ids, mask)[0], each
+        sample trimmed to its own token count (pipeline_wan.py:140-181)."""
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        enc = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                             add_special_tokens=True, return_tensors="pt")
+        ids = enc.input_ids if hasattr(enc, "input_ids") else enc["input_ids"]
+        mask = enc.attention_mask if hasattr(enc, "attention_mask") else enc["attention_mask"]
+        seq_lens = mask.gt(0).sum(dim=1).long().tolist()
+        hidden = self.text_encoder(ids.to(device), attention_mask=mask.to(device))[0]
+        return [u[:v] for u, v in zip(hidden, seq_lens)]
+
+    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device,
+                      max_sequence_length: int = 512):
         def enc(p):
             if self.text_encoder is None:
-                raise ValueError("no text_encoder: provide `prompt_embeds` (umT5 is outside the accelerated path)")
+                raise ValueError("no text_encoder: provide `prompt_embeds`, or build the pipeline with a tokenizer "
+                                 "and a WanT5EncoderModel")
             p = [p] if isinstance(p, str) else list(p)
+            if self.tokenizer is not None:
+                return self._get_t5_prompt_embeds(p, max_sequence_length, device)
             return [e.to(device) for e in self.text_encoder(p)]
         if prompt_embeds is None:
             prompt_embeds = enc(prompt)
@@ -127,7 +144,7 @@ class WanPipeline:
         device = torch.device(device) if device is not None else self.transformer.device
         do_cfg = guidance_scale > 1.0                                                           # :592
         prompt_embeds, negative_prompt_embeds = self.encode_prompt(
-            prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device)
+            prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device, max_sequence_length)
         in_prompt_embeds = (negative_prompt_embeds + prompt_embeds) if do_cfg else prompt_embeds   # :605-608
 
         if not isinstance(self.scheduler, FlowUniPCMultistepScheduler):
