@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 counter passes per kernel.
+
+    python tools/pmc_summary.py OUT.json NAME=DIR [NAME=DIR ...]
+
+Each DIR is the `-d` directory of one `rocprofv3 --pmc <COUNTER> -- python bench.py ...` pass (one counter
+per pass, as MI355X_MICROARCH.md prescribes).  For every kernel the average counter value per launch and the
+average launch duration are written; FETCH_SIZE / WRITE_SIZE are reported in KB as the counter delivers them
+(the x2 gfx950 correction of FETCH_SIZE is applied by the reader, bench.py:pmc_traffic)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    m = re.search(r"(attn_fwd_v2_kernel<[^>]*>|attn_fwd_kernel<[^>]*>|gemm256_kernel<[^>]*>|gemm_bf16_kernel<[^>]*>|"
+                  r"ln_modulate_kernel|rmsnorm_rope_kernel|rmsnorm_rope|conv_cl_kernel<[^>]*>)", name)
+    return m.group(1) if m else name[:60]
+
+
+def main():
+    out, passes = sys.argv[1], dict(a.split("=", 1) for a in sys.argv[2:])
+    res = defaultdict(dict)
+    for pname, d in passes.items():
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        acc = defaultdict(lambda: [0, 0.0, 0.0, 0])
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                a = acc[k]
+                a[0] += 1
+                a[1] += float(row["Counter_Value"])
+                a[2] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                a[3] = int(row["Grid_Size"])
+        for k, (n, v, ms, grid) in acc.items():
+            res[k][pname] = {"launches_counted": n, "avg_counter": v / n, "avg_ms": ms / n, "grid": grid}
+    keep = {k: v for k, v in res.items() if any(p["avg_ms"] > 0.05 for p in v.values())}
+    json.dump(keep, open(out, "w"), indent=1)
+    for k, v in sorted(keep.items(), key=lambda kv: -max(p["avg_ms"] * p["launches_counted"] for p in kv[1].values()))[:12]:
+        print(k, {p: (round(x["avg_counter"]), round(x["avg_ms"], 3)) for p, x in v.items()})
+
+
+if __name__ == "__main__":
+    main()
