@@ -161,6 +161,32 @@ def test_wider_model_3_heads_vs_oracle():
     assert rel_l2(out, ref) < 1e-2 and cosine(out, ref) > 0.9999
 
 
+def test_baseline_config0_wan_1p3b_single_forward_vs_cpu_oracle():
+    """BASELINE.json configs[0]: the real Wan2.1-T2V-1.3B architecture (dim 1536, 12 heads, ffn 8960, 30 layers,
+    text_dim 4096, 1.42 B parameters) on a 9 x 32 x 32 random latent (L = 2304), CoF layout 4|1|4, one forward
+    against the fp32 CPU oracle on the same weights (random, rounded to bf16 so both sides hold identical values)."""
+    from videocof_amd.weights import random_dit_state_dict
+    cfgd = dict(dim=1536, ffn_dim=8960, num_layers=30, in_dim=16, out_dim=16, text_dim=4096, freq_dim=256)
+    sd = random_dit_state_dict("cpu", dtype=torch.bfloat16, seed=3, **cfgd)
+    g = torch.Generator().manual_seed(0)
+    for k in sd:                      # random_* zeroes biases / unit norms: perturb them so they are exercised
+        if k.endswith(".bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+        elif k.endswith(("norm_q.weight", "norm_k.weight", "norm3.weight")):
+            sd[k] = 1 + torch.randn(sd[k].shape, generator=g) * 0.1
+    sd = {k: v.float() for k, v in sd.items()}
+    m = WanTransformer3DModel(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, text_dim=4096)
+    m.load_state_dict(sd, device=DEV)
+    lat = torch.randn(1, 16, 9, 32, 32, generator=g)
+    ctx = [torch.randn(77, 4096, generator=g)]
+    out = m(lat.to(DEV), torch.tensor([749], device=DEV), [c.to(DEV) for c in ctx], 2304,
+            frame_split_indices=[4], ground_frame_indices=[(4, 5)])
+    cfg = O.DiTConfig(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, text_dim=4096)
+    ref = O.dit_forward(sd, cfg, lat, torch.tensor([749]), ctx, 2304, [4], [(4, 5)])
+    assert out.shape == ref.shape == (1, 16, 9, 32, 32)
+    assert rel_l2(out, ref) < 1.5e-2 and cosine(out, ref) > 0.9999
+
+
 def test_end_to_end_video_in_video_out():
     """WanPipeline with the HIP VAE and the HIP DiT: source video -> VAE encode -> CoF latents ->
     4-step denoise -> decode ground + edit segments, against the same chain built from the CPU oracles
