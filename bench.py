@@ -46,6 +46,11 @@ WORKLOADS = {
                      desc="Wan2.1-T2V-1.3B + VideoCoF layout, 4-step, 81f@480p (BASELINE configs[1])"),
     "14b-t2v": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=0, g=0, ft=21, h=60, w=104,
                     desc="Wan2.1-T2V-14B plain T2V layout, 81f@480p"),
+    "14b-720p": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=0, g=0, ft=21, h=90, w=160,
+                     desc="Wan2.1-T2V-14B plain T2V layout, 81f@720p (BASELINE configs[3] shape; 50-step in the reference)"),
+    "14b-cof-321f-720p": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=81, g=1, ft=81, h=90, w=160,
+                              desc="Wan2.1-T2V-14B + VideoCoF layout, 321f@720p length extrapolation (BASELINE configs[4] shape; "
+                                   "586 800 tokens -- meant for --gpus 8)"),
     "1.3b-small": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, fs=4, g=1, ft=4, h=32, w=32,
                        desc="Wan2.1-T2V-1.3B dims on a 9x32x32 latent (BASELINE configs[0] shape, plumbing)"),
 }

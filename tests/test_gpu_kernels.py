@@ -318,6 +318,41 @@ def test_attention_full_size_properties():
         assert rel_l2(o1[0, rows, h * 128:(h + 1) * 128], ref.cpu()) < 6e-3
 
 
+def test_config4_length_321f_720p_rope_and_attention(rope_dev):
+    """BASELINE configs[4] sequence length: VideoCoF layout of a 321-frame 720p clip = (81 + 1 + 81) x 45 x 80 =
+    586 800 tokens, one head.  (i) RMSNorm + CoF RoPE on slabs at the start, across the source/ground/target
+    boundaries and at the end vs the oracle evaluated at the same global token offsets; (ii) attention over the
+    full length: constant V column => constant output, and sampled queries vs an fp32 softmax."""
+    F, Hp, Wp = 163, 45, 80
+    L, C, hw = F * Hp * Wp, 128, 45 * 80
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(L, 2 * C, device=DEV, generator=g).bfloat16()
+    w = (torch.rand(C, device=DEV, generator=g) + 0.5)
+    qk = x.clone()
+    rp = RopeParams(F, Hp, Wp, 2, 81, 82, 0, L, 1024)
+    qs = ops.q_prescale(128)
+    ops.rmsnorm_rope_(qk[:, :C], w, qk[:, C:], w, 128, 1e-6, rope_dev, rp, x0_scale=qs)
+    ang = O.rope_angles(128)
+    for off in (0, 81 * hw - 130, 82 * hw - 130, L - 260):
+        xs = x[off:off + 260, C:].float().cpu()
+        ref = O.rope_apply(O.rms_norm(xs, w.cpu(), 1e-6).view(260, 1, 128), (F, Hp, Wp), ang, 81, (81, 82),
+                           token_offset=off, total_tokens=L).reshape(260, C)
+        assert rel_l2(qk[off:off + 260, C:], ref) < 4e-3, off
+    # temporal positions really are src 1..81 | ground 0 | tgt 1..81: token of frame 82 (first target) == frame 0's map
+    q, k = qk[None, :, :C], qk[None, :, C:]
+    colv = torch.linspace(-2, 2, C, device=DEV).bfloat16()
+    ld = ops.round_up(L, 64)
+    vt = torch.zeros(1, C, ld, device=DEV, dtype=torch.bfloat16)
+    vt[0, :, :L] = colv[:, None]
+    out = ops.attention_fwd(q, k, vt, 1, q_prescaled=True)
+    assert float((out[0].float() - colv.float()).abs().max()) < 2e-2
+    v = torch.randn(L, C, device=DEV, generator=g).bfloat16()
+    rows = torch.tensor([0, 255, 256, 300000, L - 257, L - 1], device=DEV)
+    o = ops.attention_fwd(q[:, rows].contiguous(), k, ops.transpose_pad(v)[None], 1, q_prescaled=True)
+    p = torch.softmax((q[0, rows].float() / qs) @ k[0].float().t() / 128 ** 0.5, dim=-1)
+    assert rel_l2(o[0], (p @ v.float()).cpu()) < 6e-3
+
+
 def test_gemm_full_size_vs_fp32_matmul_samples():
     """14B FFN shapes at M = 67 080: sampled rows vs an fp32 matmul of the same bf16 operands."""
     M, C, Fd = 67080, 5120, 13824
