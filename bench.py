@@ -237,7 +237,7 @@ def main():
         flop = 4.0 * Lq * Lk * heads_local * 128
         ach = flop / (avg_ms * 1e-3) / 1e12
         traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1)
-        roof = {"kernel": "attn_fwd_v2_kernel<0> (self-attention)", "bound": "mfma", "achieved": round(ach, 1),
+        roof = {"kernel": "attn_fwd_v2_kernel<0, true> (self-attention; per wan_attention_fwd call = main launch + split-KV tail round + merge)", "bound": "mfma", "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}

@@ -135,7 +135,14 @@ wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                const void* vt, int64_t ldvt, int64_t vt_bstride,
                                void* out, int64_t ldo, int64_t o_bstride,
                                int batch, int Lq, int Lk, int num_heads, int head_dim,
-                               float softmax_scale, int flags, void* stream);
+                               float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+/* Optional scratch for wan_attention_fwd (16-byte aligned device memory, contents irrelevant, reusable across
+ * calls on one stream).  With at least this many bytes the last, partially filled round of workgroups of a long
+ * self-attention launch is split over the key range so that it fills the chip (matters when few heads are
+ * local, e.g. the 5 heads per GPU of an 8-way Ulysses shard: +10 %); 0 = this shape is launched plainly anyway.
+ * workspace = NULL is always valid. */
+int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim);
 #define WAN_ATTN_Q_PRESCALED 1
 #define WAN_ATTN_QSCALE(softmax_scale) ((softmax_scale) * 1.4426950408889634f)
 

@@ -48,7 +48,7 @@ def test_argument_errors_map_to_python_exceptions():
     assert st == _lib.WAN_ERR_INVALID
     with pytest.raises(ValueError, match="null tensor"):
         _lib.check(st, "wan_ln_modulate")
-    st = lib.wan_attention_fwd(1, 128, 0, 1, 128, 0, 1, 64, 0, 1, 128, 0, 1, 8, 8, 1, 64, 0.1, 0, None)
+    st = lib.wan_attention_fwd(1, 128, 0, 1, 128, 0, 1, 64, 0, 1, 128, 0, 1, 8, 8, 1, 64, 0.1, 0, None, 0, None)
     assert st == _lib.WAN_ERR_UNSUPPORTED      # head_dim 64 is not built
     with pytest.raises(RuntimeError, match="head_dim"):
         _lib.check(st, "wan_attention_fwd")

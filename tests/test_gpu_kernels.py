@@ -226,7 +226,7 @@ def test_attention_prescaled_q_path(Lq, Lk, H, qs, spike):
     assert rel_l2(plain, _attn_ref(bf(q), k, v).view(1, Lq, C)) < 6e-3
     with pytest.raises(ValueError, match="unknown flags"):
         from videocof_amd import _lib
-        _lib.check(_lib.load().wan_attention_fwd(1, C, 0, 1, C, 0, 1, 64, 0, 1, C, 0, 1, 8, 8, H, 128, 0.1, 6, None),
+        _lib.check(_lib.load().wan_attention_fwd(1, C, 0, 1, C, 0, 1, 64, 0, 1, C, 0, 1, 8, 8, H, 128, 0.1, 6, None, 0, None),
                    "wan_attention_fwd")
 
 
@@ -261,6 +261,40 @@ def test_attention_is_bitwise_reproducible():
         for pre in (False, True):
             outs = [ops.attention_fwd(q, k, vt, H, q_prescaled=pre).clone() for _ in range(4)]
             assert all(torch.equal(outs[0], o) for o in outs[1:]), (Lq, Lk, H, pre)
+
+
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_split_tail_round(pre, monkeypatch):
+    """Launches whose workgroup count leaves a small remainder over the CU count run their last query blocks
+    split over the key range + a merge kernel (wan_attention_workspace_bytes > 0).  Same function as the plain
+    launch (WAN_ATTN_TAIL=0) and as the oracle, including the ragged last key tile inside the last split."""
+    from videocof_amd import _lib
+    Lq, Lk, H = 86 * 256 + 10, 1100, 3                  # 87 x 3 = 261 workgroups = 256 + 5
+    C = H * 128
+    assert _lib.load().wan_attention_workspace_bytes(1, Lq, Lk, H, 128) > 0
+    assert _lib.load().wan_attention_workspace_bytes(1, 4096, Lk, H, 128) == 0      # fits one round: plain launch
+    g = torch.Generator(device=DEV).manual_seed(8)
+    q = torch.randn(1, Lq, C, device=DEV, generator=g).bfloat16()
+    k = torch.randn(1, Lk, C, device=DEV, generator=g).bfloat16()
+    v = (torch.randn(Lk, C, device=DEV, generator=g) + torch.arange(C, device=DEV) % 128 * 0.01).bfloat16()
+    k[0, 1090] = (q[0, -300:].float().mean(0) * 30).bfloat16()       # a spike inside the last split, seen by the tail rows
+    vt = ops.transpose_pad(v)[None]
+    qq = (q.float() * ops.q_prescale(128)).bfloat16() if pre else q
+    out = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
+    monkeypatch.setenv("WAN_ATTN_TAIL", "0")
+    plain = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
+    monkeypatch.delenv("WAN_ATTN_TAIL")
+    assert torch.equal(out[:, :85 * 256], plain[:, :85 * 256])       # main launch untouched
+    assert not torch.equal(out[:, 85 * 256:], plain[:, 85 * 256:])   # tail rows really took the other path
+    assert rel_l2(out[:, 85 * 256:], plain[:, 85 * 256:].cpu()) < 3e-3
+    rows = torch.cat([torch.arange(0, 40), torch.arange(Lq - 300, Lq)]).to(DEV)
+    qe = (qq[0, rows].float() / ops.q_prescale(128)) if pre else q[0, rows].float()
+    for h in range(H):
+        p = torch.softmax(qe[:, h * 128:(h + 1) * 128] @ k[0, :, h * 128:(h + 1) * 128].float().t() / 128 ** 0.5, dim=-1)
+        ref = p @ v[:, h * 128:(h + 1) * 128].float()
+        assert rel_l2(out[0, rows, h * 128:(h + 1) * 128], ref.cpu()) < 6e-3
+    again = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
+    assert torch.equal(again, out)
 
 
 def test_attention_rejects_unbuilt_options():

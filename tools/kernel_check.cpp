@@ -245,12 +245,13 @@ static void check_gemm() {
 }
 
 static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, const std::vector<float>& v,
-                     int Lq, int Lk, int H, float scale, std::vector<double>& out) {
+                     int Lq, int Lk, int H, float scale, std::vector<double>& out, const std::vector<int>& rows) {
     const int D = 128, C = H * D;
-    out.assign((size_t)Lq * C, 0);
+    out.assign(rows.size() * C, 0);
     std::vector<double> s(Lk);
     for (int h = 0; h < H; ++h)
-        for (int i = 0; i < Lq; ++i) {
+        for (size_t ri = 0; ri < rows.size(); ++ri) {
+            const int i = rows[ri];
             double mx = -1e300;
             for (int j = 0; j < Lk; ++j) {
                 double d = 0;
@@ -261,7 +262,7 @@ static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, c
             for (int j = 0; j < Lk; ++j) { s[j] = exp(s[j] - mx); den += s[j]; }
             for (int j = 0; j < Lk; ++j) {
                 const double p = s[j] / den;
-                for (int c = 0; c < D; ++c) out[(size_t)i * C + h * D + c] += p * v[(size_t)j * C + h * D + c];
+                for (int c = 0; c < D; ++c) out[ri * C + h * D + c] += p * v[(size_t)j * C + h * D + c];
             }
         }
 }
@@ -272,7 +273,7 @@ static void check_attn() {
     setenv("WAN_ATTN_VARIANT", pre ? "2" : var, 1);
     printf("wan_attention_fwd variant %s (+ wan_transpose_bf16)\n", var);
     struct Shape { int Lq, Lk, H; float qs; };
-    for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}}) {
+    for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}, Shape{86 * 256 + 10, 1100, 3, 1.f}}) {
         const int Lq = sh.Lq, Lk = sh.Lk, H = sh.H, C = H * 128;
         auto q = bf_round(randn((size_t)Lq * C, sh.qs)), k = bf_round(randn((size_t)Lk * C)), v = bf_round(randn((size_t)Lk * C));
         // make V asymmetric across d and key so a transposed/permuted read cannot pass
@@ -288,10 +289,19 @@ static void check_attn() {
             HIP(hipMemcpy(dq.p, to_bf(q).data(), q.size() * 2, hipMemcpyHostToDevice));
             for (auto& x : q) x /= cc;
         }
-        WAN(wan_attention_fwd(dq.p, C, 0, dk.p, C, 0, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, scale, pre ? WAN_ATTN_Q_PRESCALED : 0, nullptr));
+        const int64_t wsb = wan_attention_workspace_bytes(1, Lq, Lk, H, 128);
+        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+        WAN(wan_attention_fwd(dq.p, C, 0, dk.p, C, 0, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, scale, pre ? WAN_ATTN_Q_PRESCALED : 0,
+                              wsb ? ws.p : nullptr, wsb, nullptr));
+        if (wsb) printf("  (tail split active: workspace %lld B)\n", (long long)wsb);
         HIP(hipDeviceSynchronize());
-        std::vector<double> ref; attn_ref(q, k, v, Lq, Lk, H, scale, ref);
-        auto got = bf_to_f(dout.host());
+        // reference on every row for small shapes; on the head, the 4-wave tail region and a stride for large ones
+        std::vector<int> rows;
+        for (int i = 0; i < Lq; ++i) if (Lq <= 1024 || i < 64 || i >= Lq - 600 || i % 211 == 0) rows.push_back(i);
+        std::vector<double> ref; attn_ref(q, k, v, Lq, Lk, H, scale, ref, rows);
+        auto all = bf_to_f(dout.host());
+        std::vector<float> got(rows.size() * C);
+        for (size_t ri = 0; ri < rows.size(); ++ri) memcpy(&got[ri * C], &all[(size_t)rows[ri] * C], C * sizeof(float));
         double maxabs = 0; for (size_t i = 0; i < ref.size(); ++i) maxabs = std::max(maxabs, fabs(got[i] - ref[i]));
         char nm[96]; snprintf(nm, sizeof nm, "Lq=%d Lk=%d H=%d qscale=%.0f", Lq, Lk, H, sh.qs);
         report(nm, rel_l2(ref, got), 6e-3);
@@ -371,7 +381,8 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
     }
     struct A_ { int Lq, Lk, H; const char* what; };
     if (gemm_only) return;
-    std::vector<A_> as = {{8192, 8192, 40, "self L=8k H=40"}, {L, L, big ? 40 : 12, "self full"}, {L, 512, 40, "cross Lk=512"}};
+    std::vector<A_> as = {{8192, 8192, 40, "self L=8k H=40"}, {L, L, big ? 40 : 12, "self full"}, {L, 512, 40, "cross Lk=512"},
+                          {L, L, 5, "self, SP8 shard (5 heads)"}, {L, L, 10, "self, SP4 shard (10 heads)"}, {L, L, 20, "self, SP2 shard"}};
     for (auto s : as) {
         const int C = s.H * 128; const int64_t ldvt = (s.Lk + 63) / 64 * 64;
         auto hq = to_bf(randn((size_t)4096 * 128));
@@ -379,13 +390,17 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(q); fill(k); fill(vt);
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
-        for (const char* var : {"1", "2", "3"}) {
+        for (const char* var : {"2", "3n", "3"}) {       // 3 = pre-scaled q; 3n = the same without the 4-wave tail launch
             if (!attn_only && strcmp(var, "2")) continue;
             setenv("WAN_ATTN_VARIANT", var[0] == '3' ? "2" : var, 1);
-            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0, nullptr)); }, 3, 1);
+            setenv("WAN_ATTN_TAIL", strlen(var) > 1 ? "0" : "1", 1);
+            const int64_t wsb = wan_attention_workspace_bytes(1, s.Lq, s.Lk, s.H, 128);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0,
+                                                            wsb ? ws.p : nullptr, wsb, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
         }
-        unsetenv("WAN_ATTN_VARIANT");
+        unsetenv("WAN_ATTN_VARIANT"); unsetenv("WAN_ATTN_TAIL");
     }
 }
 

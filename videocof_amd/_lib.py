@@ -47,7 +47,8 @@ SIGNATURES = {
                               c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "wan_attention_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
-                                  c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                  c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_attention_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "wan_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "wan_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_void_p]),

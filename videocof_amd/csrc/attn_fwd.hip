@@ -23,6 +23,9 @@
 // on the read):  K tile [64 keys][128 d]: 256-B rows, chunk' = chunk ^ (row & 15)
 //                V^T tile [128 d][64 keys]: 128-B rows, chunk' = chunk ^ ((row >> 1) & 7)
 #include <stdlib.h>
+#include <stdint.h>
+
+#include <algorithm>
 
 #include "common.hpp"
 
@@ -46,6 +49,10 @@ struct AttnArgs {
     bf16_t* o; int64_t ldo, o_bs;
     int Lq, Lk, H;
     float scale_log2e;    // softmax_scale * log2(e)
+    // split-KV tail launch (see the launcher): query blocks start at qblk0; blockIdx.z = batch * nsplit + split
+    int qblk0, nsplit, tiles_per_split, row0, rows_tail;
+    float* ws_o;          // [batch][nsplit][H][rows_tail][128] un-normalised partial outputs
+    float* ws_ml;         // [batch][nsplit][H][rows_tail][2]   running max (log2 units), sum
 };
 
 // VARIANT only names the instantiation so profiles separate the two call sites:
@@ -271,7 +278,7 @@ __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
 // wan_rmsnorm_rope's x0_scale).  The running max then rides in the MFMA accumulator: S' = K.Q^T + (-m)
 // starts from a 16-register splat of -m instead of the inline constant 0, so p = exp2(S') needs no
 // per-score fma: 32 fewer VALU per wave and tile (+6..8 % end to end on this VALU-co-limited loop).
-template <int VARIANT, bool PRE>
+template <int VARIANT, bool PRE, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -279,10 +286,14 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int qblk = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    const int qblk = blockIdx.x + (SPLIT ? a.qblk0 : 0), head = blockIdx.y;
+    const int batch = SPLIT ? blockIdx.z / a.nsplit : blockIdx.z;
+    const int split = SPLIT ? blockIdx.z - batch * a.nsplit : 0;
+    const int t0 = split * a.tiles_per_split;                     // first KV tile of this split
+    const int Lk = SPLIT ? min(a.Lk - t0 * kKV, a.tiles_per_split * kKV) : a.Lk;
     const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
-    const bf16_t* K = a.k + batch * a.k_bs + head * kD;
-    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt;
+    const bf16_t* K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
+    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt + t0 * kKV;
     bf16_t* O = a.o + batch * a.o_bs + head * kD;
 
     const int qrow = qblk * kQPerWG + wid * kQPerWave + l31;
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         const int kv0 = t * kKV;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int kr = min(kv0 + k_row[j], a.Lk - 1);
+            const int kr = min(kv0 + k_row[j], Lk - 1);
             glds16(K + (int64_t)kr * a.ldk + k_col[j], kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
         }
     };
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
     float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
     const float c = a.scale_log2e;
-    const int nkv = (a.Lk + kKV - 1) / kKV;
+    const int nkv = (Lk + kKV - 1) / kKV;
 
     // segment A: finish the row max, decide / apply the rescale; returns m*c (unused with PRE)
     f32x16 negm;
@@ -483,13 +494,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) sl[kt] = last_in_s1 ? s1[kt] : s0[kt];
         const int kv0 = it * kKV;
-        if (kv0 + kKV > a.Lk) {
+        if (kv0 + kKV > Lk) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= a.Lk) sl[kt][r] = -INFINITY;
+                    if (key >= Lk) sl[kt][r] = -INFINITY;
                 }
             mx_part = rowmax32(sl);
         }
@@ -504,18 +515,54 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (qrow < a.Lq) {
-        bf16_t* op = O + (int64_t)qrow * a.ldo + 4 * hi;
+    if constexpr (SPLIT) {
+        // partial result of this KV range: un-normalised O, its reference max (log2 units) and its sum
+        if (qrow < a.Lq) {
+            const int64_t r = ((int64_t)(batch * a.nsplit + split) * a.H + head) * a.rows_tail + (qrow - a.row0);
+            float* wo = a.ws_o + r * kD + 4 * hi;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w = {pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv),
-                           pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv)};
-                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wo + 32 * dt + 8 * g) =
+                        make_float4(o_acc[dt][4 * g + 0], o_acc[dt][4 * g + 1], o_acc[dt][4 * g + 2], o_acc[dt][4 * g + 3]);
+            if (hi == 0) {
+                a.ws_ml[2 * r] = PRE ? m_run : m_run * c;
+                a.ws_ml[2 * r + 1] = l_tot;
             }
+        }
+    } else {
+        const float inv = 1.0f / l_tot;
+        if (qrow < a.Lq) {
+            bf16_t* op = O + (int64_t)qrow * a.ldo + 4 * hi;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w = {pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv),
+                               pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+                }
+        }
     }
+}
+
+// merge the nsplit partial results of the tail rows: out = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
+__global__ __launch_bounds__(kD) void attn_combine_kernel(AttnArgs a) {
+    const int row = blockIdx.x, head = blockIdx.y, batch = blockIdx.z, d = threadIdx.x;
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const int64_t r = ((int64_t)(batch * a.nsplit + s) * a.H + head) * a.rows_tail + row;
+        M = fmaxf(M, a.ws_ml[2 * r]);
+    }
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const int64_t r = ((int64_t)(batch * a.nsplit + s) * a.H + head) * a.rows_tail + row;
+        const float w = __builtin_amdgcn_exp2f(a.ws_ml[2 * r] - M);
+        num += a.ws_o[r * kD + d] * w;
+        den += a.ws_ml[2 * r + 1] * w;
+    }
+    a.o[batch * a.o_bs + (int64_t)(a.row0 + row) * a.ldo + head * kD + d] = (bf16_t)(num / den);
 }
 
 // ------------------------------------------------------------------ [rows, cols] -> [cols, ldt]
@@ -542,12 +589,67 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 
 }  // namespace
 
+namespace {
+
+// Tail balancing.  Every workgroup of a launch costs the same (all stream the whole K/V of their head) and one
+// fits per CU, so W workgroups take ceil(W / CUs) rounds and the last round may be nearly empty: the 5 heads of
+// an 8-way Ulysses shard at L = 67 080 give 1315 = 5 x 256 + 35 workgroups -> 6 rounds for 5.14 rounds of work
+// (measured 1007 vs 1165 TFLOP/s).  When the remainder is small, the last `tq` query blocks of every
+// (batch, head) leave the main launch; a second launch covers them with the SAME 8-wave kernel, each workgroup
+// taking 1/nsplit of the keys (so that the tail fills the chip for 1/nsplit of a round), and a small kernel
+// merges the partial (O, max, sum) triples.  Needs caller-provided workspace; without it the plain launch runs.
+struct TailPlan { int tq = 0, nsplit = 1, tiles_per_split = 0, main_qb = 0, rows_tail = 0; int64_t ws_bytes = 0; };
+
+int cu_count() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        ncu = v;
+    }
+    return ncu;
+}
+
+TailPlan plan_tail(int batch, int Lq, int Lk, int num_heads) {
+    TailPlan p;
+    const int ncu = cu_count();
+    const int nqb = (Lq + kQPerWG - 1) / kQPerWG, nkv = (Lk + kKV - 1) / kKV;
+    p.main_qb = nqb;
+    const int64_t hb = (int64_t)num_heads * batch, items = hb * nqb;
+    const char* et = getenv("WAN_ATTN_TAIL");          // developer A/B switch: 0 disables
+    if ((et && atoi(et) == 0) || Lk <= 1024 || items <= ncu || items % ncu == 0) return p;
+    const int64_t rem = items % ncu;
+    const int cand = (int)((rem + hb - 1) / hb);        // query blocks per (batch, head) moved to the tail launch
+    if (cand >= nqb) return p;
+    const int64_t tail_items = hb * cand, main_items = hb * (nqb - cand);
+    int nsplit = (int)std::min<int64_t>(std::min<int64_t>(ncu / tail_items, nkv / 8), 16);
+    if (nsplit < 2) return p;
+    const int tps = (nkv + nsplit - 1) / nsplit;
+    nsplit = (nkv + tps - 1) / tps;                     // no empty split
+    const double before = (double)((items + ncu - 1) / ncu);
+    const double after = (double)((main_items + ncu - 1) / ncu) + 1.0 / nsplit + 0.05;
+    if (nsplit < 2 || after > before - 0.2) return p;
+    p.tq = cand; p.nsplit = nsplit; p.tiles_per_split = tps; p.main_qb = nqb - cand;
+    p.rows_tail = Lq - p.main_qb * kQPerWG;
+    p.ws_bytes = (int64_t)batch * nsplit * num_heads * p.rows_tail * (kD + 2) * (int64_t)sizeof(float);
+    return p;
+}
+
+}  // namespace
+
+extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim) {
+    if (batch <= 0 || Lq <= 0 || Lk <= 0 || num_heads <= 0 || head_dim != kD) return 0;
+    return plan_tail(batch, Lq, Lk, num_heads).ws_bytes;
+}
+
 extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                           const void* k, int64_t ldk, int64_t k_bstride,
                                           const void* vt, int64_t ldvt, int64_t vt_bstride,
                                           void* out, int64_t ldo, int64_t o_bstride,
                                           int batch, int Lq, int Lk, int num_heads, int head_dim,
-                                          float softmax_scale, int flags, void* stream) {
+                                          float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
     WAN_REQUIRE(q && k && vt && out, WAN_ERR_INVALID, "wan_attention_fwd: null tensor");
     WAN_REQUIRE((flags & ~WAN_ATTN_Q_PRESCALED) == 0, WAN_ERR_INVALID, "wan_attention_fwd: unknown flags 0x%x", flags);
     WAN_REQUIRE(head_dim == kD, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: head_dim=%d (only 128 is built)", head_dim);
@@ -565,10 +667,11 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (Lq == 0) return WAN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[6] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
-                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
-                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>)};
-        for (int i = 0; i < 6; ++i) {
+        const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>)};
+        for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? kLdsBytes : kLdsBytesV2);
             if (e != hipSuccess) {
                 wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
@@ -585,6 +688,7 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
     const bool pre = (flags & WAN_ATTN_Q_PRESCALED) != 0;
     a.scale_log2e = pre ? 1.0f : softmax_scale * 1.4426950408889634f;
+    a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     // developer A/B switch (not a product option): WAN_ATTN_VARIANT = 1 plain, 2 software-pipelined (default)
@@ -595,12 +699,31 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         if (self) hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, st, a);
         else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, st, a);
     } else {
+        TailPlan tp;
+        if (workspace != nullptr) {
+            tp = plan_tail(batch, Lq, Lk, num_heads);
+            if (tp.tq > 0 && (workspace_bytes < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();
+            WAN_REQUIRE(tp.tq == 0 || ((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
+        }
+        if (tp.tq > 0) grid.x = (unsigned)tp.main_qb;
         if (pre) {
             if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
             else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
         } else {
             if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
             else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
+        }
+        if (tp.tq > 0) {
+            WAN_CHECK_LAUNCH("wan_attention_fwd");
+            a.qblk0 = tp.main_qb; a.nsplit = tp.nsplit; a.tiles_per_split = tp.tiles_per_split;
+            a.row0 = tp.main_qb * kQPerWG; a.rows_tail = tp.rows_tail;
+            a.ws_o = (float*)workspace;
+            a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
+            dim3 tgrid((unsigned)tp.tq, (unsigned)num_heads, (unsigned)(batch * tp.nsplit));
+            if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
+            else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
+            WAN_CHECK_LAUNCH("wan_attention_fwd (tail)");
+            hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)tp.rows_tail, (unsigned)num_heads, (unsigned)batch), dim3(kD), 0, st, a);
         }
     }
     WAN_CHECK_LAUNCH("wan_attention_fwd");

@@ -150,6 +150,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     return out
 
 
+_ATTN_WS = {}
+
+
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads: int, k_len: Optional[int] = None,
                   softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
                   q_prescaled: bool = False) -> torch.Tensor:
@@ -172,10 +175,16 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
         raise ValueError("attention: q/k/vt shapes disagree")
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(head_dim)
     lib = _lib.load()
+    ws, ws_bytes = None, int(lib.wan_attention_workspace_bytes(B, Lq, Lk, num_heads, head_dim))
+    if ws_bytes > 0:        # scratch for the split tail round; one growing buffer per device, reused stream-ordered
+        ws = _ATTN_WS.get(q.device)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = _ATTN_WS[q.device] = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8)
     _lib.check(lib.wan_attention_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
                                      _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
                                      B, Lq, Lk, num_heads, head_dim, float(scale),
-                                     _lib.ATTN_Q_PRESCALED if q_prescaled else 0, _stream()), "wan_attention_fwd")
+                                     _lib.ATTN_Q_PRESCALED if q_prescaled else 0, _p(ws), ws_bytes if ws is not None else 0,
+                                     _stream()), "wan_attention_fwd")
     return out
 
 
