@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q_out):
+def _worker(rank, world, port, q_out, heads):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LOCAL_RANK"] = "0"
@@ -29,10 +29,9 @@ def _worker(rank, world, port, q_out):
         from videocof_amd import WanTransformer3DModel
         from videocof_amd import dist as vdist
         from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
-        heads = 4
-        cfgd = dict(dim=512, ffn_dim=1024, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+        cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
         sd = deterministic_dit_state_dict(**cfgd)
-        m = WanTransformer3DModel(dim=512, ffn_dim=1024, num_heads=heads, num_layers=2, text_dim=64)
+        m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=2, text_dim=64)
         m.load_state_dict(sd, device="cuda:0")
         lat = det_uniform("sp.lat", (2, 16, 7, 12, 20), 1.0).cuda()
         ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda(), det_uniform("sp.c1", (5, 64), 1.0).cuda()]
@@ -42,7 +41,7 @@ def _worker(rank, world, port, q_out):
         vdist.init_sequence_parallel()
         m.enable_multi_gpus_inference()
         assert m.sp_world_size == world and m.sp_world_rank == rank
-        sharded = m(lat, t, ctx, 420, **kw)              # 420 tokens -> padded to 432 = 2 x 216
+        sharded = m(lat, t, ctx, 420, **kw)              # 420 tokens -> padded to a multiple of 8 * world
         torch.cuda.synchronize()
         rel = float((sharded - single).norm() / single.norm())
         q_out.put((rank, rel, float(single.abs().mean())))
@@ -50,12 +49,12 @@ def _worker(rank, world, port, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sp_forward_equals_single_device(world):
+@pytest.mark.parametrize("world,heads", [(2, 4), (4, 4), (8, 8)])
+def test_sp_forward_equals_single_device(world, heads):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, heads)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
