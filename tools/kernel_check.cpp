@@ -268,9 +268,8 @@ static void attn_ref(const std::vector<float>& q, const std::vector<float>& k, c
 }
 
 static void check_attn() {
-  for (const char* var : {"1", "2", "3"}) {      // 3 = variant 2 with WAN_ATTN_Q_PRESCALED
+  for (const char* var : {"2", "3"}) {      // 2 = plain q, 3 = WAN_ATTN_Q_PRESCALED
     const bool pre = var[0] == '3';
-    setenv("WAN_ATTN_VARIANT", pre ? "2" : var, 1);
     printf("wan_attention_fwd variant %s (+ wan_transpose_bf16)\n", var);
     struct Shape { int Lq, Lk, H; float qs; };
     for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}, Shape{86 * 256 + 10, 1100, 3, 1.f}}) {
@@ -308,7 +307,6 @@ static void check_attn() {
         report("   max abs err", maxabs, 3e-2, "max_abs");
     }
   }
-  unsetenv("WAN_ATTN_VARIANT");
 }
 
 static void check_layout() {
@@ -392,7 +390,6 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
         for (const char* var : {"2", "3n", "3"}) {       // 3 = pre-scaled q; 3n = the same without the 4-wave tail launch
             if (!attn_only && strcmp(var, "2")) continue;
-            setenv("WAN_ATTN_VARIANT", var[0] == '3' ? "2" : var, 1);
             setenv("WAN_ATTN_TAIL", strlen(var) > 1 ? "0" : "1", 1);
             const int64_t wsb = wan_attention_workspace_bytes(1, s.Lq, s.Lk, s.H, 128);
             Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
@@ -400,7 +397,7 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
                                                             wsb ? ws.p : nullptr, wsb, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
         }
-        unsetenv("WAN_ATTN_VARIANT"); unsetenv("WAN_ATTN_TAIL");
+        unsetenv("WAN_ATTN_TAIL");
     }
 }
 

@@ -39,8 +39,6 @@ constexpr int kKV = 64;          // keys per tile
 constexpr int kThreads = kWavesPerWG * 64;
 constexpr int kKTileBytes = kKV * kD * 2;    // 16 KiB
 constexpr int kVTileBytes = kD * kKV * 2;    // 16 KiB
-constexpr int kStageBytes = kKTileBytes + kVTileBytes;
-constexpr int kLdsBytes = 2 * kStageBytes;   // 64 KiB
 
 struct AttnArgs {
     const bf16_t* q; int64_t ldq, q_bs;
@@ -55,177 +53,14 @@ struct AttnArgs {
     float* ws_ml;         // [batch][nsplit][H][rows_tail][2]   running max (log2 units), sum
 };
 
-// VARIANT only names the instantiation so profiles separate the two call sites:
-//   0 = attn_self  (long KV stream: self-attention, Lk ~ 1e4..1e5)
-//   1 = attn_cross (short KV: the 512 text tokens of WanT2VCrossAttention)
-template <int VARIANT>
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5;
-    const int l31 = lane & 31;
-
-    const int qblk = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
-    const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
-    const bf16_t* K = a.k + batch * a.k_bs + head * kD;
-    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt;
-    bf16_t* O = a.o + batch * a.o_bs + head * kD;
-
-    // ---- Q fragments: B operand of S^T = K.Q^T; lane holds Q[q][16*ks + 8*hi .. +7]
-    const int qrow = qblk * kQPerWG + wid * kQPerWave + l31;
-    const int qrow_c = min(qrow, a.Lq - 1);
-    bf16x8 qf[8];
-    {
-        const bf16_t* qp = Q + (int64_t)qrow_c * a.ldq + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-    }
-
-    // ---- LDS-DMA source addresses. Wave w copies K pieces 2w, 2w+1 (4 rows x 256 B each) and
-    //      V^T pieces 2w, 2w+1 (8 rows x 128 B each).
-    int k_row[2], k_col[2];
-    const bf16_t* v_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wid * 2 + j;
-        const int kr = p * 4 + (lane >> 4);                  // key row inside the tile
-        k_row[j] = kr;
-        k_col[j] = ((lane & 15) ^ (kr & 15)) * 8;            // logical chunk -> element offset
-        const int vr = p * 8 + (lane >> 3);                  // d row inside the tile
-        const int vc = (lane & 7) ^ ((vr >> 1) & 7);
-        v_src[j] = VT + (int64_t)vr * a.ldvt + vc * 8;
-    }
-    auto stage = [&](int buf, int kv0) {
-        char* base = smem + buf * kStageBytes;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kr = min(kv0 + k_row[j], a.Lk - 1);    // clamp: masked later
-            glds16(K + (int64_t)kr * a.ldk + k_col[j], base + (wid * 2 + j) * 1024);
-            glds16(v_src[j] + kv0, base + kKTileBytes + (wid * 2 + j) * 1024);
-        }
-    };
-
-    // ---- LDS read offsets
-    // K: row = 32*kt + pi(l31), logical chunk = 2*ks + hi
-    const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    const int k_rowoff = pi * 256;
-    const int k_sw = pi & 15;
-    // V^T: row = 32*dt + l31, logical chunk = 2*t + hi
-    const int v_rowoff = l31 * 128;
-    const int v_sw = (l31 >> 1) & 7;
-    int v_off[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v_off[t] = kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
-
-    f32x16 o_acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-    float m_run = -INFINITY;   // running max of raw scores
-    float l_run = 0.f;         // running sum of this lane's 32-key share
-
-    const int nkv = (a.Lk + kKV - 1) / kKV;
-    stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-
-    for (int it = 0; it < nkv; ++it) {
-        const int cur = it & 1;
-        const int kv0 = it * kKV;
-        if (it + 1 < nkv) stage(cur ^ 1, kv0 + kKV);
-        const char* sb = smem + cur * kStageBytes;
-
-        // ---- S^T = K . Q^T
-        f32x16 s[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(
-                    sb + kt * 32 * 256 + k_rowoff + (((2 * ks + hi) ^ k_sw) << 4));
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-            }
-        }
-        // register r of tile kt <-> key kv0 + 32*kt + 16*(r>>3) + 8*hi + (r&7)
-        if (kv0 + kKV > a.Lk) {      // ragged last tile (wave-uniform branch)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= a.Lk) s[kt][r] = -INFINITY;
-                }
-        }
-
-        // ---- online softmax (base-2)
-        float mx = s[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2e);
-        m_run = m_new;
-        const float mc = m_new * a.scale_log2e;
-        float psum = 0.f;
-        bf16x8 pf[4];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                float p[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][8 * t2 + j], a.scale_log2e, -mc));
-                    psum += p[j];
-                }
-                u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
-                           pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
-                pf[2 * kt + t2] = __builtin_bit_cast(bf16x8, w);
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + dt * 32 * 128 + v_off[t]);
-                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t], o_acc[dt], 0, 0, 0);
-            }
-
-        __builtin_amdgcn_s_waitcnt(0);   // next tile landed + our LDS reads retired
-        __syncthreads();
-    }
-
-    // ---- normalise and store: lane (q, hi) holds d = 32*dt + 8*g + 4*hi + (r&3), g = r>>2
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (qrow < a.Lq) {
-        bf16_t* op = O + (int64_t)qrow * a.ldo + 4 * hi;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w = {pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv),
-                           pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv)};
-                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
-            }
-    }
-}
+// VARIANT (template parameter of the kernel below) only names the instantiation so profiles separate the two
+// call sites:  0 = attn_self (long KV stream: self-attention, Lk ~ 1e4..1e5),
+//              1 = attn_cross (short KV: the 512 text tokens of WanT2VCrossAttention).
+// The first version of this kernel (one tile at a time: S, softmax, P.V, barrier; 1.00-1.07 PFLOP/s) was kept
+// as an in-process A/B partner through round 1 (profiles/r01/attn_variants_ab.log) and has been removed.
 
 // ====================================================================================================
-// v2: software-pipelined variant.  Per KV tile j a wave runs three straight-line segments:
+// The software pipeline.  Per KV tile j a wave runs three straight-line segments:
 //   A  finish the row max of S(j) (its per-lane partial max was computed as filler of the previous
 //      tile), one lane^32 exchange, and the rare rescale of O (deferred: while the running max grows
 //      by less than 2^kDeferLog2 the old max is kept and O / l are not touched -- guide T13);
@@ -255,7 +90,6 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 // interval tracks (MFMA cycles + VALU cycles) of the two waves of a SIMD, not their maximum.
 // ====================================================================================================
 constexpr float kDeferLog2 = 6.0f;
-constexpr int kDefaultAttnVariant = 2;
 constexpr int kVRing = 2;
 constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 64 KiB
 
@@ -667,12 +501,11 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (Lq == 0) return WAN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
+        const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? kLdsBytes : kLdsBytesV2);
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
             if (e != hipSuccess) {
                 wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
                 return WAN_ERR_LAUNCH;
@@ -691,40 +524,32 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
-    // developer A/B switch (not a product option): WAN_ATTN_VARIANT = 1 plain, 2 software-pipelined (default)
-    const char* ev = getenv("WAN_ATTN_VARIANT");
-    const int variant = ev ? atoi(ev) : kDefaultAttnVariant;
     const bool self = Lk > 1024;
-    if (variant == 1) {
-        if (self) hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, kLdsBytes, st, a);
-        else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, kLdsBytes, st, a);
+    TailPlan tp;
+    if (workspace != nullptr) {
+        tp = plan_tail(batch, Lq, Lk, num_heads);
+        if (tp.tq > 0 && (workspace_bytes < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();
+        WAN_REQUIRE(tp.tq == 0 || ((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
+    }
+    if (tp.tq > 0) grid.x = (unsigned)tp.main_qb;
+    if (pre) {
+        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
     } else {
-        TailPlan tp;
-        if (workspace != nullptr) {
-            tp = plan_tail(batch, Lq, Lk, num_heads);
-            if (tp.tq > 0 && (workspace_bytes < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();
-            WAN_REQUIRE(tp.tq == 0 || ((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
-        }
-        if (tp.tq > 0) grid.x = (unsigned)tp.main_qb;
-        if (pre) {
-            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
-            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
-        } else {
-            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
-            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
-        }
-        if (tp.tq > 0) {
-            WAN_CHECK_LAUNCH("wan_attention_fwd");
-            a.qblk0 = tp.main_qb; a.nsplit = tp.nsplit; a.tiles_per_split = tp.tiles_per_split;
-            a.row0 = tp.main_qb * kQPerWG; a.rows_tail = tp.rows_tail;
-            a.ws_o = (float*)workspace;
-            a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
-            dim3 tgrid((unsigned)tp.tq, (unsigned)num_heads, (unsigned)(batch * tp.nsplit));
-            if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
-            else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
-            WAN_CHECK_LAUNCH("wan_attention_fwd (tail)");
-            hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)tp.rows_tail, (unsigned)num_heads, (unsigned)batch), dim3(kD), 0, st, a);
-        }
+        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
+    }
+    if (tp.tq > 0) {
+        WAN_CHECK_LAUNCH("wan_attention_fwd");
+        a.qblk0 = tp.main_qb; a.nsplit = tp.nsplit; a.tiles_per_split = tp.tiles_per_split;
+        a.row0 = tp.main_qb * kQPerWG; a.rows_tail = tp.rows_tail;
+        a.ws_o = (float*)workspace;
+        a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
+        dim3 tgrid((unsigned)tp.tq, (unsigned)num_heads, (unsigned)(batch * tp.nsplit));
+        if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
+        WAN_CHECK_LAUNCH("wan_attention_fwd (tail)");
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)tp.rows_tail, (unsigned)num_heads, (unsigned)batch), dim3(kD), 0, st, a);
     }
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;
