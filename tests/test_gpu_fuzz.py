@@ -113,3 +113,43 @@ def test_beyond_2gib_indexing():
     o = ops.gemm(a, wt, None, ops.EPI_BF16)
     assert o.numel() * 2 > 2 ** 31
     assert rel_l2(o[rows].float(), a[rows].float() @ wt.float().t()) < 4e-3
+
+
+def test_attention_split_tail_random_shapes():
+    """Shapes whose workgroup count leaves a remainder over the CU count: whatever the launcher decides (plain
+    launch or main launch + split tail + merge), the result equals an fp32 evaluation on sampled query rows and
+    agrees with the plain launch (WAN_ATTN_TAIL=0) to bf16 noise."""
+    import os
+    from videocof_amd import _lib
+    rnd = random.Random(5)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    split_seen = 0
+    for _ in range(10):
+        B = rnd.choice([1, 1, 2])
+        H = rnd.choice([2, 3, 5, 7])
+        nqb = rnd.randint(256 // (B * H) + 1, 3 * 256 // (B * H) + 2)
+        Lq = nqb * 256 - rnd.randint(0, 255)
+        Lk = rnd.choice([1025, 1100, 1664, 2500, 4096])
+        pre = rnd.random() < 0.5
+        C = H * 128
+        split_seen += int(_lib.load().wan_attention_workspace_bytes(B, Lq, Lk, H, 128) > 0)
+        q = torch.randn(B, Lq, C, device=DEV, generator=g).bfloat16()
+        k = torch.randn(B, Lk, C, device=DEV, generator=g).bfloat16()
+        v = torch.randn(B, Lk, C, device=DEV, generator=g).bfloat16()
+        vt = torch.stack([ops.transpose_pad(v[b]) for b in range(B)])
+        qq = (q.float() * ops.q_prescale(128)).bfloat16() if pre else q
+        out = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
+        os.environ["WAN_ATTN_TAIL"] = "0"
+        try:
+            plain = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
+        finally:
+            del os.environ["WAN_ATTN_TAIL"]
+        assert rel_l2(out.float(), plain.float()) < 3e-3, (B, H, Lq, Lk, pre)
+        rows = torch.cat([torch.arange(0, 16), torch.arange(Lq - 700, Lq, 7)]).to(DEV)
+        qe = (qq[:, rows].float() / ops.q_prescale(128)) if pre else q[:, rows].float()
+        qf = qe.view(B, -1, H, 128).transpose(1, 2)
+        kf = k.float().view(B, Lk, H, 128).transpose(1, 2)
+        vf = v.float().view(B, Lk, H, 128).transpose(1, 2)
+        ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(128), dim=-1) @ vf).transpose(1, 2).reshape(B, -1, C)
+        assert rel_l2(out[:, rows].float(), ref) < 6e-3, (B, H, Lq, Lk, pre)
+    assert split_seen >= 3, split_seen
