@@ -412,6 +412,19 @@ int main(int argc, char** argv) {
     }
     if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
     if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
+    if (mode == "attnprof") {     // one shape, final kernel only: the target of the rocprofv3 --pmc passes (tools/profile_attn.sh)
+        const int L = 67080, H = 40, C = H * 128; const int64_t ldvt = (L + 63) / 64 * 64;
+        auto hq = to_bf(randn((size_t)4096 * 128));
+        Dev<bf16> q((size_t)L * C), k((size_t)L * C), vt((size_t)C * ldvt), o((size_t)L * C);
+        auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
+        fill(q); fill(k); fill(vt);
+        const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
+        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+        for (int i = 0; i < 3; ++i)
+            WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr));
+        HIP(hipDeviceSynchronize());
+        printf("attnprof done\n");
+    }
     if (mode == "perf" || mode == "all") perf(big);
     return g_fail ? 1 : 0;
 }

@@ -30,14 +30,17 @@ def main():
         acc = defaultdict(lambda: [0, 0.0, 0.0, 0])
         for f in files:
             for row in csv.DictReader(open(f)):
-                k = short(row["Kernel_Name"])
+                k = (short(row["Kernel_Name"]), row.get("Counter_Name", pname))
                 a = acc[k]
                 a[0] += 1
                 a[1] += float(row["Counter_Value"])
                 a[2] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
                 a[3] = int(row["Grid_Size"])
-        for k, (n, v, ms, grid) in acc.items():
-            res[k][pname] = {"launches_counted": n, "avg_counter": v / n, "avg_ms": ms / n, "grid": grid}
+        names = {c for (_, c) in acc}
+        for (k, c), (n, v, ms, grid) in acc.items():
+            # one counter per pass keeps the pass name (fetch / write); several counters are keyed by their own names
+            key = pname if len(names) == 1 else c
+            res[k][key] = {"launches_counted": n, "avg_counter": v / n, "avg_ms": ms / n, "grid": grid}
     keep = {k: v for k, v in res.items() if any(p["avg_ms"] > 0.05 for p in v.values())}
     json.dump(keep, open(out, "w"), indent=1)
     for k, v in sorted(keep.items(), key=lambda kv: -max(p["avg_ms"] * p["launches_counted"] for p in kv[1].values()))[:12]:
