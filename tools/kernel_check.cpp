@@ -388,9 +388,9 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(q); fill(k); fill(vt);
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
-        for (const char* var : {"2", "3n", "3"}) {       // 3 = pre-scaled q; 3n = the same without the 4-wave tail launch
-            if (!attn_only && strcmp(var, "2")) continue;
-            setenv("WAN_ATTN_TAIL", strlen(var) > 1 ? "0" : "1", 1);
+        for (const char* var : {"2", "3n", "3"}) {       // 2 = plain q; 3 = pre-scaled q; 3n = the same without the split tail
+            if (!attn_only && strcmp(var, "3")) continue;
+            setenv("WAN_ATTN_TAIL", !strcmp(var, "3n") ? "0" : "1", 1);
             const int64_t wsb = wan_attention_workspace_bytes(1, s.Lq, s.Lk, s.H, 128);
             Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
             double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0,

@@ -88,6 +88,8 @@ struct AttnArgs {
 // order thoroughly and the time not at all (78.07 vs 78.15 ms).  What does move the loop is REMOVING VALU work:
 // the PRE form below (-32 v_fma per wave and tile) gained 7-8 %, the 15 x v_max3 row max ~1 %.  Time per
 // interval tracks (MFMA cycles + VALU cycles) of the two waves of a SIMD, not their maximum.
+// (h) the first MFMA of each S chain as inline asm with D != C, so that the 16-register splat of -m is not copied
+// into the accumulator every tile (16 v_mov_b64 per tile): removes the copies, runs 2.7 % SLOWER (79.0 vs 76.9 ms).
 // ====================================================================================================
 constexpr float kDeferLog2 = 6.0f;
 constexpr int kVRing = 2;
@@ -142,7 +144,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 
     char* const kring = smem;                       // K tile t -> slot t & 1
     char* const vring = smem + 2 * kKTileBytes;     // V^T tile t -> slot t % 3
+    // Per-lane source addresses are "tile-0 address + a wave-uniform tile offset", so staging a tile costs one
+    // 64-bit add per piece; only the last tile, whose rows may run past Lk, is clamped per lane.
     int k_row[2], k_col[2];
+    const bf16_t* k_src[2];
     const bf16_t* v_src[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -150,16 +155,24 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         const int kr = p * 4 + (lane >> 4);
         k_row[j] = kr;
         k_col[j] = ((lane & 15) ^ (kr & 15)) * 8;
+        k_src[j] = K + (int64_t)kr * a.ldk + k_col[j];
         const int vr = p * 8 + (lane >> 3);
         const int vc = (lane & 7) ^ ((vr >> 1) & 7);
         v_src[j] = VT + (int64_t)vr * a.ldvt + vc * 8;
     }
+    const int nkv_ = (Lk + kKV - 1) / kKV;
     auto stage_k = [&](int t) {
         const int kv0 = t * kKV;
+        if (t == nkv_ - 1) {            // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kr = min(kv0 + k_row[j], Lk - 1);
-            glds16(K + (int64_t)kr * a.ldk + k_col[j], kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
+            for (int j = 0; j < 2; ++j) {
+                const int kr = min(kv0 + k_row[j], Lk - 1);
+                glds16(K + (int64_t)kr * a.ldk + k_col[j], kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
+            }
+        } else {
+            const int64_t off = (int64_t)kv0 * a.ldk;       // scalar
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(k_src[j] + off, kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
         }
     };
     auto stage_v = [&](int t) {
@@ -258,8 +271,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         const char* kb = kring + ((t + 1) & 1) * kKTileBytes;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            if constexpr (PRE) sn[kt] = negm;
-            else {
+            if constexpr (!PRE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
             }
@@ -270,7 +282,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * 256 + k_off[ks]);
-                sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
+                if (PRE && ks == 0) {
+                    sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, negm, 0, 0, 0);
+                } else {
+                    sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
+                }
             }
             if (ks == 3) pf[0] = p_group(sc[0], 0, mc, psum);
             if (ks == 7) pf[1] = p_group(sc[0], 1, mc, psum);
