@@ -100,6 +100,16 @@ constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 64 KiB
 // No inline asm here: an asm v_max3 reading MFMA results is invisible to the hazard recogniser (measured:
 // missing wait states, run-to-run different maxima).
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// max(x, x of lane ^ 32) with one v_permlane32_swap (gfx950) instead of a ds_bpermute round trip through the LDS
+// pipe at the head of every tile.  Inline asm because hipcc folds __builtin_amdgcn_permlane32_swap(x, x) to x;
+// both operands come from plain VALU results (the v_max3 chain), the leading s_nop covers the VALU-write ->
+// permlane-read wait states the compiler inserts for its own uses of the instruction.
+__device__ __forceinline__ float max_with_lane_xor32(float x) {
+    float y = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return fmaxf(x, y);
+}
 __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
     float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[1][0], s[1][1], s[1][2]);
 #pragma unroll
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
     bool first = true;
     auto seg_a = [&](float mx_part, f32x16 (&sc)[2]) -> float {
-        const float mx = fmaxf(mx_part, __shfl_xor(mx_part, 32, 64));
+        const float mx = max_with_lane_xor32(mx_part);
         if constexpr (PRE) {
             // scores are already relative to m_run and in log2 units
             if (first || !__all(mx <= kDeferLog2)) {           // wave-uniform; rare after the first tiles
