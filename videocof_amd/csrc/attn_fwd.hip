@@ -90,6 +90,7 @@ struct AttnArgs {
 // interval tracks (MFMA cycles + VALU cycles) of the two waves of a SIMD, not their maximum.
 // (h) the first MFMA of each S chain as inline asm with D != C, so that the 16-register splat of -m is not copied
 // into the accumulator every tile (16 v_mov_b64 per tile): removes the copies, runs 2.7 % SLOWER (79.0 vs 76.9 ms).
+// (i) the row sum kept as a packed pair and accumulated with v_pk_add_f32: within noise (74.4 / 76.2 vs 75.3 ms).
 // ====================================================================================================
 constexpr float kDeferLog2 = 6.0f;
 constexpr int kVRing = 2;
@@ -264,8 +265,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     };
     // segment C: O^T += V^T(t).P^T(t).  With BALANCED the exp2/convert work of the second key-tile
     // (groups 2,3) runs here as filler of the first two k-steps instead of all of it in segment B.
-    auto pv = [&](int t, bf16x8 (&pf)[4], const f32x16* sc_late, float mc, float* psum_late) {
-        const char* vb = vring + (t % kVRing) * kVTileBytes;
+    // Ring slots are passed as literals from the 2x-unrolled loop (tile parity is known there), so every ds_read
+    // address is a loop-invariant VGPR + immediate offset.
+    auto pv = [&](int vslot, bf16x8 (&pf)[4], const f32x16* sc_late, float mc, float* psum_late) {
+        const char* vb = vring + vslot * kVTileBytes;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         }
     };
     // segment B: S(t+1) -> sn from K(t+1); P(t) groups 0,1 (key-tile 0) -> pf; groups 2,3 follow in segment C
-    auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t, float mc, bf16x8 (&pf)[4], float& psum) {
-        const char* kb = kring + ((t + 1) & 1) * kKTileBytes;
+    auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int kslot_next, float mc, bf16x8 (&pf)[4], float& psum) {
+        const char* kb = kring + kslot_next * kKTileBytes;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if constexpr (!PRE) {
@@ -333,17 +336,17 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     bf16x8 pf[4];
     int it = 0;
     bool last_in_s1 = false;
-    for (; it + 2 <= nfull; it += 2) {
+    for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
         prefetch(it);
-        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
+        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, 1, mc, pf, ps); pv(0, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
         fence();
         prefetch(it + 1);
-        { const float mc = seg_a(mx_part, s1); float ps = 0.f; seg_b(s1, s0, it + 1, mc, pf, ps); pv(it + 1, pf, &s1[1], mc, &ps); l_run += ps; mx_part = rowmax32(s0); }
+        { const float mc = seg_a(mx_part, s1); float ps = 0.f; seg_b(s1, s0, 0, mc, pf, ps); pv(1, pf, &s1[1], mc, &ps); l_run += ps; mx_part = rowmax32(s0); }
         fence();
     }
     if (it < nfull) {
         prefetch(it);
-        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, it, mc, pf, ps); pv(it, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
+        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, 1, mc, pf, ps); pv(0, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
         fence();
         ++it;
         last_in_s1 = true;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) pf[2 * kt + t2] = p_group(sl[kt], t2, mc, psum);
         l_run += psum;
-        pv(it, pf, nullptr, 0.f, nullptr);
+        pv(it & 1, pf, nullptr, 0.f, nullptr);
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
