@@ -19,7 +19,7 @@ All tensors are [C, T, H, W] (batch 1).
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Sequence
 
 import torch
 import torch.nn.functional as F

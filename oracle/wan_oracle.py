@@ -17,7 +17,7 @@ State-dict key names are the reference's ``nn.Module`` parameter names.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np

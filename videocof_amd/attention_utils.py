@@ -10,7 +10,6 @@ options the kernel does not implement raise, as flash-attn itself would.
 from __future__ import annotations
 
 import warnings
-from typing import Optional
 
 import torch
 

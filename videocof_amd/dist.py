@@ -30,7 +30,7 @@ identically on gloo/CPU (tests) and RCCL/GPU.
 from __future__ import annotations
 
 import os
-from typing import List, Optional
+from typing import Optional
 
 import torch
 import torch.distributed as dist

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 from types import SimpleNamespace
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
