@@ -20,6 +20,10 @@
 // XOR swizzle as the 128^2 kernel.  K tile t+1 streams into the other buffer during phases 2
 // and 3 of tile t (regions whose last reader finished two barriers earlier) and is waited for before
 // the barrier that closes tile t for BOTH groups (the late group waits one segment earlier).
+//
+// Measured and not kept: de-synchronising the CUs with a per-workgroup start delay in the first round (so that the
+// HBM-bound fp32 read-modify-write epilogues of different CUs do not coincide): 1282 vs 1285-1304 TFLOP/s on the
+// o-projection, 1165 vs 1165-1170 on ffn.2 -- noise; the CUs drift apart on their own.
 #include <stdlib.h>
 
 #include "common.hpp"
