@@ -10,7 +10,7 @@
 //
 // With the swapped product every lane owns ONE query column of S^T and of O^T, so the running
 // max / sum and the rescale of O are lane-local; the only cross-lane traffic per tile is one
-// exchange of the row max between lanes l and l^32.
+// exchange of the row max between lanes l and l^32 (one v_permlane32_swap, no LDS round trip).
 //
 // Key order: the MFMA leaves score row i = (r&3) + 8*(r>>2) + 4*hi in register r.  K rows are
 // fetched from LDS through the permutation pi (swap bits 2 and 3 of the row index), which makes
