@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/wan_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -15,3 +17,16 @@ void wan_set_error(const char* fmt, ...) {
 
 extern "C" const char* wan_last_error(void) { return g_err; }
 extern "C" int wan_abi_version(void) { return WAN_ABI_VERSION; }
+
+// Launch planning (tile quantisation) wants the CU count; it is host arithmetic and must also work where no GPU is
+// visible (the CPU-side ABI tests), hence the fallback.
+int wan_cu_count() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        ncu = v;
+    }
+    return ncu;
+}

@@ -463,20 +463,9 @@ namespace {
 // merges the partial (O, max, sum) triples.  Needs caller-provided workspace; without it the plain launch runs.
 struct TailPlan { int tq = 0, nsplit = 1, tiles_per_split = 0, main_qb = 0, rows_tail = 0; int64_t ws_bytes = 0; };
 
-int cu_count() {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        ncu = v;
-    }
-    return ncu;
-}
-
 TailPlan plan_tail(int batch, int Lq, int Lk, int num_heads) {
     TailPlan p;
-    const int ncu = cu_count();
+    const int ncu = wan_cu_count();
     const int nqb = (Lq + kQPerWG - 1) / kQPerWG, nkv = (Lk + kKV - 1) / kKV;
     p.main_qb = nqb;
     const int64_t hb = (int64_t)num_heads * batch, items = hb * nqb;

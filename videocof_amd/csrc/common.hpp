@@ -21,6 +21,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // host-side error plumbing -----------------------------------------------------
 void wan_set_error(const char* fmt, ...);
+int wan_cu_count();      // compute units of the current device (256 on MI355X), cached; 256 if it cannot be queried
 #define WAN_REQUIRE(cond, code, ...)            \
     do {                                        \
         if (!(cond)) {                          \

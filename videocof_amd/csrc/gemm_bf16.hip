@@ -253,10 +253,13 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
     WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
                 "wan_gemm_bf16: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
     if (M == 0) return WAN_OK;
-    {   // large shapes -> 256^2 phased kernel.  WAN_GEMM_VARIANT=1|2 is a developer A/B switch, not a product option.
+    {   // Large shapes -> 256^2 phased kernel (one workgroup per CU), unless its tiles would leave more than half of
+        // the CUs idle (M ~ 1e3: the text encoder, the VAE's attention block): four times as many 128^2 tiles at two
+        // per CU fill the chip better.  WAN_GEMM_VARIANT=1|2 is a developer A/B switch, not a product option.
         const char* ev = getenv("WAN_GEMM_VARIANT");
         const int variant = ev ? atoi(ev) : 0;
-        const bool big = M >= 1024 && N >= 256;
+        const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+        const bool big = M >= 1024 && N >= 256 && 2 * tiles256 > wan_cu_count();
         if (variant == 2 || (variant == 0 && big))
             return wan_gemm_bf16_256(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch,
                                      (hipStream_t)stream);
