@@ -223,32 +223,54 @@ wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ per-pixel RMS_norm (+SiLU)
-// F.normalize(x, dim=channel) * sqrt(C) * gamma  (wan_vae.py:43-58), optional SiLU; one wave per pixel.
+// F.normalize(x, dim=channel) * sqrt(C) * gamma  (wan_vae.py:43-58), optional SiLU.  A pixel's C channels are
+// C/8 16-byte chunks; LPP = 8/16/32/64 lanes share a pixel (the next power of two >= C/8), so a wave normalises
+// 64/LPP pixels at once (C = 96 at full resolution: 4 pixels per wave, 12 of every 16 lanes active instead of 12
+// of 64) and each wave walks PIX_ITERS pixel groups to keep more bytes in flight.
+template <int LPP>
 __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                               bf16_t* __restrict__ out, int64_t rows, int C, int silu) {
+    constexpr int PPW = 64 / LPP;            // pixels per wave and step
+    constexpr int PIX_ITERS = 4;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int sub = lane & (LPP - 1);        // chunk index inside the pixel
+    const int pw = lane / LPP;               // pixel slot inside the wave
     const int nchunk = C >> 3;
-    const bool act = lane < nchunk;
-    u32x4 v = {0, 0, 0, 0};
-    if (act) v = reinterpret_cast<const u32x4*>(x + row * C)[lane];
-    float ss = 0.f;
+    const bool act_c = sub < nchunk;
+    float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (act_c) {
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[sub * 2], gb = reinterpret_cast<const float4*>(gamma)[sub * 2 + 1];
+        gv[0] = ga.x; gv[1] = ga.y; gv[2] = ga.z; gv[3] = ga.w; gv[4] = gb.x; gv[5] = gb.y; gv[6] = gb.z; gv[7] = gb.w;
+    }
+    const float sqrt_c = sqrtf((float)C);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row0 = wave * (PPW * PIX_ITERS) + pw;
+    u32x4 v[PIX_ITERS];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float a = bf16lo_to_f32(v[j]), b = bf16hi_to_f32(v[j]); ss += a * a + b * b; }
-    ss = wave_sum(ss);
-    const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
-    if (act) {
-        const float4 ga = reinterpret_cast<const float4*>(gamma)[lane * 2], gb = reinterpret_cast<const float4*>(gamma)[lane * 2 + 1];
-        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        u32x4 o;
+    for (int it = 0; it < PIX_ITERS; ++it) {
+        const int64_t row = row0 + (int64_t)it * PPW;
+        v[it] = u32x4{0, 0, 0, 0};
+        if (act_c && row < rows) v[it] = reinterpret_cast<const u32x4*>(x + row * C)[sub];
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = bf16lo_to_f32(v[j]) * scale * gv[2 * j], b = bf16hi_to_f32(v[j]) * scale * gv[2 * j + 1];
-            if (silu) { a = a / (1.f + __expf(-a)); b = b / (1.f + __expf(-b)); }
-            o[j] = pack_bf16x2(a, b);
+    for (int it = 0; it < PIX_ITERS; ++it) {
+        const int64_t row = row0 + (int64_t)it * PPW;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float a = bf16lo_to_f32(v[it][j]), b = bf16hi_to_f32(v[it][j]); ss += a * a + b * b; }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);      // stays inside the LPP-lane group
+        const float scale = sqrt_c / fmaxf(sqrtf(ss), 1e-12f);
+        if (act_c && row < rows) {
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = bf16lo_to_f32(v[it][j]) * scale * gv[2 * j], b = bf16hi_to_f32(v[it][j]) * scale * gv[2 * j + 1];
+                if (silu) { a = a / (1.f + __expf(-a)); b = b / (1.f + __expf(-b)); }
+                o[j] = pack_bf16x2(a, b);
+            }
+            reinterpret_cast<u32x4*>(out + row * C)[sub] = o;
         }
-        reinterpret_cast<u32x4*>(out + row * C)[lane] = o;
     }
 }
 
@@ -341,8 +363,19 @@ extern "C" wan_status_t wan_rmsnorm_silu_cl(const void* x, const float* gamma, v
     WAN_REQUIRE(x && gamma && out, WAN_ERR_INVALID, "wan_rmsnorm_silu_cl: null tensor");
     WAN_REQUIRE(C > 0 && C % 8 == 0 && C <= 512, WAN_ERR_UNSUPPORTED, "wan_rmsnorm_silu_cl: C=%d (multiple of 8, <= 512)", C);
     if (rows <= 0) return WAN_OK;
-    hipLaunchKernelGGL(rmsnorm_silu_cl_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, gamma, (bf16_t*)out, rows, C, silu);
+    const int nchunk = C / 8;
+    const int lpp = nchunk <= 8 ? 8 : (nchunk <= 16 ? 16 : (nchunk <= 32 ? 32 : 64));
+    const int64_t rows_per_wg = 4 * (64 / lpp) * 4;                 // 4 waves x pixels per wave x PIX_ITERS
+    const dim3 grid((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* xp = (const bf16_t*)x;
+    bf16_t* op = (bf16_t*)out;
+    switch (lpp) {
+        case 8: hipLaunchKernelGGL(rmsnorm_silu_cl_kernel<8>, grid, block, 0, st, xp, gamma, op, rows, C, silu); break;
+        case 16: hipLaunchKernelGGL(rmsnorm_silu_cl_kernel<16>, grid, block, 0, st, xp, gamma, op, rows, C, silu); break;
+        case 32: hipLaunchKernelGGL(rmsnorm_silu_cl_kernel<32>, grid, block, 0, st, xp, gamma, op, rows, C, silu); break;
+        default: hipLaunchKernelGGL(rmsnorm_silu_cl_kernel<64>, grid, block, 0, st, xp, gamma, op, rows, C, silu); break;
+    }
     WAN_CHECK_LAUNCH("wan_rmsnorm_silu_cl");
     return WAN_OK;
 }
