@@ -16,7 +16,7 @@
 // the reference calls feat_cache).
 //
 // Tile 128 pixels x (32*NT) channels x 64 k, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, double
-// buffered LDS, same source-side XOR swizzle as the GEMM.  NT = 3 / 4 / 6 -> BN = 96 / 128 / 192 so
+// buffered LDS, same source-side XOR swizzle as the GEMM.  NT = 1 / 3 / 4 / 6 -> BN = 32 / 96 / 128 / 192 so
 // the VAE widths 96 / 192 / 384 waste no MFMA columns.
 #include <algorithm>
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
     constexpr int BN = 32 * NT;
     constexpr int kWTile = BN * BK * 2;
     constexpr int kStage = kATile + kWTile;
-    constexpr int WP = BN / 8 / 4;          // W pieces (8 rows each) per wave: 3, 4, 6
+    constexpr int WP = BN / 8 / 4;          // W pieces (8 rows each) per wave: 1, 3, 4, 6
 
     // tile coordinates: N fastest so the CUs working at one time share the gathered A panel in L2
     const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;
@@ -352,6 +352,7 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
     g.cin_magic = (unsigned)((0x100000000ULL + p->Cin - 1) / p->Cin);
     g.tiles_m = (g.M + BM - 1) / BM;
     hipStream_t s = (hipStream_t)stream;
+    if (p->Cout <= 32) { g.tiles_n = 1; return launch_conv<1>(g, s); }      // decoder head (3), latent convs (16 / 32)
     if (p->Cout <= 96) { g.tiles_n = (p->Cout + 95) / 96; return launch_conv<3>(g, s); }
     if (p->Cout % 192 == 0) { g.tiles_n = p->Cout / 192; return launch_conv<6>(g, s); }
     g.tiles_n = (p->Cout + 127) / 128;
