@@ -409,9 +409,9 @@ class WanTransformer3DModel(nn.Module):
                 break
             # ---- self attention (:495-499)
             ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
-            ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
-            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
             if P == 1:
+                ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
+                ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
                 for b in range(B):
                     ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
                 ev = self._event_pair()
@@ -419,12 +419,19 @@ class WanTransformer3DModel(nn.Module):
                 self._event_done(ev, B * Ll)
                 o_in = att
             else:
+                # Ulysses: each projection is followed at once by its own head exchange (async, on RCCL's stream), so
+                # the k exchange runs under the V projection and the V^T exchange under the q projection; only the q
+                # exchange is left exposed before the attention launch.
                 sp = self._sp
-                fq = sp.scatter_heads(qk3[:, :, :C], async_op=True)
+                ops.gemm(h, blk.w_qk[C:], blk.b_qk[C:], ops.EPI_BF16, out=qk[:, C:])
+                ops.rmsnorm_rope_(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp)
                 fk = sp.scatter_heads(qk3[:, :, C:], async_op=True)
-                for b in range(B):      # V projection overlaps the q/k exchange
+                for b in range(B):
                     ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
                 fv = sp.scatter_heads_t(vt, ld=ops.round_up(seq_len, 64), async_op=True)
+                ops.gemm(h, blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[:, :C])
+                ops.rmsnorm_rope_(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+                fq = sp.scatter_heads(qk3[:, :, :C], async_op=True)
                 q_full, k_full, vt_full = fq().contiguous(), fk().contiguous(), fv()
                 ev = self._event_pair()
                 o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L, q_prescaled=True)
