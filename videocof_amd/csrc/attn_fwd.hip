@@ -91,6 +91,7 @@ struct AttnArgs {
 // (h) the first MFMA of each S chain as inline asm with D != C, so that the 16-register splat of -m is not copied
 // into the accumulator every tile (16 v_mov_b64 per tile): removes the copies, runs 2.7 % SLOWER (79.0 vs 76.9 ms).
 // (i) the row sum kept as a packed pair and accumulated with v_pk_add_f32: within noise (74.4 / 76.2 vs 75.3 ms).
+// (j) static s_setprio 1 for waves 4..7 (or 0..3): 73.1-73.8 vs 73.7-73.9 ms, noise.
 // ====================================================================================================
 constexpr float kDeferLog2 = 6.0f;
 constexpr int kVRing = 2;
