@@ -46,6 +46,7 @@ struct GemmArgs {
     const float* gate; int64_t rows_per_batch;
     int M, N, K;
     int tiles_m, tiles_n;
+    int gm;               // M tiles per rasterisation group (see wan_gemm_bf16_256)
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -54,7 +55,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn)
     const int xcd = bid & 7, loc = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    constexpr int GM = 4;                    // 4 M tiles x all N tiles per group: 32 CUs of an XCD share 4 A panels
+    const int GM = g.gm;                     // GM M tiles x all N tiles per group: the 32 CUs of an XCD share GM A panels
     const int per_group = GM * g.tiles_n;
     const int grp = t / per_group;
     const int first_m = grp * GM;
@@ -338,6 +339,10 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    // M tiles per rasterisation group, measured at M = 67 080 (profiles/r01/gemm_raster_group_ab.log): 2 for wide N
+    // (qk projection +5 %, ffn.0 +2 % over the former 4), 3 otherwise (+2 %); 8 and 16 lose 10-15 %.
+    g.gm = g.tiles_n >= 40 ? 2 : 3;
+    { const char* eg = getenv("WAN_GEMM_GM"); if (eg && atoi(eg) > 0) g.gm = atoi(eg); }     // developer A/B switch
     const char* ev = getenv("WAN_GEMM_PHASES");          // developer A/B switch
     const int phases = ev ? atoi(ev) : kDefaultPhases;
 #define WAN_G256(E) (phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
