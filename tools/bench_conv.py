@@ -25,6 +25,7 @@ SHAPES = [  # Cin, Cout, T, H, W, what
 
 def main():
     g = torch.Generator(device=DEV).manual_seed(0)
+    print("WAN_CONV_XCD =", os.environ.get("WAN_CONV_XCD", "1 (default)"))
     for cin, cout, T, H, W, what in SHAPES:
         co = max(cout, 8)
         K = 27 * cin

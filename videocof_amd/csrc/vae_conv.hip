@@ -18,6 +18,8 @@
 // Tile 128 pixels x (32*NT) channels x 64 k, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, double
 // buffered LDS, same source-side XOR swizzle as the GEMM.  NT = 1 / 3 / 4 / 6 -> BN = 32 / 96 / 128 / 192 so
 // the VAE widths 96 / 192 / 384 waste no MFMA columns.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.hpp"
@@ -39,6 +41,7 @@ struct ConvArgs {
     int ups, interleave, hist_frames, silu;
     int M, ntaps, nk, tiles_m, tiles_n;
     unsigned cin_magic;          // ceil(2^32 / Cin)
+    int xcd_slabs;               // 1: XCD-contiguous tile slabs (default), 0: plain order (A/B switch WAN_CONV_XCD=0)
 };
 
 __device__ __forceinline__ int div3(int a) { return (a * 171) >> 9; }   // exact for 0 <= a < 256
@@ -51,8 +54,16 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
     constexpr int kStage = kATile + kWTile;
     constexpr int WP = BN / 8 / 4;          // W pieces (8 rows each) per wave: 1, 3, 4, 6
 
-    // tile coordinates: N fastest so the CUs working at one time share the gathered A panel in L2
-    const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;
+    // Tile coordinates.  Block b runs on XCD b % 8 (observed): each XCD takes a contiguous slab of the tile sequence
+    // (bijective remap as in the GEMM) so that neighbouring pixel tiles -- whose 3x3x3 gathers overlap by whole image
+    // rows -- share one XCD's L2; N fastest inside the sequence so the N tiles of one pixel tile run together.
+    int t = blockIdx.x;
+    if (g.xcd_slabs) {
+        const int nwg = g.tiles_m * g.tiles_n;
+        const int xcd = t & 7, loc = t >> 3, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = t % g.tiles_n, tm = t / g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -350,6 +361,7 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
     g.ups = p->upsample2x ? 1 : 0; g.interleave = p->time_interleave ? 1 : 0; g.hist_frames = hist_frames; g.silu = 0;
     g.M = (int)M; g.ntaps = ntaps; g.nk = Kpad / BK;
     g.cin_magic = (unsigned)((0x100000000ULL + p->Cin - 1) / p->Cin);
+    { const char* ex = getenv("WAN_CONV_XCD"); g.xcd_slabs = !(ex && atoi(ex) == 0); }      // developer A/B switch
     g.tiles_m = (g.M + BM - 1) / BM;
     hipStream_t s = (hipStream_t)stream;
     if (p->Cout <= 32) { g.tiles_n = 1; return launch_conv<1>(g, s); }      // decoder head (3), latent convs (16 / 32)
