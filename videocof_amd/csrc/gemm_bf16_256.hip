@@ -23,7 +23,9 @@
 //
 // Measured and not kept: de-synchronising the CUs with a per-workgroup start delay in the first round (so that the
 // HBM-bound fp32 read-modify-write epilogues of different CUs do not coincide): 1282 vs 1285-1304 TFLOP/s on the
-// o-projection, 1165 vs 1165-1170 on ffn.2 -- noise; the CUs drift apart on their own.
+// o-projection, 1165 vs 1165-1170 on ffn.2 -- noise; the CUs drift apart on their own.  The same wave tile computed
+// with v_mfma_f32_32x32x16_bf16 (4 x 2 tiles, half the MFMA instructions, same LDS traffic): 5-8 % SLOWER on every
+// shape (profiles/r01/gemm_mfma32x32_ab.log).
 #include <stdlib.h>
 
 #include "common.hpp"
