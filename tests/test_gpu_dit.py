@@ -279,3 +279,19 @@ def test_skip_source_prediction_is_parity_neutral(golden, model):
                  frame_split_indices=[3], ground_frame_indices=[(3, 4)])
     assert float(out[:, :, :3].abs().max()) == 0.0
     assert rel_l2(out[:, :, 3:], full[:, :, 3:].cpu()) < 1e-6
+
+
+def test_unipc_12_step_trajectory_on_device(golden):
+    """The scheduler's update on CUDA tensors is one fused wan_lincomb per step; 12 steps at shift 5 against the
+    trajectory captured from the reference scheduler (fixture g7b), fp32 and bf16 latents."""
+    g = golden("dit_g7b_unipc12")
+    for dtype, tol in ((torch.float32, 2e-6), (torch.bfloat16, 3e-2)):
+        s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)
+        s.set_timesteps(12, device=DEV, shift=5.0)
+        cur = torch.from_numpy(g["x"]).to(DEV, dtype)
+        for i, t in enumerate(s.timesteps):
+            cur = s.step(torch.from_numpy(g["v"][i]).to(DEV, dtype), t, cur, return_dict=False)[0]
+            assert cur.dtype == dtype and cur.is_cuda
+            if dtype == torch.float32:
+                assert rel_l2(cur, g["traj"][i]) < tol, i
+        assert rel_l2(cur.float(), g["traj"][11]) < tol

@@ -64,6 +64,20 @@ def test_unipc_matches_reference_trajectory(golden):
     np.testing.assert_array_equal(s.sigmas.numpy(), g50["sigmas"])
 
 
+def test_unipc_matches_reference_12_step_trajectory(golden):
+    g = golden("dit_g7b_unipc12")
+    s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)
+    s.set_timesteps(12, device="cpu", shift=5.0)
+    np.testing.assert_array_equal(s.timesteps.numpy(), g["timesteps"])
+    np.testing.assert_array_equal(s.sigmas.numpy(), g["sigmas"])
+    cur, orders = torch.from_numpy(g["x"]), []
+    for i, t in enumerate(s.timesteps):
+        cur = s.step(torch.from_numpy(g["v"][i]), t, cur, return_dict=False)[0]
+        orders.append(s.this_order)
+        assert rel_l2(cur, g["traj"][i]) < 5e-6, i
+    assert orders == [1] + [2] * 10 + [1]
+
+
 def test_unipc_bf16_latents_stay_bf16_and_close(golden):
     g = golden("dit_g7_unipc")
     s = FlowUniPCMultistepScheduler(shift=1)

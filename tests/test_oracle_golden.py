@@ -126,6 +126,21 @@ def test_g7_unipc(golden):
     np.testing.assert_array_equal(s.sigmas.numpy(), g50["sigmas"])
 
 
+def test_g7b_unipc_12_steps(golden):
+    """Steady second-order steps + lower_order_final (orders 1, 2 x 10, 1), shift 5 as in inference.py."""
+    g = golden("dit_g7b_unipc12")
+    s = O.UniPCOracle()
+    s.set_timesteps(12, 5.0)
+    assert s.timesteps.tolist() == g["timesteps"].tolist()
+    np.testing.assert_array_equal(s.sigmas.numpy(), g["sigmas"])
+    cur, orders = torch.from_numpy(g["x"]), []
+    for i in range(12):
+        cur = s.step(torch.from_numpy(g["v"][i]), cur)
+        orders.append(s.this_order)
+        assert rel_l2(cur, g["traj"][i]) < 5e-6, i
+    assert orders == g["orders"].tolist() == [1] + [2] * 10 + [1]
+
+
 def test_g8_cof_loop(golden, sd):
     g = golden("dit_g8_cof_loop")
     assert O.cof_layout(9, 4) == (3, 1)
