@@ -219,3 +219,37 @@ def test_pipeline_encodes_prompt_strings_with_the_hip_encoder():
     assert rel_l2(embeds[0][0], ref_emb[0, :9]) < 1.5e-2 and rel_l2(embeds[1][0], ref_emb[1, :4]) < 1.5e-2
     want = pipe(prompt_embeds=[ref_emb[0, :9].to(DEV)], negative_prompt_embeds=[ref_emb[1, :4].to(DEV)], **kw).latents
     assert rel_l2(got, want) < 2e-2
+
+
+def test_from_pretrained_files_vae_and_t5(tmp_path):
+    """The reference's checkpoint conventions: Wan2.1_VAE.pth holds un-prefixed keys (wan_vae.py:699-702 adds
+    "model."), models_t5_umt5-xxl-enc-bf16.pth is a plain state dict (wan_text_encoder.py:383-390); both loaders also
+    take .safetensors."""
+    from safetensors.torch import save_file
+    from videocof_amd import AutoencoderKLWan
+    from videocof_amd.weights import deterministic_vae_state_dict
+    vsd = deterministic_vae_state_dict()
+    bare = {k[len("model."):]: v.contiguous() for k, v in vsd.items()}
+    save_file(bare, str(tmp_path / "vae.safetensors"))
+    torch.save(bare, str(tmp_path / "Wan2.1_VAE.pth"))
+    direct = AutoencoderKLWan()
+    direct.load_state_dict(vsd, device=DEV)
+    video = (torch.rand(1, 3, 5, 32, 48, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(DEV)
+    want = direct.encode(video)[0].mode()
+    for name in ("vae.safetensors", "Wan2.1_VAE.pth"):
+        vae = AutoencoderKLWan.from_pretrained(str(tmp_path / name))
+        assert torch.equal(vae.encode(video)[0].mode(), want), name
+
+    tsd = deterministic_t5_state_dict(**TINY)
+    save_file({k: v.contiguous() for k, v in tsd.items()}, str(tmp_path / "t5.safetensors"))
+    torch.save(tsd, str(tmp_path / "t5.pth"))
+    ids = torch.randint(1, TINY["vocab"], (1, 24), generator=torch.Generator().manual_seed(1)).to(DEV)
+    ref = WanT5EncoderModel(shared_pos=False, **TINY)
+    ref.load_state_dict(tsd, device=DEV)
+    want = ref(ids)[0]
+    kwargs = dict(TINY, shared_pos=False, dropout=0.0, text_length=512, tokenizer_subpath="ignored")
+    for name in ("t5.safetensors", "t5.pth"):
+        m = WanT5EncoderModel.from_pretrained(str(tmp_path / name), additional_kwargs=kwargs)
+        assert torch.equal(m(ids)[0], want), name
+    with pytest.raises(FileNotFoundError):
+        WanT5EncoderModel.from_pretrained(str(tmp_path / "missing.pth"), additional_kwargs=kwargs)
