@@ -295,3 +295,43 @@ def test_unipc_12_step_trajectory_on_device(golden):
             if dtype == torch.float32:
                 assert rel_l2(cur, g["traj"][i]) < tol, i
         assert rel_l2(cur.float(), g["traj"][11]) < tol
+
+
+def test_merge_lora_in_place_on_the_loaded_model(golden, tmp_path):
+    """merge_lora(pipeline, path, multiplier, ...) with the reference's signature (lora_utils.py:371), applied to the
+    packed device weights: the merged weights equal fixture g12 (captured from the reference's merge_lora on the same
+    LoRA, three key styles), the forward changes, unmerge restores the original output up to bf16 rounding."""
+    from types import SimpleNamespace
+    from safetensors.torch import save_file
+    from videocof_amd.lora_utils import merge_lora, unmerge_lora
+    g = golden("dit_g12_lora")
+    sd = deterministic_dit_state_dict(**TINY)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(sd, device=DEV)
+    C, r = 256, 4
+    lora = {
+        "diffusion_model.blocks.0.self_attn.q.lora_down.weight": det_uniform("l.a.down", (r, C), 0.3),
+        "diffusion_model.blocks.0.self_attn.q.lora_up.weight": det_uniform("l.a.up", (C, r), 0.3),
+        "diffusion_model.blocks.0.self_attn.q.alpha": torch.tensor(2.0),
+        "blocks.1.ffn.0.lora_A.default.weight": det_uniform("l.b.down", (r, C), 0.3),
+        "blocks.1.ffn.0.lora_B.default.weight": det_uniform("l.b.up", (512, r), 0.3),
+        "lora_unet__blocks_1_cross_attn_o.lora_down.weight": det_uniform("l.c.down", (r, C), 0.3),
+        "lora_unet__blocks_1_cross_attn_o.lora_up.weight": det_uniform("l.c.up", (C, r), 0.3),
+        "lora_unet__blocks_1_cross_attn_o.alpha": torch.tensor(8.0),
+        "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight": torch.zeros(r, 8),
+    }
+    save_file({k: v.contiguous() for k, v in lora.items()}, str(tmp_path / "lora.safetensors"))
+    pipe = SimpleNamespace(transformer=m)
+    lat = det_uniform("ml.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("ml.ctx", (9, 64), 1.0).to(DEV)]
+    t = torch.tensor([321], device=DEV)
+    before = m(lat, t, ctx, 48)
+    assert merge_lora(pipe, str(tmp_path / "lora.safetensors"), 0.75, device=DEV, dtype=torch.bfloat16) is pipe
+    w = m.linear_weights()
+    for name, key in (("blocks.0.self_attn.q", "q"), ("blocks.1.ffn.0", "ffn0"), ("blocks.1.cross_attn.o", "o"),
+                      ("blocks.0.self_attn.k", "untouched")):
+        assert rel_l2(w[name], g[key]) < 3e-3, name              # bf16 storage of the fp32 reference merge
+    merged = m(lat, t, ctx, 48)
+    assert rel_l2(merged, before.cpu()) > 1e-3
+    unmerge_lora(pipe, None, 0.75, state_dict=lora)
+    assert rel_l2(m(lat, t, ctx, 48), before.cpu()) < 1e-2

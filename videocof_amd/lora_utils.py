@@ -25,7 +25,7 @@ from typing import Dict, Optional
 
 import torch
 
-__all__ = ["merge_lora_state_dict", "unmerge_lora_state_dict"]
+__all__ = ["merge_lora_state_dict", "unmerge_lora_state_dict", "merge_lora", "unmerge_lora"]
 
 
 def _module_index(sd: Dict[str, torch.Tensor]) -> Dict[str, str]:
@@ -91,3 +91,44 @@ def merge_lora_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.
 def unmerge_lora_state_dict(sd, lora_sd, multiplier: float = 1.0, device: Optional[str] = None) -> int:
     """Inverse of merge_lora_state_dict (lora_utils.py:503-620)."""
     return merge_lora_state_dict(sd, lora_sd, -multiplier, device)
+
+
+@torch.no_grad()
+def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32, state_dict=None,
+               transformer_only=False, sub_transformer_name="transformer"):
+    """Same call as the reference's ``merge_lora`` (lora_utils.py:371-500; three calls in fast_infer.py:366-386),
+    applied IN PLACE to the packed device weights of a loaded ``videocof_amd.WanTransformer3DModel``:
+    ``W = bf16(fp32(W) + multiplier * alpha/r * up @ down)``.  Text-encoder entries are ignored (the reference
+    skips them with ``transformer_only`` and VideoCoF's LoRAs carry none); returns the pipeline."""
+    if state_dict is None:
+        from safetensors.torch import load_file
+        state_dict = load_file(lora_path)
+    model = getattr(pipeline, sub_transformer_name)
+    weights = model.linear_weights()
+    index = {name.replace(".", "_"): name for name in weights}
+    groups = defaultdict(dict)
+    for key, val in state_dict.items():
+        n = _normalise(key)
+        if n is not None:
+            groups[n[0]][n[1]] = val
+    for flat, elems in groups.items():
+        mod = index.get(flat)
+        if mod is None or "lora_up.weight" not in elems or "lora_down.weight" not in elems:
+            continue
+        w = weights[mod]
+        up = elems["lora_up.weight"].to(w.device, torch.float32).flatten(1)
+        down = elems["lora_down.weight"].to(w.device, torch.float32).flatten(1)
+        scale = float(elems["alpha"]) / up.shape[1] if "alpha" in elems else 1.0
+        delta = torch.mm(up, down)
+        if delta.shape != w.shape:
+            raise ValueError(f"LoRA for {mod}: delta {tuple(delta.shape)} does not match weight {tuple(w.shape)}")
+        w.copy_((w.float() + multiplier * scale * delta).to(w.dtype))
+    if hasattr(model, "_ctx_cache"):
+        model._ctx_cache = None          # hoisted text K/V were built from the old cross-attention weights
+    return pipeline
+
+
+def unmerge_lora(pipeline, lora_path, multiplier=1, device=None, dtype=torch.float32, state_dict=None,
+                 sub_transformer_name="transformer"):
+    """Inverse of ``merge_lora`` (lora_utils.py:503-620); exact up to the bf16 rounding of the merged weights."""
+    return merge_lora(pipeline, lora_path, -multiplier, device, dtype, state_dict, sub_transformer_name=sub_transformer_name)

@@ -197,6 +197,21 @@ class WanTransformer3DModel(nn.Module):
         self._ctx_cache = None
         return SimpleNamespace(missing_keys=[], unexpected_keys=[])
 
+    def linear_weights(self):
+        """Reference module name (``blocks.3.self_attn.q`` ...) -> the packed bf16 [out, in] device weight of that
+        ``nn.Linear`` (a VIEW: in-place edits take effect at the next forward; used by ``lora_utils.merge_lora``)."""
+        if self._device is None:
+            raise RuntimeError("load_state_dict first")
+        C, w = self.dim, self._w
+        out = {"text_embedding.0": w["te_w0"], "text_embedding.2": w["te_w2"], "head.head": w["head_w"],
+               "patch_embedding": w["pe_w"]}
+        for i, b in enumerate(self.blocks):
+            p = f"blocks.{i}."
+            out.update({p + "self_attn.q": b.w_qk[:C], p + "self_attn.k": b.w_qk[C:], p + "self_attn.v": b.w_v,
+                        p + "self_attn.o": b.w_o, p + "cross_attn.q": b.w_cq, p + "cross_attn.k": b.w_ck,
+                        p + "cross_attn.v": b.w_cv, p + "cross_attn.o": b.w_co, p + "ffn.0": b.w1, p + "ffn.2": b.w2})
+        return out
+
     @classmethod
     def from_pretrained(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
                         low_cpu_mem_usage=False, torch_dtype=torch.bfloat16):
