@@ -335,3 +335,41 @@ def test_merge_lora_in_place_on_the_loaded_model(golden, tmp_path):
     assert rel_l2(merged, before.cpu()) > 1e-3
     unmerge_lora(pipe, None, 0.75, state_dict=lora)
     assert rel_l2(m(lat, t, ctx, 48), before.cpu()) < 1e-2
+
+
+def test_module_surface_state_dict_partial_load_and_pipeline_to(model):
+    """What fast_infer.py does around the models (:280-362): `m, u = model.load_state_dict(ckpt, strict=False)` with a
+    partial fine-tuned checkpoint on top of from_pretrained, `.to()`, `.eval()`, `pipeline.to(device)`, the offload
+    switches; plus state_dict() round trip under the reference's key names."""
+    sd = deterministic_dit_state_dict(**TINY)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    assert m.state_dict() == {}
+    r = m.load_state_dict(sd, device=DEV)
+    assert tuple(r) == ([], []) and r.missing_keys == []
+    got = m.state_dict()
+    assert set(got) == set(sd)
+    for k, v in sd.items():
+        assert got[k].shape == v.shape, k
+        assert rel_l2(got[k].float(), v) < 4e-3 or float(v.abs().max()) == 0, k
+    lat = det_uniform("ms.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("ms.ctx", (9, 64), 1.0).to(DEV)]
+    t = torch.tensor([321], device=DEV)
+    base = m(lat, t, ctx, 48)
+    assert torch.equal(base, model(lat, t, ctx, 48))
+    # partial checkpoint: only two tensors, strict=False -> the rest keeps its values, result is unpackable
+    part = {"blocks.1.ffn.0.weight": sd["blocks.1.ffn.0.weight"] * 1.5, "blocks.0.self_attn.q.bias": sd["blocks.0.self_attn.q.bias"] + 0.2,
+            "not.a.key": torch.zeros(1)}
+    missing, unexpected = m.load_state_dict(part, strict=False)
+    assert unexpected == ["not.a.key"] and len(missing) == len(sd) - 2
+    sd2 = dict(sd); sd2.update({k: v for k, v in part.items() if k in sd})
+    ref = O.dit_forward(sd2, CFG, lat.cpu(), t.cpu(), [c.cpu() for c in ctx], 48)
+    out = m(lat, t, ctx, 48)
+    assert rel_l2(out, ref) < 1e-2 and rel_l2(out, base.cpu()) > 1e-3
+    with pytest.raises(KeyError, match="unexpected"):
+        m.load_state_dict(dict(sd, extra=torch.zeros(1)), strict=True)
+    assert m.eval() is m and m.to(torch.bfloat16) is m
+    pipe = WanPipeline(transformer=m, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    assert pipe.to(device=DEV) is pipe and pipe.to("cuda") is pipe
+    assert pipe.enable_model_cpu_offload(device=DEV) is None and pipe.enable_sequential_cpu_offload(device=DEV) is None
+    with pytest.raises(RuntimeError, match="loaded on"):
+        pipe.to("cpu")

@@ -56,6 +56,26 @@ class WanPipeline:
     num_timesteps = property(lambda self: self._num_timesteps)
     interrupt = property(lambda self: self._interrupt)
 
+    # -------------------------------------------------------------- placement (fast_infer.py:347-362)
+    def to(self, *args, device=None, **kwargs):
+        """The models are packed on their HIP device by ``load_state_dict``; ``pipeline.to(device)`` only checks that
+        the request matches (no parameters to move), so the reference's ``model_full_load`` branch works unchanged."""
+        want = device if device is not None else next((a for a in args if isinstance(a, (str, torch.device))), None)
+        if want is not None:
+            want = torch.device(want)
+            have = self.transformer.device
+            if want.type != "cuda" or (want.index is not None and have is not None and have.index is not None
+                                       and want.index != have.index):
+                raise RuntimeError(f"WanPipeline.to({want}): the transformer was loaded on {have}; load it there instead")
+        return self
+
+    def enable_model_cpu_offload(self, *args, **kwargs):
+        """No-op: 14B bf16 weights (28 GB) + umT5 (11 GB) + VAE stay resident in the 288 GB of HBM; there is nothing to
+        offload (the reference's default ``sequential_cpu_offload`` exists for 24-80 GB cards)."""
+        return None
+
+    enable_sequential_cpu_offload = enable_model_cpu_offload
+
     # -------------------------------------------------------------- prompt handling (:595-608)
     def _get_t5_prompt_embeds(self, prompt, max_sequence_length: int = 512, device=None):
         """tokenizer(padding="max_length", max_length=512, truncation) -> text_encoder(ids, mask)[0], each

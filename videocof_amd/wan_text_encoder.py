@@ -134,7 +134,8 @@ class WanT5EncoderModel:
                 raise ValueError(p + "pos_embedding.embedding.weight has the wrong shape")
             self._blocks.append(b)
         self._device = dev
-        return [], unexpected
+        from .wan_transformer3d import IncompatibleKeys
+        return IncompatibleKeys([], unexpected)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_path, additional_kwargs={}, low_cpu_mem_usage=False,

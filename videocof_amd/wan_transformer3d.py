@@ -26,6 +26,7 @@ import glob
 import json
 import math
 import os
+from collections import namedtuple
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -56,6 +57,10 @@ def rope_params(max_seq_len: int, dim: int, theta: float = 10000.0) -> torch.Ten
                           torch.arange(0, dim, 2, dtype=torch.float64) / dim)
     ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64), inv)
     return torch.polar(torch.ones_like(ang), ang)
+
+
+# what nn.Module.load_state_dict returns: unpackable as `m, u = model.load_state_dict(...)` (fast_infer.py:294)
+IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 
 class _Block:
@@ -137,6 +142,13 @@ class WanTransformer3DModel(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("WanTransformer3DModel runs on a HIP device only (no CPU fallback)")
         sd = state_dict
+        missing = []
+        if not strict and getattr(self, "_w", None):
+            # nn.Module semantics of strict=False on a loaded model (fast_infer.py:286-295: a fine-tuned checkpoint on
+            # top of from_pretrained): keys that are absent keep their current values
+            current = self.state_dict()
+            missing = [k for k in current if k not in sd]
+            sd = {**current, **sd}
         used = set()
 
         def get(k):
@@ -186,21 +198,49 @@ class WanTransformer3DModel(nn.Module):
             b.modulation = vec(p + "modulation").reshape(6, C)
             self.blocks.append(b)
         w["mod_all"] = torch.stack([b.modulation for b in self.blocks])        # [layers, 6, C]
-        if strict:
-            extra = [k for k in sd.keys() if k not in used]
-            if extra:
-                raise KeyError(f"unexpected keys in state_dict: {extra[:5]}{'...' if len(extra) > 5 else ''}")
+        extra = [k for k in sd.keys() if k not in used]
+        if strict and extra:
+            raise KeyError(f"unexpected keys in state_dict: {extra[:5]}{'...' if len(extra) > 5 else ''}")
         ang = torch.view_as_real(self.freqs)          # [1024, 64, 2] = (cos, sin) of the fp64 angles
         self._rope_dev = (ang[..., 0].to(torch.float32).contiguous().to(dev),
                           ang[..., 1].to(torch.float32).contiguous().to(dev))
         self._device = dev
         self._ctx_cache = None
-        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+        return IncompatibleKeys(missing, extra)
+
+    def state_dict(self, *args, **kwargs):  # type: ignore[override]
+        """The weights under the reference's key names (views of the packed device tensors: bf16 matrices, fp32
+        vectors) -- what ``load_state_dict`` accepts and what ``safetensors.save_file`` can write."""
+        if not getattr(self, "_w", None):
+            return {}
+        C, w = self.dim, self._w
+        sd = {"patch_embedding.weight": w["pe_w"].view(C, self.in_dim, *self.patch_size), "patch_embedding.bias": w["pe_b"],
+              "time_projection.1.weight": w["tp_w"], "time_projection.1.bias": w["tp_b"],
+              "head.head.weight": w["head_w"], "head.head.bias": w["head_b"], "head.modulation": w["head_mod"].view(1, 2, C)}
+        for i in ("0", "2"):
+            sd[f"text_embedding.{i}.weight"], sd[f"text_embedding.{i}.bias"] = w[f"te_w{i}"], w[f"te_b{i}"]
+            sd[f"time_embedding.{i}.weight"], sd[f"time_embedding.{i}.bias"] = w[f"tm_w{i}"], w[f"tm_b{i}"]
+        for i, b in enumerate(self.blocks):
+            p = f"blocks.{i}."
+            sd.update({p + "modulation": b.modulation.view(1, 6, C),
+                       p + "self_attn.q.weight": b.w_qk[:C], p + "self_attn.q.bias": b.b_qk[:C],
+                       p + "self_attn.k.weight": b.w_qk[C:], p + "self_attn.k.bias": b.b_qk[C:],
+                       p + "self_attn.v.weight": b.w_v, p + "self_attn.v.bias": b.b_v,
+                       p + "self_attn.o.weight": b.w_o, p + "self_attn.o.bias": b.b_o,
+                       p + "self_attn.norm_q.weight": b.nq, p + "self_attn.norm_k.weight": b.nk,
+                       p + "cross_attn.q.weight": b.w_cq, p + "cross_attn.q.bias": b.b_cq,
+                       p + "cross_attn.k.weight": b.w_ck, p + "cross_attn.k.bias": b.b_ck,
+                       p + "cross_attn.v.weight": b.w_cv, p + "cross_attn.v.bias": b.b_cv,
+                       p + "cross_attn.o.weight": b.w_co, p + "cross_attn.o.bias": b.b_co,
+                       p + "cross_attn.norm_q.weight": b.ncq, p + "cross_attn.norm_k.weight": b.nck,
+                       p + "norm3.weight": b.n3w, p + "norm3.bias": b.n3b,
+                       p + "ffn.0.weight": b.w1, p + "ffn.0.bias": b.b1, p + "ffn.2.weight": b.w2, p + "ffn.2.bias": b.b2})
+        return sd
 
     def linear_weights(self):
         """Reference module name (``blocks.3.self_attn.q`` ...) -> the packed bf16 [out, in] device weight of that
         ``nn.Linear`` (a VIEW: in-place edits take effect at the next forward; used by ``lora_utils.merge_lora``)."""
-        if self._device is None:
+        if not getattr(self, "_w", None):
             raise RuntimeError("load_state_dict first")
         C, w = self.dim, self._w
         out = {"text_embedding.0": w["te_w0"], "text_embedding.2": w["te_w2"], "head.head": w["head_w"],

@@ -133,7 +133,8 @@ class AutoencoderKLWan(nn.Module):
             raise KeyError(f"missing keys in state_dict: {missing}")
         self._device = dev
         self.clear_cache()
-        return SimpleNamespace(missing_keys=missing, unexpected_keys=[])
+        from .wan_transformer3d import IncompatibleKeys
+        return IncompatibleKeys(missing, [])
 
     @classmethod
     def from_pretrained(cls, pretrained_model_path, additional_kwargs={}):
