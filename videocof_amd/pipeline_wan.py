@@ -147,15 +147,21 @@ class WanPipeline:
     # -------------------------------------------------------------- __call__ (:516-799)
     @torch.no_grad()
     def __call__(self, video: Optional[torch.Tensor] = None, prompt=None, negative_prompt=None,
-                 height: int = 480, width: int = 832, num_frames: int = 49, source_frames: int = 33,
-                 reasoning_frames: int = 4, num_inference_steps: int = 50, guidance_scale: float = 6.0,
-                 shift: float = 5.0, repeat_rope: bool = False, cot: bool = False,
-                 num_videos_per_prompt: int = 1, generator: Optional[torch.Generator] = None,
-                 latents: Optional[torch.Tensor] = None, source_latents: Optional[torch.Tensor] = None,
+                 height: int = 480, width: int = 720, num_frames: int = 49, source_frames: int = 33,
+                 reasoning_frames: int = 4, num_inference_steps: int = 50, timesteps=None,
+                 guidance_scale: float = 6.0, num_videos_per_prompt: int = 1, eta: float = 0.0,
+                 generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
                  prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "numpy",
                  return_dict: bool = False, callback_on_step_end: Optional[Callable] = None,
-                 max_sequence_length: int = 512, device=None, weight_dtype: torch.dtype = torch.bfloat16,
-                 cache_context: bool = True, skip_source_prediction: bool = True):
+                 attention_kwargs=None, callback_on_step_end_tensor_inputs=("latents",),
+                 max_sequence_length: int = 512, comfyui_progressbar: bool = False,
+                 shift: float = 5.0, repeat_rope: bool = True, cot: bool = False,
+                 # extensions of this package (keyword-only in spirit; the names above are the reference's, :516-548)
+                 source_latents: Optional[torch.Tensor] = None, device=None,
+                 weight_dtype: torch.dtype = torch.bfloat16, cache_context: bool = True,
+                 skip_source_prediction: bool = True):
+        if timesteps is not None:
+            raise NotImplementedError("custom `timesteps` are not supported (the reference's CLIs never pass them)")
         if num_videos_per_prompt != 1:
             raise NotImplementedError("num_videos_per_prompt must be 1 (as in fast_infer.py / inference.py)")
         self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
