@@ -353,7 +353,9 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         printf("  rmsnorm_rope q+k L=%d C=%d: %.3f ms  %.0f GB/s (8C B/row)\n", L, C, ms, 8.0 * C * L / ms / 1e6);
     }
     struct G { int M, N, K; int epi; const char* what; };
-    std::vector<G> gs = {{L, 5120, 5120, WAN_EPI_BF16, "14B o/q proj"}, {L, 10240, 5120, WAN_EPI_BF16, "14B qk proj"},
+    std::vector<G> gs = {{8392, 5120, 5120, WAN_EPI_BF16, "14B o/q proj, SP8 shard"}, {8392, 13824, 5120, WAN_EPI_GELU_BF16, "14B ffn.0, SP8 shard"},
+                         {8392, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2, SP8 shard"}, {16776, 5120, 5120, WAN_EPI_BF16, "14B o/q proj, SP4 shard"},
+                         {L, 5120, 5120, WAN_EPI_BF16, "14B o/q proj"}, {L, 10240, 5120, WAN_EPI_BF16, "14B qk proj"},
                          {L, 13824, 5120, WAN_EPI_GELU_BF16, "14B ffn.0+gelu"}, {L, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2+resid"},
                          {L, 5120, 5120, WAN_EPI_BF16_T, "14B v proj (T)"}, {L, 1536, 1536, WAN_EPI_BF16, "1.3B proj"},
                          {L, 8960, 1536, WAN_EPI_GELU_BF16, "1.3B ffn.0"}};
