@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--workload", default="14b-cof", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="sp", choices=["sp", "dp"], help="N>1: Ulysses sequence parallel or replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo (host-staged exchanges) only to exercise the N>1 code path on a box "
+                         "whose ranks share one GPU -- its numbers are meaningless")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
@@ -154,6 +158,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         args.gpus = world
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -164,7 +170,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     wl = WORKLOADS[args.workload]
     sp = world > 1 and args.mode == "sp"
     if sp and wl["num_heads"] % world:
@@ -221,7 +230,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     if world > 1:
-        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
+        tw = torch.tensor([wall], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     assert torch.isfinite(out.float()).all(), "non-finite latents"
