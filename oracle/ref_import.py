@@ -4,7 +4,8 @@ Runs only in the build container where ``/root/reference`` is mounted; nothing i
 ``-m gpu`` tests, ``bench.py`` or ``smoke()`` may import this module (the reference
 does not exist on the GPU box).  It is used by ``oracle/gen_golden.py`` to
 produce the committed fixtures under ``tests/golden/`` and by
-``tests/test_oracle_vs_reference.py`` (skipped when the reference is absent).
+``tests/test_oracle_vs_reference.py`` (live oracle-vs-reference checks on fresh inputs; skipped when the reference is
+absent).
 
 The reference needs ``diffusers`` (absent here) for a few base classes only.  We
 install minimal stand-in modules in ``sys.modules`` -- behavioural stubs of

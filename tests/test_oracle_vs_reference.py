@@ -1,0 +1,98 @@
+"""Live cross-check of the CPU oracles against the REFERENCE itself on fresh random inputs (not the
+committed fixtures).  Runs only where /root/reference is mounted (the build container); skipped elsewhere -- the
+reference never travels to the GPU box.  fp32 vs fp32: rel-L2 <= 1e-5."""
+import pytest
+import torch
+
+from oracle.ref_import import load_reference, reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="reference tree not mounted")
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ns():
+    torch.set_num_threads(8)
+    return load_reference()
+
+
+@torch.no_grad()
+def test_dit_forward_random_inputs(ns):
+    """Another grid, another source / ground split (two grounding frames), B = 2 with different prompts."""
+    from oracle import wan_oracle as O
+    from videocof_amd.weights import deterministic_dit_state_dict
+    cfgd = dict(dim=384, ffn_dim=640, num_layers=2, in_dim=16, out_dim=16, text_dim=96, freq_dim=256)
+    sd = deterministic_dit_state_dict(**cfgd)
+    m = ns.transformer.WanTransformer3DModel(model_type="t2v", dim=384, ffn_dim=640, num_heads=3, num_layers=2, text_dim=96,
+                                             in_dim=16, out_dim=16, freq_dim=256, cross_attn_norm=True, qk_norm=True)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(123)
+    lat = torch.randn(2, 16, 8, 6, 10, generator=g)
+    ctx = [torch.randn(17, 96, generator=g), torch.randn(3, 96, generator=g)]
+    t = torch.tensor([612, 612])
+    seq_len = 8 * 3 * 5
+    ref = m(lat, t=t, context=ctx, seq_len=seq_len, frame_split_indices=[3, 3], ground_frame_indices=[(3, 5), (3, 5)])
+    cfg = O.DiTConfig(dim=384, ffn_dim=640, num_heads=3, num_layers=2, text_dim=96)
+    out = O.dit_forward(sd, cfg, lat, t, ctx, seq_len, [3, 3], [(3, 5), (3, 5)])
+    assert rel_l2(out, ref) < 1e-5
+    ref_pad = m(lat[:1], t=t[:1], context=ctx[:1], seq_len=seq_len + 8)                  # padded sequence, plain T2V
+    assert rel_l2(O.dit_forward(sd, cfg, lat[:1], t[:1], ctx[:1], seq_len + 8), ref_pad) < 1e-5
+
+
+@torch.no_grad()
+def test_unipc_random_trajectory(ns):
+    from oracle import wan_oracle as O
+    g = torch.Generator().manual_seed(7)
+    for steps, shift in ((7, 3.0), (20, 5.0)):
+        sch = ns.unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2,
+                                                   prediction_type="flow_prediction")
+        sch.set_timesteps(steps, device="cpu", shift=shift)
+        s = O.UniPCOracle()
+        s.set_timesteps(steps, shift)
+        assert s.timesteps.tolist() == sch.timesteps.tolist()
+        x = torch.randn(1, 16, 2, 4, 4, generator=g)
+        a, b = x, x
+        for tt in sch.timesteps:
+            v = torch.randn(1, 16, 2, 4, 4, generator=g)
+            a = sch.step(v, tt, a, return_dict=False)[0]
+            b = s.step(v, b)
+            assert rel_l2(b, a) < 1e-5
+
+
+@torch.no_grad()
+def test_t5_random_tokens(ns):
+    from oracle import t5_oracle as T
+    from videocof_amd.weights import deterministic_t5_state_dict
+    cfg = dict(vocab=301, dim=192, dim_attn=192, dim_ffn=448, num_heads=3, num_layers=3, num_buckets=32)
+    sd = deterministic_t5_state_dict(**cfg)
+    m = ns.load_text_encoder().WanT5EncoderModel(shared_pos=False, dropout=0.0, **cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, 301, (2, 150), generator=g)          # spans the logarithmic buckets (offsets > 128)
+    mask = torch.ones(2, 150, dtype=torch.long)
+    mask[1, 40:] = 0
+    ref = m(ids, mask)[0]
+    out = T.T5EncoderOracle(sd, 3, 3, 32).forward(ids, mask)
+    assert rel_l2(out, ref) < 1e-5
+
+
+@torch.no_grad()
+def test_vae_random_clip(ns):
+    from oracle.vae_oracle import WanVAEOracle
+    from videocof_amd.weights import deterministic_vae_state_dict
+    sd = deterministic_vae_state_dict()
+    vae = ns.vae.AutoencoderKLWan()
+    vae.load_state_dict(sd, strict=True)
+    vae.eval()
+    g = torch.Generator().manual_seed(5)
+    video = torch.rand(1, 3, 9, 16, 24, generator=g) * 2 - 1
+    orc = WanVAEOracle(sd)
+    ref_mu = vae.encode(video)[0].mode()
+    assert rel_l2(orc.encode(video[0])[:16], ref_mu[0]) < 1e-5
+    z = torch.randn(1, 16, 2, 2, 3, generator=g)
+    assert rel_l2(orc.decode(z[0]), vae.decode(z).sample[0]) < 1e-5
