@@ -96,3 +96,43 @@ def test_vae_random_clip(ns):
     assert rel_l2(orc.encode(video[0])[:16], ref_mu[0]) < 1e-5
     z = torch.randn(1, 16, 2, 2, 3, generator=g)
     assert rel_l2(orc.decode(z[0]), vae.decode(z).sample[0]) < 1e-5
+
+
+@torch.no_grad()
+def test_product_host_code_vs_reference(ns):
+    """The two pieces of product code that run on the host: the UniPC scheduler (CPU tensors take the torch path, CUDA
+    tensors the fused wan_lincomb) and the LoRA merge on state dicts -- against the live reference."""
+    import types
+    from videocof_amd import FlowUniPCMultistepScheduler
+    from videocof_amd.lora_utils import merge_lora_state_dict
+    from videocof_amd.weights import deterministic_dit_state_dict
+    g = torch.Generator().manual_seed(21)
+    ref = ns.unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2, prediction_type="flow_prediction")
+    mine = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)
+    for steps, shift in ((9, 3.0), (25, 5.0)):
+        ref.set_timesteps(steps, device="cpu", shift=shift)
+        mine.set_timesteps(steps, device="cpu", shift=shift)
+        assert torch.equal(mine.timesteps, ref.timesteps) and torch.equal(mine.sigmas, ref.sigmas)
+        a = b = torch.randn(1, 16, 2, 4, 4, generator=g)
+        for tt in ref.timesteps:
+            v = torch.randn(1, 16, 2, 4, 4, generator=g)
+            a = ref.step(v, tt, a, return_dict=False)[0]
+            b = mine.step(v, tt, b, return_dict=False)[0]
+            assert rel_l2(b, a) < 1e-5
+    cfgd = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    sd = deterministic_dit_state_dict(**cfgd)
+    m = ns.transformer.WanTransformer3DModel(model_type="t2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64,
+                                             in_dim=16, out_dim=16, freq_dim=256, cross_attn_norm=True, qk_norm=True)
+    m.load_state_dict(sd, strict=True)
+    lora = {}
+    for name, (o, i) in {"blocks.1.self_attn.v": (256, 256), "blocks.0.ffn.2": (256, 512), "blocks.1.cross_attn.k": (256, 256)}.items():
+        lora[f"diffusion_model.{name}.lora_down.weight"] = torch.randn(8, i, generator=g) * 0.1
+        lora[f"diffusion_model.{name}.lora_up.weight"] = torch.randn(o, 8, generator=g) * 0.1
+        lora[f"diffusion_model.{name}.alpha"] = torch.tensor(4.0)
+    ns.load_lora_utils().merge_lora(types.SimpleNamespace(transformer=m), None, 0.6, device="cpu", dtype=torch.float32,
+                                    state_dict=dict(lora), transformer_only=True)
+    want = m.state_dict()
+    got = {k: v.clone() for k, v in sd.items()}
+    assert merge_lora_state_dict(got, lora, 0.6) == 3
+    for k in want:
+        assert rel_l2(got[k], want[k]) < 1e-6, k
