@@ -58,14 +58,19 @@ def test_argument_errors_map_to_python_exceptions():
 
 def test_attention_tail_plan_is_pure_host_logic():
     """wan_attention_workspace_bytes is host arithmetic (CU count falls back to 256 without a GPU): the shapes
-    DESIGN.md quotes.  bytes = batch * nsplit * heads * rows_tail * (128 + 2) * 4."""
+    DESIGN.md quotes.  bytes = flags (one int per workgroup of the un-split grid, rounded up to 256 B)
+    + batch * nsplit * heads * rows_tail * (128 + 2) * 4 for the split tail round."""
     lib = _lib.load()
     f = lib.wan_attention_workspace_bytes
     L = 67080                                   # 263 query blocks of 256; the last one holds 8 rows
-    assert f(1, L, L, 5, 128) == 1 * 7 * 5 * (L - 256 * 256) * 130 * 4        # 8-way Ulysses shard: 35 tail blocks, 7 splits
-    assert f(1, L, L, 10, 128) == 1 * 3 * 10 * (L - 256 * 256) * 130 * 4      # 4-way shard: 70 tail blocks, 3 splits
-    assert f(1, L, L, 20, 128) == 0                                           # remainder 140 > 128 CUs: plain launch
-    assert f(1, L, L, 40, 128) == 1 * 6 * 40 * 8 * 130 * 4                    # single GPU: the 8-row last block, 6 splits
-    assert f(1, 4096, L, 5, 128) == 0                                         # fits in one round
-    assert f(1, L, 512, 40, 128) == 0                                         # cross-attention: short key range
-    assert f(1, L, L, 5, 64) == 0 and f(0, L, L, 5, 128) == 0                 # unsupported / empty
+
+    def flags(batch, lq, heads):
+        return ((lq + 255) // 256 * heads * batch * 4 + 255) // 256 * 256
+
+    assert f(1, L, L, 5, 128) == flags(1, L, 5) + 1 * 7 * 5 * (L - 256 * 256) * 130 * 4      # 8-way Ulysses shard: 35 tail blocks, 7 splits
+    assert f(1, L, L, 10, 128) == flags(1, L, 10) + 1 * 3 * 10 * (L - 256 * 256) * 130 * 4   # 4-way shard: 70 tail blocks, 3 splits
+    assert f(1, L, L, 20, 128) == flags(1, L, 20)                                            # remainder 140 > 128 CUs: no split
+    assert f(1, L, L, 40, 128) == flags(1, L, 40) + 1 * 6 * 40 * 8 * 130 * 4                 # single GPU: the 8-row last block, 6 splits
+    assert f(1, 4096, L, 5, 128) == flags(1, 4096, 5) == 512                                 # fits in one round
+    assert f(1, L, 512, 40, 128) == flags(1, L, 40)                                          # cross-attention: short key range
+    assert f(1, L, L, 5, 64) == 0 and f(0, L, L, 5, 128) == 0                                # unsupported / empty

@@ -266,13 +266,13 @@ def test_attention_is_bitwise_reproducible():
 @pytest.mark.parametrize("pre", [False, True])
 def test_attention_split_tail_round(pre, monkeypatch):
     """Launches whose workgroup count leaves a small remainder over the CU count run their last query blocks
-    split over the key range + a merge kernel (wan_attention_workspace_bytes > 0).  Same function as the plain
+    split over the key range + a merge kernel (scratch from wan_attention_workspace_bytes).  Same function as the plain
     launch (WAN_ATTN_TAIL=0) and as the oracle, including the ragged last key tile inside the last split."""
     from videocof_amd import _lib
     Lq, Lk, H = 86 * 256 + 10, 1100, 3                  # 87 x 3 = 261 workgroups = 256 + 5
     C = H * 128
-    assert _lib.load().wan_attention_workspace_bytes(1, Lq, Lk, H, 128) > 0
-    assert _lib.load().wan_attention_workspace_bytes(1, 4096, Lk, H, 128) == 0      # fits one round: plain launch
+    assert _lib.load().wan_attention_workspace_bytes(1, Lq, Lk, H, 128) > 4096      # flags + tail partials
+    assert _lib.load().wan_attention_workspace_bytes(1, 4096, Lk, H, 128) == 256    # fits one round: flags only
     g = torch.Generator(device=DEV).manual_seed(8)
     q = torch.randn(1, Lq, C, device=DEV, generator=g).bfloat16()
     k = torch.randn(1, Lk, C, device=DEV, generator=g).bfloat16()
@@ -295,6 +295,70 @@ def test_attention_split_tail_round(pre, monkeypatch):
         assert rel_l2(out[0, rows, h * 128:(h + 1) * 128], ref.cpu()) < 6e-3
     again = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
     assert torch.equal(again, out)
+
+
+def test_attention_max_free_kernel_and_its_fixup(monkeypatch):
+    """Pre-scaled q with scratch memory runs the max-free kernel (p = exp2(S), no running max) and, right behind it, the
+    fix-up launch that recomputes every workgroup whose rows left the checked score window.  (i) ordinary scores: no
+    workgroup is flagged, the result matches the running-max kernel (WAN_ATTN_FAST=0) to bf16 noise and the fp32 oracle;
+    (ii) rows with scores of +-150 (log2 domain): flagged, and those workgroups come out BITWISE equal to the
+    running-max kernel; (iii) scores far below zero for every key of a row: same."""
+    Lq, Lk, H = 600, 1300, 2
+    C = H * 128
+    g = torch.Generator(device=DEV).manual_seed(12)
+    c = ops.q_prescale(128)
+    q = torch.randn(1, Lq, C, device=DEV, generator=g)
+    k = torch.randn(1, Lk, C, device=DEV, generator=g).bfloat16()
+    v = torch.randn(Lk, C, device=DEV, generator=g).bfloat16()
+    vt = ops.transpose_pad(v)[None]
+
+    def run(qf, fast):
+        if not fast:
+            monkeypatch.setenv("WAN_ATTN_FAST", "0")
+        out = ops.attention_fwd((qf * c).bfloat16(), k, vt, H, q_prescaled=True)
+        ws = ops._ATTN_WS[q.device]
+        flags = ws[: 4 * 3 * H].view(torch.int32).clone()           # 3 query blocks x H workgroups
+        monkeypatch.delenv("WAN_ATTN_FAST", raising=False)
+        return out, flags
+
+    fast, flags = run(q, True)
+    assert int(flags.sum()) == 0
+    safe, _ = run(q, False)
+    # two independently bf16-rounded evaluations of one function (different softmax reference point): sqrt(2) x one run's error
+    assert rel_l2(fast, safe.cpu()) < 4.5e-3 and not torch.equal(fast, safe)
+    qe = (q * c).bfloat16().float() / c
+    ref = _attn_ref(qe.view(1, Lq, H, 128).cpu(), k.view(1, Lk, H, 128).cpu(), v.view(1, Lk, H, 128).cpu()).view(1, Lq, C)
+    assert rel_l2(fast, ref) < 6e-3
+    # (ii) a key aligned with the queries of block 1, head 0: log2-domain score 40 * 60 * c ~ +306 -> exp2 overflows
+    u = torch.ones(128, device=DEV) / 128 ** 0.5
+    q2 = q.clone()
+    k2 = k.clone()
+    k2[0, 700, :128] = (60 * u).bfloat16()
+    q2[0, 256:512, :128] = 40 * u + 0.1 * q2[0, 256:512, :128]
+    k_saved, k = k, k2                                             # `run` reads k from this scope
+    fast2, flags2 = run(q2, True)
+    safe2, _ = run(q2, False)
+    assert torch.isfinite(fast2).all()
+    flagged = flags2.view(H, 3).bool()                              # wg = qblk + 3 * head
+    assert bool(flagged[0, 1]) and int(flags2.ne(0).sum()) >= 1
+    for h in range(H):
+        for b in range(3):
+            blk_fast, blk_safe = fast2[0, 256 * b:256 * (b + 1), 128 * h:128 * (h + 1)], safe2[0, 256 * b:256 * (b + 1), 128 * h:128 * (h + 1)]
+            if bool(flagged[h, b]):
+                assert torch.equal(blk_fast, blk_safe), (h, b)
+            else:
+                assert rel_l2(blk_fast, blk_safe.cpu()) < 4.5e-3, (h, b)
+    k = k_saved
+    # (iii) every score of some rows far below the window: l underflows in the max-free kernel -> flagged -> exact
+    q3 = q.clone()
+    kk = k.clone()
+    kk[0, :, 128:] = (torch.ones(Lk, 128, device=DEV) * 4).bfloat16()
+    q3[0, :40, 128:] = -16.0                                                                 # score = -16*4*128*c ~ -1000
+    k = kk
+    fast3, flags3 = run(q3, True)
+    safe3, _ = run(q3, False)
+    assert torch.isfinite(fast3).all() and bool(flags3.view(H, 3)[1, 0])
+    assert torch.equal(fast3[0, :256, 128:], safe3[0, :256, 128:])
 
 
 def test_attention_rejects_unbuilt_options():

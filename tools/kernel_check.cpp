@@ -394,16 +394,17 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         { std::vector<float> hf = bf_to_f(hq); for (auto& x : hf) x *= WAN_ATTN_QSCALE(0.0883883f); auto hs = to_bf(hf);
           for (size_t off = 0; off < qs.n; off += hs.size()) HIP(hipMemcpy(qs.p + off, hs.data(), std::min(hs.size(), qs.n - off) * 2, hipMemcpyHostToDevice)); }
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
-        for (const char* var : {"2", "3n", "3"}) {       // 2 = plain q; 3 = pre-scaled q; 3n = the same without the split tail
+        for (const char* var : {"3s", "3n", "3"}) {       // 3 = pre-scaled q (max-free fast kernel + fix-up); 3s = running-max kernel only; 3n = 3 without the split tail
             if (!attn_only && strcmp(var, "3")) continue;
             setenv("WAN_ATTN_TAIL", !strcmp(var, "3n") ? "0" : "1", 1);
+            setenv("WAN_ATTN_FAST", !strcmp(var, "3s") ? "0" : "1", 1);
             const int64_t wsb = wan_attention_workspace_bytes(1, s.Lq, s.Lk, s.H, 128);
             Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
             double ms = time_ms([&] { WAN(wan_attention_fwd(var[0] == '3' ? qs.p : q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0,
                                                             wsb ? ws.p : nullptr, wsb, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
         }
-        unsetenv("WAN_ATTN_TAIL");
+        unsetenv("WAN_ATTN_TAIL"); unsetenv("WAN_ATTN_FAST");
     }
 }
 

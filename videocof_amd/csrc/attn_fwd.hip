@@ -51,6 +51,7 @@ struct AttnArgs {
     int qblk0, nsplit, tiles_per_split, row0, rows_tail;
     float* ws_o;          // [batch][nsplit][H][rows_tail][128] un-normalised partial outputs
     float* ws_ml;         // [batch][nsplit][H][rows_tail][2]   running max (log2 units), sum
+    int* flags;           // MODE 1 / 2: one word per workgroup of the main launch, != 0 -> recompute with the running max
 };
 
 // VARIANT (template parameter of the kernel below) only names the instantiation so profiles separate the two
@@ -129,8 +130,21 @@ __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
 // wan_rmsnorm_rope's x0_scale).  The running max then rides in the MFMA accumulator: S' = K.Q^T + (-m)
 // starts from a 16-register splat of -m instead of the inline constant 0, so p = exp2(S') needs no
 // per-score fma: 32 fewer VALU per wave and tile (+6..8 % end to end on this VALU-co-limited loop).
-template <int VARIANT, bool PRE, bool SPLIT = false>
+// MODE 0: the kernel as described above.
+// MODE 1 (PRE only): NO running max at all.  softmax is invariant to the reference point and bf16 P / fp32 accumulators
+//         have head-room for log2-domain scores in about [-90, 100], so p = exp2(S) is taken directly: no row max, no
+//         lane exchange, no rescale branch, S chains start from the inline constant 0 (-37 VALU per wave and tile, and a
+//         straight-line loop).  The assumption is CHECKED: a row whose sum leaves [2^-90, 2^100] (or is not finite)
+//         flags its workgroup, and
+// MODE 2: the MODE 0 kernel launched right behind on the same grid, recomputes exactly the flagged workgroups (all
+//         others exit at once).  DiT activations never raise a flag; adversarial inputs cost a second pass, not accuracy.
+template <int VARIANT, bool PRE, bool SPLIT = false, int MODE = 0>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
+    static_assert(MODE == 0 || (PRE && !SPLIT), "fast / fixup modes exist for the pre-scaled, unsplit launch only");
+    const int wg_linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if constexpr (MODE == 2) {
+        if (a.flags[wg_linear] == 0) return;          // workgroup-uniform
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         const char* kb = kring + kslot_next * kKTileBytes;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            if constexpr (!PRE) {
+            if constexpr (!PRE || MODE == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
             }
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * 256 + k_off[ks]);
-                if (PRE && ks == 0) {
+                if (PRE && MODE != 1 && ks == 0) {
                     sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, negm, 0, 0, 0);
                 } else {
                     sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
@@ -333,24 +347,34 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
             s0[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q_frag(ks), s0[kt], 0, 0, 0);
         }
     }
-    float mx_part = rowmax32(s0);
+    float mx_part = MODE == 1 ? 0.f : rowmax32(s0);
     __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
 
     const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
     bf16x8 pf[4];
     int it = 0;
     bool last_in_s1 = false;
+    // one interval: tile t lives in `sc`, S(t+1) is produced into `sn`
+    auto interval = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int kslot_next, int vslot) {
+        float mc = 0.f;
+        if constexpr (MODE != 1) mc = seg_a(mx_part, sc);
+        float ps = 0.f;
+        seg_b(sc, sn, kslot_next, mc, pf, ps);
+        pv(vslot, pf, &sc[1], mc, &ps);
+        l_run += ps;
+        if constexpr (MODE != 1) mx_part = rowmax32(sn);
+    };
     for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
         prefetch(it);
-        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, 1, mc, pf, ps); pv(0, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
+        interval(s0, s1, 1, 0);
         fence();
         prefetch(it + 1);
-        { const float mc = seg_a(mx_part, s1); float ps = 0.f; seg_b(s1, s0, 0, mc, pf, ps); pv(1, pf, &s1[1], mc, &ps); l_run += ps; mx_part = rowmax32(s0); }
+        interval(s1, s0, 0, 1);
         fence();
     }
     if (it < nfull) {
         prefetch(it);
-        { const float mc = seg_a(mx_part, s0); float ps = 0.f; seg_b(s0, s1, 1, mc, pf, ps); pv(0, pf, &s0[1], mc, &ps); l_run += ps; mx_part = rowmax32(s1); }
+        interval(s0, s1, 1, 0);
         fence();
         ++it;
         last_in_s1 = true;
@@ -369,9 +393,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
                     const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
                     if (key >= Lk) sl[kt][r] = -INFINITY;
                 }
-            mx_part = rowmax32(sl);
+            if constexpr (MODE != 1) mx_part = rowmax32(sl);
         }
-        const float mc = seg_a(mx_part, sl);
+        float mc = 0.f;
+        if constexpr (MODE != 1) mc = seg_a(mx_part, sl);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -382,6 +407,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if constexpr (MODE == 1) {
+        // the checked assumption of MODE 1 (NaN fails both comparisons)
+        const bool ok = (l_tot >= 0x1p-90f && l_tot <= 0x1p100f) || qrow >= a.Lq;
+        const int bad = __syncthreads_or(!ok);
+        if (tid == 0) a.flags[wg_linear] = bad;
+    }
     if constexpr (SPLIT) {
         // partial result of this KV range: un-normalised O, its reference max (log2 units) and its sum
         if (qrow < a.Lq) {
@@ -494,9 +525,17 @@ TailPlan plan_tail(int batch, int Lq, int Lk, int num_heads) {
 
 }  // namespace
 
+namespace {
+// scratch layout: [one int per workgroup of the un-split grid, rounded up to 256 B][partials of the split tail round]
+int64_t flag_bytes(int batch, int Lq, int num_heads) {
+    const int64_t wgs = (int64_t)((Lq + kQPerWG - 1) / kQPerWG) * num_heads * batch;
+    return (wgs * (int64_t)sizeof(int) + 255) / 256 * 256;
+}
+}  // namespace
+
 extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim) {
     if (batch <= 0 || Lq <= 0 || Lk <= 0 || num_heads <= 0 || head_dim != kD) return 0;
-    return plan_tail(batch, Lq, Lk, num_heads).ws_bytes;
+    return flag_bytes(batch, Lq, num_heads) + plan_tail(batch, Lq, Lk, num_heads).ws_bytes;
 }
 
 extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
@@ -525,7 +564,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     if (!attr_set) {
         const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>)};
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>),
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 1>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 1>),
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 2>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 2>)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
             if (e != hipSuccess) {
@@ -543,29 +584,49 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
     const bool pre = (flags & WAN_ATTN_Q_PRESCALED) != 0;
     a.scale_log2e = pre ? 1.0f : softmax_scale * 1.4426950408889634f;
-    a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr;
+    a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr; a.flags = nullptr;
     dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     const bool self = Lk > 1024;
+    // With scratch memory: (1) pre-scaled q runs the max-free kernel (MODE 1) followed by the fix-up launch (MODE 2) that
+    // recomputes flagged workgroups only; (2) the last partial round of a long launch is split over the keys (plan_tail).
+    // WAN_ATTN_FAST=0 / WAN_ATTN_TAIL=0 are developer A/B switches.
     TailPlan tp;
+    bool fast = false;
+    char* ws_tail = nullptr;
     if (workspace != nullptr) {
-        tp = plan_tail(batch, Lq, Lk, num_heads);
-        if (tp.tq > 0 && (workspace_bytes < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();
-        WAN_REQUIRE(tp.tq == 0 || ((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
+        WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
+        const int64_t fb = flag_bytes(batch, Lq, num_heads);
+        if (workspace_bytes >= fb) {
+            const char* ef = getenv("WAN_ATTN_FAST");
+            fast = pre && !(ef && atoi(ef) == 0);
+            a.flags = (int*)workspace;
+            ws_tail = (char*)workspace + fb;
+            tp = plan_tail(batch, Lq, Lk, num_heads);
+            if (tp.tq > 0 && (workspace_bytes - fb < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();
+        }
     }
     if (tp.tq > 0) grid.x = (unsigned)tp.main_qb;
-    if (pre) {
+    if (pre && fast) {
+        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 1>), grid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 1>), grid, block, kLdsBytesV2, st, a);
+    } else if (pre) {
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
     } else {
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
     }
+    if (pre && fast) {       // same grid, right behind: workgroups whose rows left the checked score window are redone
+        WAN_CHECK_LAUNCH("wan_attention_fwd");
+        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 2>), grid, block, kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 2>), grid, block, kLdsBytesV2, st, a);
+    }
     if (tp.tq > 0) {
         WAN_CHECK_LAUNCH("wan_attention_fwd");
         a.qblk0 = tp.main_qb; a.nsplit = tp.nsplit; a.tiles_per_split = tp.tiles_per_split;
         a.row0 = tp.main_qb * kQPerWG; a.rows_tail = tp.rows_tail;
-        a.ws_o = (float*)workspace;
+        a.ws_o = (float*)ws_tail;
         a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
         dim3 tgrid((unsigned)tp.tq, (unsigned)num_heads, (unsigned)(batch * tp.nsplit));
         if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
