@@ -137,10 +137,11 @@ wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                int batch, int Lq, int Lk, int num_heads, int head_dim,
                                float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
                                void* stream);
-/* Optional scratch for wan_attention_fwd (16-byte aligned device memory, contents irrelevant, reusable across
- * calls on one stream).  With at least this many bytes (a) pre-scaled q runs a max-free kernel (p = exp2(S) without a
+/* Optional scratch for wan_attention_fwd (16-byte aligned device memory whose first 16 bytes are ZERO when it is first
+ * used -- they carry a sticky switch, see (a) -- and otherwise of irrelevant content; reusable across calls on one stream).  With at least this many bytes (a) pre-scaled q runs a max-free kernel (p = exp2(S) without a
  * running max; rows whose sum leaves a checked window flag their workgroup in the scratch and are recomputed by the
- * running-max kernel launched right behind -- same results, ~2 % faster), and (b) the last, partially filled round of
+ * running-max kernel launched right behind -- same results, ~2 % faster; once more than 1/8 of a launch had to be
+ * recomputed the switch in the scratch turns the attempt off for later calls), and (b) the last, partially filled round of
  * workgroups of a long self-attention launch is split over the key range so that it fills the chip (matters when few
  * heads are local, e.g. the 5 heads per GPU of an 8-way Ulysses shard: +15 %).  workspace = NULL is always valid. */
 int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim);

@@ -37,3 +37,17 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _reset_attention_fast_switch(request):
+    """The attention scratch carries a sticky "fast path off" word that adversarial test inputs set on purpose; clear
+    it before every GPU test so that each one starts with the max-free kernel enabled."""
+    if "gpu" in request.keywords:
+        try:
+            from videocof_amd import ops
+            for ws in ops._ATTN_WS.values():
+                ws[:16].zero_()
+        except Exception:
+            pass
+    yield

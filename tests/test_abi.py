@@ -58,14 +58,14 @@ def test_argument_errors_map_to_python_exceptions():
 
 def test_attention_tail_plan_is_pure_host_logic():
     """wan_attention_workspace_bytes is host arithmetic (CU count falls back to 256 without a GPU): the shapes
-    DESIGN.md quotes.  bytes = flags (one int per workgroup of the un-split grid, rounded up to 256 B)
+    DESIGN.md quotes.  bytes = flags (16-byte header + one int per workgroup of the un-split grid, rounded up to 256 B)
     + batch * nsplit * heads * rows_tail * (128 + 2) * 4 for the split tail round."""
     lib = _lib.load()
     f = lib.wan_attention_workspace_bytes
     L = 67080                                   # 263 query blocks of 256; the last one holds 8 rows
 
     def flags(batch, lq, heads):
-        return ((lq + 255) // 256 * heads * batch * 4 + 255) // 256 * 256
+        return (16 + (lq + 255) // 256 * heads * batch * 4 + 255) // 256 * 256
 
     assert f(1, L, L, 5, 128) == flags(1, L, 5) + 1 * 7 * 5 * (L - 256 * 256) * 130 * 4      # 8-way Ulysses shard: 35 tail blocks, 7 splits
     assert f(1, L, L, 10, 128) == flags(1, L, 10) + 1 * 3 * 10 * (L - 256 * 256) * 130 * 4   # 4-way shard: 70 tail blocks, 3 splits

@@ -132,7 +132,7 @@ def test_attention_split_tail_random_shapes():
         Lk = rnd.choice([1025, 1100, 1664, 2500, 4096])
         pre = rnd.random() < 0.5
         C = H * 128
-        flag_bytes = ((Lq + 255) // 256 * H * B * 4 + 255) // 256 * 256
+        flag_bytes = (16 + (Lq + 255) // 256 * H * B * 4 + 255) // 256 * 256
         split_seen += int(_lib.load().wan_attention_workspace_bytes(B, Lq, Lk, H, 128) > flag_bytes)
         q = torch.randn(B, Lq, C, device=DEV, generator=g).bfloat16()
         k = torch.randn(B, Lk, C, device=DEV, generator=g).bfloat16()

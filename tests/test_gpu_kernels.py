@@ -317,7 +317,10 @@ def test_attention_max_free_kernel_and_its_fixup(monkeypatch):
             monkeypatch.setenv("WAN_ATTN_FAST", "0")
         out = ops.attention_fwd((qf * c).bfloat16(), k, vt, H, q_prescaled=True)
         ws = ops._ATTN_WS[q.device]
-        flags = ws[: 4 * 3 * H].view(torch.int32).clone()           # 3 query blocks x H workgroups
+        hdr = ws[:16].view(torch.int32).clone()                     # [sticky switch, workgroups redone, -, -]
+        flags = ws[16: 16 + 4 * 3 * H].view(torch.int32).clone()    # 3 query blocks x H workgroups
+        ws[:4].zero_()                                              # a test must not switch the fast path off for the next one
+        run.hdr = hdr
         monkeypatch.delenv("WAN_ATTN_FAST", raising=False)
         return out, flags
 
@@ -359,6 +362,17 @@ def test_attention_max_free_kernel_and_its_fixup(monkeypatch):
     safe3, _ = run(q3, False)
     assert torch.isfinite(fast3).all() and bool(flags3.view(H, 3)[1, 0])
     assert torch.equal(fast3[0, :256, 128:], safe3[0, :256, 128:])
+    # (iv) the sticky switch: 1 of 6 workgroups redone (> 1/8) turns the attempt off for later calls on this scratch;
+    #      they then run the running-max kernel for every workgroup
+    ws = ops._ATTN_WS[q.device]
+    assert int(ws[:4].view(torch.int32)) == 0
+    out_a = ops.attention_fwd((q3 * c).bfloat16(), k, vt, H, q_prescaled=True)
+    assert ws[:8].view(torch.int32).tolist() == [1, 1] and torch.equal(out_a, fast3)   # this call itself was still fast
+    k = k_saved
+    out_b = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True)       # harmless input, switch still on
+    assert ws[:8].view(torch.int32).tolist() == [1, 6] and torch.equal(out_b, safe)
+    ws[:16].zero_()
+    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True), fast)
 
 
 def test_attention_rejects_unbuilt_options():

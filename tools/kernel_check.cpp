@@ -289,7 +289,7 @@ static void check_attn() {
             for (auto& x : q) x /= cc;
         }
         const int64_t wsb = wan_attention_workspace_bytes(1, Lq, Lk, H, 128);
-        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();      // the header of the scratch must start as zero
         WAN(wan_attention_fwd(dq.p, C, 0, dk.p, C, 0, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, scale, pre ? WAN_ATTN_Q_PRESCALED : 0,
                               wsb ? ws.p : nullptr, wsb, nullptr));
         if (wsb) printf("  (tail split active: workspace %lld B)\n", (long long)wsb);
@@ -399,7 +399,7 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
             setenv("WAN_ATTN_TAIL", !strcmp(var, "3n") ? "0" : "1", 1);
             setenv("WAN_ATTN_FAST", !strcmp(var, "3s") ? "0" : "1", 1);
             const int64_t wsb = wan_attention_workspace_bytes(1, s.Lq, s.Lk, s.H, 128);
-            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();      // the header of the scratch must start as zero
             double ms = time_ms([&] { WAN(wan_attention_fwd(var[0] == '3' ? qs.p : q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0,
                                                             wsb ? ws.p : nullptr, wsb, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
@@ -426,7 +426,7 @@ int main(int argc, char** argv) {
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(q); fill(k); fill(vt);
         const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
-        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();      // the header of the scratch must start as zero
         for (int i = 0; i < 3; ++i)
             WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr));
         HIP(hipDeviceSynchronize());

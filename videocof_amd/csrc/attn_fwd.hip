@@ -142,8 +142,22 @@ template <int VARIANT, bool PRE, bool SPLIT = false, int MODE = 0>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     static_assert(MODE == 0 || (PRE && !SPLIT), "fast / fixup modes exist for the pre-scaled, unsplit launch only");
     const int wg_linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    // scratch header (the 4 ints in front of the flags): [0] sticky "fast path off", [1] workgroups redone by this call
+    int* const hdr = (MODE != 0) ? a.flags - 4 : nullptr;
     if constexpr (MODE == 2) {
         if (a.flags[wg_linear] == 0) return;          // workgroup-uniform
+        if (threadIdx.x == 0) {
+            // if more than 1/8 of a launch had to be redone, later calls on this scratch skip the max-free attempt
+            const int redone = atomicAdd(&hdr[1], 1) + 1;
+            if (redone * 8 > (int)(gridDim.x * gridDim.y * gridDim.z)) hdr[0] = 1;
+        }
+    }
+    if constexpr (MODE == 1) {
+        if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;     // the fix-up launch of this call starts counting at 0
+        if (hdr[0] != 0) {                                       // workgroup-uniform: hand everything to the fix-up launch
+            if (threadIdx.x == 0) a.flags[wg_linear] = 1;
+            return;
+        }
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -526,10 +540,11 @@ TailPlan plan_tail(int batch, int Lq, int Lk, int num_heads) {
 }  // namespace
 
 namespace {
-// scratch layout: [one int per workgroup of the un-split grid, rounded up to 256 B][partials of the split tail round]
+// scratch layout: [16-byte header + one int per workgroup of the un-split grid, rounded up to 256 B][partials of the
+// split tail round].  The header must be zero when the scratch is first used (it carries the sticky switch).
 int64_t flag_bytes(int batch, int Lq, int num_heads) {
     const int64_t wgs = (int64_t)((Lq + kQPerWG - 1) / kQPerWG) * num_heads * batch;
-    return (wgs * (int64_t)sizeof(int) + 255) / 256 * 256;
+    return (16 + wgs * (int64_t)sizeof(int) + 255) / 256 * 256;      // 16-byte header + one int per workgroup
 }
 }  // namespace
 
@@ -600,7 +615,7 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         if (workspace_bytes >= fb) {
             const char* ef = getenv("WAN_ATTN_FAST");
             fast = pre && !(ef && atoi(ef) == 0);
-            a.flags = (int*)workspace;
+            a.flags = (int*)workspace + 4;
             ws_tail = (char*)workspace + fb;
             tp = plan_tail(batch, Lq, Lk, num_heads);
             if (tp.tq > 0 && (workspace_bytes - fb < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();

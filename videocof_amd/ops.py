@@ -179,7 +179,7 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
     if ws_bytes > 0:        # scratch for the split tail round; one growing buffer per device, reused stream-ordered
         ws = _ATTN_WS.get(q.device)
         if ws is None or ws.numel() < ws_bytes:
-            ws = _ATTN_WS[q.device] = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8)
+            ws = _ATTN_WS[q.device] = torch.zeros(ws_bytes, device=q.device, dtype=torch.uint8)    # zeroed header
     _lib.check(lib.wan_attention_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
                                      _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
                                      B, Lq, Lk, num_heads, head_dim, float(scale),
