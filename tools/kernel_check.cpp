@@ -424,7 +424,9 @@ int main(int argc, char** argv) {
         auto hq = to_bf(randn((size_t)4096 * 128));
         Dev<bf16> q((size_t)L * C), k((size_t)L * C), vt((size_t)C * ldvt), o((size_t)L * C);
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
-        fill(q); fill(k); fill(vt);
+        fill(k); fill(vt);
+        { std::vector<float> hf = bf_to_f(hq); for (auto& x : hf) x *= WAN_ATTN_QSCALE(0.0883883f); hq = to_bf(hf); }
+        fill(q);                                // q * softmax_scale * log2(e), as wan_rmsnorm_rope(x0_scale) hands it over
         const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
         Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();      // the header of the scratch must start as zero
         for (int i = 0; i < 3; ++i)
