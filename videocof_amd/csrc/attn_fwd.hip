@@ -232,7 +232,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     const int v_rowoff = l31 * 128, v_sw = (l31 >> 1) & 7;
     int v_off[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v_off[t] = v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
+    // the V ring's base (32 KiB) sits in the per-lane offset so that every ds_read immediate stays below 32 KiB
+    for (int t = 0; t < 4; ++t) v_off[t] = 2 * kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
 
     f32x16 o_acc[4];
 #pragma unroll
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     // Ring slots are passed as literals from the 2x-unrolled loop (tile parity is known there), so every ds_read
     // address is a loop-invariant VGPR + immediate offset.
     auto pv = [&](int vslot, bf16x8 (&pf)[4], const f32x16* sc_late, float mc, float* psum_late) {
-        const char* vb = vring + vslot * kVTileBytes;
+        const char* vb = smem + vslot * kVTileBytes;        // + v_off (which includes the ring base)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
