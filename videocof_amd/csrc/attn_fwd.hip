@@ -93,6 +93,8 @@ struct AttnArgs {
 // into the accumulator every tile (16 v_mov_b64 per tile): removes the copies, runs 2.7 % SLOWER (79.0 vs 76.9 ms).
 // (i) the row sum kept as a packed pair and accumulated with v_pk_add_f32: within noise (74.4 / 76.2 vs 75.3 ms).
 // (j) static s_setprio 1 for waves 4..7 (or 0..3): 73.1-73.8 vs 73.7-73.9 ms, noise.
+// (l) row sum of the packed bf16 P with v_dot2c_f32_bf16 (16 instead of 32 VALU): ~1 % faster but WRONG results (errors of
+// 10 %..100x in the harness; the instruction does not accumulate like two IEEE fmas for these operand ranges) -- not used.
 // (k) "zero mode": keep the softmax reference at 0 while all scores of the wave stay inside +-2^60 (always, for DiT
 // activations), start the S chains from the inline constant 0 and drop the 16 v_mov_b64 copies of -m per tile; the
 // wave-uniform branch around the two chain-start MFMAs costs more than the copies: 78.3 vs 74.2-75.8 ms.
