@@ -11,6 +11,12 @@ against fixtures under ``tests/golden/`` that were produced by importing the
 reference itself in the build container (``oracle/gen_golden.py``), and -- when
 the reference tree is present -- live in ``tests/test_oracle_vs_reference.py``.
 
+The functions are device-agnostic torch: the parity tests run them on the CPU; the
+full-size checks (L = 67 080 tokens at 14B width, ``tests/test_gpu_fullsize.py``)
+evaluate the SAME functions in fp32/fp64 on the GPU through torch's own kernels --
+still independent of ``libwan_hip.so`` -- after checking on a small case that the
+on-device evaluation reproduces the CPU one.
+
 All ``file:line`` citations are relative to ``/root/reference``.
 State-dict key names are the reference's ``nn.Module`` parameter names.
 """
@@ -62,7 +68,7 @@ def sinusoidal_embedding_1d(dim: int, position: Tensor) -> Tensor:
     half = dim // 2
     pos = position.to(torch.float64)
     inv = torch.pow(torch.tensor(10000.0, dtype=torch.float64),
-                    -torch.arange(half, dtype=torch.float64) / half)
+                    -torch.arange(half, dtype=torch.float64) / half).to(pos.device)
     ang = pos[:, None] * inv[None, :]
     return torch.cat([ang.cos(), ang.sin()], dim=1)  # fp64; caller casts (.float())
 
@@ -131,8 +137,10 @@ def rope_apply(x: Tensor, grid: Tuple[int, int, int], angles: Tensor,
     c = d // 2
     ct, ch, cw = rope_axis_dims(d)
     seq = f * h * w
-    pos_t = torch.tensor(temporal_positions(f, frame_split, ground), dtype=torch.long)
-    tok = torch.arange(token_offset, token_offset + L)
+    dev = x.device           # the restatement is plain torch: it runs wherever its inputs live (CPU in the parity tests;
+    angles = angles.to(dev)  # the full-size checks evaluate the same code in fp32/fp64 on the GPU through torch)
+    pos_t = torch.tensor(temporal_positions(f, frame_split, ground), dtype=torch.long, device=dev)
+    tok = torch.arange(token_offset, token_offset + L, device=dev)
     valid = tok < seq
     tokc = tok.clamp(max=seq - 1)
     fi = tokc // (h * w)
@@ -184,15 +192,23 @@ def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
 # ----------------------------------------------------------------------------
 # a9: attention                          attention_utils.py:152-211 (SDPA branch)
 # ----------------------------------------------------------------------------
+_MAX_SCORES = 1 << 29          # score elements materialised at once (2 GiB fp32)
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, k_len: Optional[int] = None) -> Tensor:
     """q [Lq,N,D], k,v [Lk,N,D] -> [Lq,N,D]; softmax(q k^T / sqrt(D)) v, non-causal.
     ``k_len`` trims keys like the flash-attn branch (attention_utils.py:95-100)."""
     if k_len is not None:
         k, v = k[:k_len], v[:k_len]
     d = q.shape[-1]
-    s = torch.einsum("qnd,knd->nqk", q, k) * (1.0 / math.sqrt(d))
-    p = torch.softmax(s, dim=-1)
-    return torch.einsum("nqk,knd->qnd", p, v)
+    lq, n, lk = q.shape[0], q.shape[1], k.shape[0]
+    step = max(1, min(lq, _MAX_SCORES // max(1, n * lk)))      # query rows per slab; softmax is per row, so slabs are exact
+    outs = []
+    for r in range(0, lq, step):
+        s = torch.einsum("qnd,knd->nqk", q[r:r + step], k) * (1.0 / math.sqrt(d))
+        p = torch.softmax(s, dim=-1)
+        outs.append(torch.einsum("nqk,knd->qnd", p, v))
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 # ----------------------------------------------------------------------------

@@ -47,7 +47,9 @@ def _reset_attention_fast_switch(request):
         try:
             from videocof_amd import ops
             for ws in ops._ATTN_WS.values():
-                ws[:16].zero_()
+                ws.reset()
+            for key, default in (("attn_tail", 1), ("attn_fast", 1)):
+                ops.set_tuning(key, default)
         except Exception:
             pass
     yield

@@ -20,7 +20,7 @@ def header_symbols():
 def test_library_present_and_loads():
     assert os.path.isfile(_lib.LIB_PATH), "run `make` / __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.wan_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.wan_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_every_header_symbol_is_exported_and_bound():
@@ -74,3 +74,30 @@ def test_attention_tail_plan_is_pure_host_logic():
     assert f(1, 4096, L, 5, 128) == flags(1, 4096, 5) == 512                                 # fits in one round
     assert f(1, L, 512, 40, 128) == flags(1, L, 40)                                          # cross-attention: short key range
     assert f(1, L, L, 5, 64) == 0 and f(0, L, L, 5, 128) == 0                                # unsupported / empty
+
+
+def test_tuning_switches_are_read_once_and_settable():
+    """Developer switches: environment consulted once at first use, then wan_set_tuning / wan_get_tuning only
+    (the launch paths never call getenv)."""
+    lib = _lib.load()
+    for key, default in (("attn_tail", 1), ("attn_fast", 1), ("attn_xcd_map", 1), ("gemm_gm", 0), ("gemm_phases", 0),
+                         ("gemm_variant", 0), ("conv_xcd", 1), ("debug_checks", 0), ("attn_exp", 0)):
+        assert lib.wan_get_tuning(key.encode()) == default, key
+    assert lib.wan_set_tuning(b"attn_tail", 0) == _lib.WAN_OK and lib.wan_get_tuning(b"attn_tail") == 0
+    os.environ["WAN_ATTN_TAIL"] = "7"                    # too late: not consulted again
+    assert lib.wan_get_tuning(b"attn_tail") == 0
+    del os.environ["WAN_ATTN_TAIL"]
+    assert lib.wan_set_tuning(b"attn_tail", 1) == _lib.WAN_OK
+    assert lib.wan_get_tuning(b"no_such_key") == -1
+    st = lib.wan_set_tuning(b"no_such_key", 1)
+    assert st == _lib.WAN_ERR_INVALID
+    with pytest.raises(ValueError, match="unknown key"):
+        _lib.check(st, "wan_set_tuning")
+    # the tail plan follows the switch (host arithmetic, no GPU needed)
+    L = 67080
+    with_tail = lib.wan_attention_workspace_bytes(1, L, L, 5, 128)
+    lib.wan_set_tuning(b"attn_tail", 0)
+    try:
+        assert lib.wan_attention_workspace_bytes(1, L, L, 5, 128) < with_tail
+    finally:
+        lib.wan_set_tuning(b"attn_tail", 1)

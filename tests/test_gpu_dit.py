@@ -107,6 +107,53 @@ def test_context_cache_is_parity_neutral(model):
     assert not torch.equal(a, c)
 
 
+def test_context_cache_never_outlives_its_prompt(model):
+    """The hoisted text K/V are keyed by tensor identity and the entry keeps the prompt alive: a second prompt that the
+    caching allocator places at the freed address of the first (same shape, _version 0) must not be served from it."""
+    lat = det_uniform("cc2.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    t = torch.tensor([500], device=DEV)
+    p1, p2 = det_uniform("cc2.p1", (9, 64), 1.0), det_uniform("cc2.p2", (9, 64), 1.0)
+    want2 = model(lat, t, [p2.to(DEV)], 48)
+    model.cache_context = True
+    try:
+        c1 = p1.to(DEV)
+        a = model(lat, t, [c1], 48)
+        ptr = c1.data_ptr()
+        del c1
+        c2 = torch.empty(9, 64, device=DEV)              # would reuse the block of c1 if the cache did not hold it
+        c2.copy_(p2)
+        got2 = model(lat, t, [c2], 48)
+        assert model._ctx_cache[0][0] is c2 and c2.data_ptr() != ptr
+    finally:
+        model.cache_context = False
+        model.clear_context_cache()
+    assert torch.equal(got2, want2) and not torch.equal(a, want2)
+
+
+def test_pipeline_clears_the_context_cache(golden, model):
+    g = golden("dit_g8_cof_loop")
+    pipe = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    kw = dict(latents=lat, source_frames=9, reasoning_frames=4, num_inference_steps=2, guidance_scale=1.0, shift=3,
+              repeat_rope=True, cot=True, output_type="latent", weight_dtype=torch.float32)
+    ctx_a = torch.from_numpy(g["ctx"]).to(DEV)
+    a = pipe(prompt_embeds=[ctx_a], **kw).latents
+    assert model._ctx_cache is None and model.cache_context is False
+    ctx_b = (ctx_a * 0.5).contiguous()
+    b = pipe(prompt_embeds=[ctx_b], **kw).latents
+    model.cache_context = False
+    b_ref = pipe(prompt_embeds=[ctx_b], cache_context=False, **kw).latents
+    assert torch.equal(b, b_ref) and not torch.equal(a, b)
+
+
+def test_g7_sched50_on_device(golden):
+    g50 = golden("dit_g7_sched50")
+    s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)
+    s.set_timesteps(50, device=DEV, shift=5.0)
+    assert s.timesteps.is_cuda and s.timesteps.cpu().tolist() == g50["timesteps"].tolist()
+    np.testing.assert_array_equal(s.sigmas.numpy(), g50["sigmas"])
+
+
 def test_g8_cof_denoise_loop(golden, model):
     g = golden("dit_g8_cof_loop")
     pipe = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))

@@ -118,8 +118,7 @@ def test_beyond_2gib_indexing():
 def test_attention_split_tail_random_shapes():
     """Shapes whose workgroup count leaves a remainder over the CU count: whatever the launcher decides (plain
     launch or main launch + split tail + merge), the result equals an fp32 evaluation on sampled query rows and
-    agrees with the plain launch (WAN_ATTN_TAIL=0) to bf16 noise."""
-    import os
+    agrees with the plain launch (tuning attn_tail = 0) to bf16 noise."""
     from videocof_amd import _lib
     rnd = random.Random(5)
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -140,11 +139,11 @@ def test_attention_split_tail_random_shapes():
         vt = torch.stack([ops.transpose_pad(v[b]) for b in range(B)])
         qq = (q.float() * ops.q_prescale(128)).bfloat16() if pre else q
         out = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
-        os.environ["WAN_ATTN_TAIL"] = "0"
+        ops.set_tuning("attn_tail", 0)
         try:
             plain = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
         finally:
-            del os.environ["WAN_ATTN_TAIL"]
+            ops.set_tuning("attn_tail", 1)
         assert rel_l2(out.float(), plain.float()) < 3e-3, (B, H, Lq, Lk, pre)
         rows = torch.cat([torch.arange(0, 16), torch.arange(Lq - 700, Lq, 7)]).to(DEV)
         qe = (qq[:, rows].float() / ops.q_prescale(128)) if pre else q[:, rows].float()

@@ -109,6 +109,39 @@ def test_rope_token_offset_is_a_slice_of_the_full_map(rope_dev):
         assert torch.equal(part, full[r * Ll:(r + 1) * Ll])
 
 
+@pytest.mark.parametrize("mode,key,fs,gr", [(0, "default", None, None), (2, "cof", 3, (3, 4))])
+def test_g3_rope_fixture_direct(golden, rope_dev, mode, key, fs, gr):
+    """The reference-captured rope_apply output itself (not the oracle): RoPE is linear in the row and WanRMSNorm with a
+    unit gain scales the row by 1/rms, so kernel(x, w = 1) == fixture(x) / rms(x)."""
+    g = golden("dit_g3_rope")
+    x = torch.from_numpy(g["x"])[0].reshape(116, 256)
+    xb = bf(x)
+    q = xb.to(DEV).clone()
+    ops.rmsnorm_rope_(q, torch.ones(256, device=DEV), None, None, 128, 1e-6, rope_dev,
+                      RopeParams(7, 4, 4, mode, fs or 0, gr[1] if gr else 0, 0, 116, 1024))
+    rms = torch.sqrt(xb.float().pow(2).mean(dim=1, keepdim=True) + 1e-6)
+    ref = torch.from_numpy(g[key])[0].reshape(116, 256).float() / rms
+    assert rel_l2(q, ref) < 5e-3          # x itself is bf16-rounded on the way in (2^-9) + the bf16 output rounding
+
+
+def test_g11_sp_rope_fixture(golden, rope_dev):
+    """The reference's sequence-parallel rope_apply (dist/wan_xfuser.py:22-63), captured with rank r of 2: the kernel with
+    token_offset = r * L/2 on the local rows must reproduce it (same 1/rms argument as above)."""
+    g = golden("dit_g11_sp_rope")
+    x = torch.from_numpy(g["x"])[0].reshape(56, 256)
+    xb = bf(x)
+    rms = torch.sqrt(xb.float().pow(2).mean(dim=1, keepdim=True) + 1e-6)
+    outs = []
+    for r in range(2):
+        q = xb.to(DEV).clone()
+        ops.rmsnorm_rope_(q, torch.ones(256, device=DEV), None, None, 128, 1e-6, rope_dev,
+                          RopeParams(7, 4, 4, 0, 0, 0, r * 56, 56, 1024))
+        ref = torch.from_numpy(g[f"rank{r}"])[0].reshape(56, 256).float() / rms
+        assert rel_l2(q, ref) < 5e-3, r
+        outs.append(q)
+    assert not torch.equal(outs[0], outs[1])       # the two shards really sit at different positions
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1, 128, 64), (515, 64, 1024), (129, 1536, 192)])
 def test_gemm_epilogues_vs_oracle(M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
@@ -264,10 +297,10 @@ def test_attention_is_bitwise_reproducible():
 
 
 @pytest.mark.parametrize("pre", [False, True])
-def test_attention_split_tail_round(pre, monkeypatch):
+def test_attention_split_tail_round(pre):
     """Launches whose workgroup count leaves a small remainder over the CU count run their last query blocks
     split over the key range + a merge kernel (scratch from wan_attention_workspace_bytes).  Same function as the plain
-    launch (WAN_ATTN_TAIL=0) and as the oracle, including the ragged last key tile inside the last split."""
+    launch (tuning attn_tail = 0) and as the oracle, including the ragged last key tile inside the last split."""
     from videocof_amd import _lib
     Lq, Lk, H = 86 * 256 + 10, 1100, 3                  # 87 x 3 = 261 workgroups = 256 + 5
     C = H * 128
@@ -281,9 +314,11 @@ def test_attention_split_tail_round(pre, monkeypatch):
     vt = ops.transpose_pad(v)[None]
     qq = (q.float() * ops.q_prescale(128)).bfloat16() if pre else q
     out = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
-    monkeypatch.setenv("WAN_ATTN_TAIL", "0")
-    plain = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
-    monkeypatch.delenv("WAN_ATTN_TAIL")
+    ops.set_tuning("attn_tail", 0)
+    try:
+        plain = ops.attention_fwd(qq, k, vt, H, q_prescaled=pre)
+    finally:
+        ops.set_tuning("attn_tail", 1)
     assert torch.equal(out[:, :85 * 256], plain[:, :85 * 256])       # main launch untouched
     assert not torch.equal(out[:, 85 * 256:], plain[:, 85 * 256:])   # tail rows really took the other path
     assert rel_l2(out[:, 85 * 256:], plain[:, 85 * 256:].cpu()) < 3e-3
@@ -297,10 +332,10 @@ def test_attention_split_tail_round(pre, monkeypatch):
     assert torch.equal(again, out)
 
 
-def test_attention_max_free_kernel_and_its_fixup(monkeypatch):
+def test_attention_max_free_kernel_and_its_fixup():
     """Pre-scaled q with scratch memory runs the max-free kernel (p = exp2(S), no running max) and, right behind it, the
     fix-up launch that recomputes every workgroup whose rows left the checked score window.  (i) ordinary scores: no
-    workgroup is flagged, the result matches the running-max kernel (WAN_ATTN_FAST=0) to bf16 noise and the fp32 oracle;
+    workgroup is flagged, the result matches the running-max kernel (tuning attn_fast = 0) to bf16 noise and the fp32 oracle;
     (ii) rows with scores of +-150 (log2 domain): flagged, and those workgroups come out BITWISE equal to the
     running-max kernel; (iii) scores far below zero for every key of a row: same."""
     Lq, Lk, H = 600, 1300, 2
@@ -312,16 +347,19 @@ def test_attention_max_free_kernel_and_its_fixup(monkeypatch):
     v = torch.randn(Lk, C, device=DEV, generator=g).bfloat16()
     vt = ops.transpose_pad(v)[None]
 
+    site = ops.AttentionWorkspace()        # this call site's scratch (flags + sticky word)
+
     def run(qf, fast):
-        if not fast:
-            monkeypatch.setenv("WAN_ATTN_FAST", "0")
-        out = ops.attention_fwd((qf * c).bfloat16(), k, vt, H, q_prescaled=True)
-        ws = ops._ATTN_WS[q.device]
+        ops.set_tuning("attn_fast", 1 if fast else 0)
+        try:
+            out = ops.attention_fwd((qf * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)
+        finally:
+            ops.set_tuning("attn_fast", 1)
+        ws = site.buf
         hdr = ws[:16].view(torch.int32).clone()                     # [sticky switch, workgroups redone, -, -]
         flags = ws[16: 16 + 4 * 3 * H].view(torch.int32).clone()    # 3 query blocks x H workgroups
         ws[:4].zero_()                                              # a test must not switch the fast path off for the next one
         run.hdr = hdr
-        monkeypatch.delenv("WAN_ATTN_FAST", raising=False)
         return out, flags
 
     fast, flags = run(q, True)
@@ -364,15 +402,19 @@ def test_attention_max_free_kernel_and_its_fixup(monkeypatch):
     assert torch.equal(fast3[0, :256, 128:], safe3[0, :256, 128:])
     # (iv) the sticky switch: 1 of 6 workgroups redone (> 1/8) turns the attempt off for later calls on this scratch;
     #      they then run the running-max kernel for every workgroup
-    ws = ops._ATTN_WS[q.device]
+    ws = site.buf
     assert int(ws[:4].view(torch.int32)) == 0
-    out_a = ops.attention_fwd((q3 * c).bfloat16(), k, vt, H, q_prescaled=True)
+    out_a = ops.attention_fwd((q3 * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)
     assert ws[:8].view(torch.int32).tolist() == [1, 1] and torch.equal(out_a, fast3)   # this call itself was still fast
     k = k_saved
-    out_b = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True)       # harmless input, switch still on
+    out_b = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)   # harmless input, switch still on
     assert ws[:8].view(torch.int32).tolist() == [1, 6] and torch.equal(out_b, safe)
-    ws[:16].zero_()
-    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True), fast)
+    # (v) the switch belongs to the call site: another site (another layer type, another model) still runs the fast kernel
+    other = ops.AttentionWorkspace()
+    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=other), fast)
+    assert other.buf[:8].view(torch.int32).tolist() == [0, 0]
+    site.reset()
+    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site), fast)
 
 
 def test_attention_rejects_unbuilt_options():

@@ -32,10 +32,19 @@ def from_cl(y):        # [T,H,W,C] -> [C,T,H,W] fp32 cpu
 
 
 @pytest.fixture(scope="module")
-def vae():
+def vae_sd():
+    return deterministic_vae_state_dict()
+
+
+@pytest.fixture(scope="module")
+def vae(vae_sd):
     m = AutoencoderKLWan()
-    m.load_state_dict(deterministic_vae_state_dict(), device=DEV)
+    m.load_state_dict(vae_sd, device=DEV)
     return m
+
+
+def rel_l2_dev(a, b):          # on the device: the full-resolution tensors are 1e8 elements
+    return float((a.double() - b.double()).norm() / b.double().norm())
 
 
 def test_g9_causal_conv_streaming(golden, vae):
@@ -140,3 +149,70 @@ def test_vae_rejects_cpu_and_bad_sizes(vae):
         vae.encode(torch.zeros(1, 3, 1, 8, 8))
     with pytest.raises(ValueError, match="divisible by 8"):
         vae.encode(torch.zeros(1, 3, 1, 12, 8, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------
+# Full resolution (81f@480p decode / encode shapes): every stage's 3x3x3 conv, the 3-channel head conv, the fused
+# nearest-2x resample conv, the stride-2 down-sampling conv and the encoder's 3-channel input conv, each on a
+# 480x832-derived frame size with a random 2-frame history, against torch's fp32 conv3d / conv2d on the same
+# bf16-rounded inputs and weights (MIOpen / torch kernels: independent of libwan_hip.so).  These are the shapes that
+# take the 1.6 M-pixel tiles, the XCD slab remap and the NT = 1 head path, which the 32x48 fixtures never reach.
+# Tolerance: bf16 output rounding + accumulation order only -> rel-L2 <= 4e-3.
+# ------------------------------------------------------------------------------------------------
+FULLRES = [  # (conv, T, H, W)
+    ("decoder.upsamples.0.residual.2", 1, 60, 104),      # 384 -> 384
+    ("decoder.upsamples.5.residual.2", 2, 120, 208),     # 384 -> 384
+    ("decoder.upsamples.8.residual.2", 2, 240, 416),     # 192 -> 192
+    ("decoder.upsamples.12.residual.2", 2, 480, 832),    # 96 -> 96
+    ("decoder.head.2", 4, 480, 832),                     # 96 -> 3
+    ("encoder.conv1", 4, 480, 832),                      # 3 (padded to 8) -> 96
+]
+
+
+def _ref_weight(vae_sd, name):
+    w = vae_sd["model." + name + ".weight"].float().bfloat16().float().to(DEV)
+    return (w[:, :, None] if w.dim() == 4 else w), vae_sd["model." + name + ".bias"].float().to(DEV)
+
+
+@pytest.mark.parametrize("name,T,H,W", FULLRES)
+def test_full_resolution_causal_conv_vs_torch_fp32(vae, vae_sd, name, T, H, W):
+    sd = vae_sd
+    w, b = _ref_weight(sd, name)
+    cin = w.shape[1]
+    c = vae._c[name]
+    g = torch.Generator(device=DEV).manual_seed(H + T)
+    x = torch.zeros(T + 2, H, W, c.cin, device=DEV, dtype=torch.bfloat16)        # 2 history frames + T new ones
+    x[..., :cin] = torch.randn(T + 2, H, W, cin, device=DEV, generator=g).bfloat16()
+    vae.clear_cache()
+    vae._hist[name] = x[:2].contiguous()
+    out = vae._causal(x[2:].contiguous(), name)                                  # [T, H, W, cout_padded]
+    vae.clear_cache()
+    xin = x[..., :cin].float().permute(3, 0, 1, 2)[None]                         # [1, Cin, T+2, H, W]
+    ref = torch.nn.functional.conv3d(xin, w, b, padding=(0, 1, 1))[0].permute(1, 2, 3, 0)     # [T, H, W, Cout]
+    got = out[..., :w.shape[0]].float()
+    assert got.shape == ref.shape
+    assert rel_l2_dev(got, ref) < 4e-3, name
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-2
+
+
+def test_full_resolution_resample_convs_vs_torch_fp32(vae, vae_sd):
+    sd = vae_sd
+    g = torch.Generator(device=DEV).manual_seed(77)
+    # nearest-exact 2x upsample fused into the gather of the Conv2d (wan_vae.py:61-67, 84-88): 240x416 -> 480x832, 192 -> 96
+    name = "decoder.upsamples.11.resample.1"
+    w, b = _ref_weight(sd, name)
+    x = torch.randn(2, 240, 416, 192, device=DEV, generator=g).bfloat16()
+    vae.clear_cache()
+    out = vae._resample(x, "decoder.upsamples.11", "upsample2d")
+    up = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest-exact")
+    ref = torch.nn.functional.conv2d(up, w[:, :, 0], b, padding=1).permute(0, 2, 3, 1)
+    assert rel_l2_dev(out[..., :96].float(), ref) < 4e-3
+    # ZeroPad2d((0,1,0,1)) + stride-2 Conv2d (wan_vae.py:93-96): 480x832 -> 240x416, 96 -> 96
+    name = "encoder.downsamples.2.resample.1"
+    w, b = _ref_weight(sd, name)
+    x = torch.randn(2, 480, 832, 96, device=DEV, generator=g).bfloat16()
+    vae.clear_cache()
+    out = vae._resample(x, "encoder.downsamples.2", "downsample2d")
+    xp = torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1))
+    ref = torch.nn.functional.conv2d(xp, w[:, :, 0], b, stride=2).permute(0, 2, 3, 1)
+    assert out.shape[:3] == ref.shape[:3] and rel_l2_dev(out[..., :96].float(), ref) < 4e-3

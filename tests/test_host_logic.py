@@ -173,3 +173,9 @@ def test_model_rejects_other_families():
         WanTransformer3DModel(model_type="i2v", dim=256, num_heads=2)
     with pytest.raises(NotImplementedError):
         WanTransformer3DModel(dim=256, num_heads=4)     # head_dim 64
+
+
+def test_unipc_rejects_orders_it_does_not_build():
+    with pytest.raises(NotImplementedError, match="solver_order=3"):
+        FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=3)
+    FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=1)

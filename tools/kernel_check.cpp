@@ -371,13 +371,13 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         Dev<char> out(osz); out.zero();
         for (int round = 0; round < 2; ++round)
         for (const char* var : {"1", "2", "2p4"}) {
-            setenv("WAN_GEMM_VARIANT", var[0] == '1' ? "1" : "2", 1);
-            setenv("WAN_GEMM_PHASES", strlen(var) > 1 ? "4" : "2", 1);
+            WAN(wan_set_tuning("gemm_variant", var[0] == '1' ? 1 : 2));
+            WAN(wan_set_tuning("gemm_phases", strlen(var) > 1 ? 4 : 2));
             double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
                                                         g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
             printf("  gemm[v%s] %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", var, g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
         }
-        unsetenv("WAN_GEMM_VARIANT"); unsetenv("WAN_GEMM_PHASES");
+        WAN(wan_set_tuning("gemm_variant", 0)); WAN(wan_set_tuning("gemm_phases", 0));
     }
     struct A_ { int Lq, Lk, H; const char* what; };
     if (gemm_only) return;
@@ -396,15 +396,15 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         for (int round = 0; round < (attn_only ? 2 : 1); ++round)
         for (const char* var : {"3s", "3n", "3"}) {       // 3 = pre-scaled q (max-free fast kernel + fix-up); 3s = running-max kernel only; 3n = 3 without the split tail
             if (!attn_only && strcmp(var, "3")) continue;
-            setenv("WAN_ATTN_TAIL", !strcmp(var, "3n") ? "0" : "1", 1);
-            setenv("WAN_ATTN_FAST", !strcmp(var, "3s") ? "0" : "1", 1);
+            WAN(wan_set_tuning("attn_tail", !strcmp(var, "3n") ? 0 : 1));
+            WAN(wan_set_tuning("attn_fast", !strcmp(var, "3s") ? 0 : 1));
             const int64_t wsb = wan_attention_workspace_bytes(1, s.Lq, s.Lk, s.H, 128);
             Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();      // the header of the scratch must start as zero
             double ms = time_ms([&] { WAN(wan_attention_fwd(var[0] == '3' ? qs.p : q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, s.Lq, s.Lk, s.H, 128, 0.0883883f, var[0] == '3' ? WAN_ATTN_Q_PRESCALED : 0,
                                                             wsb ? ws.p : nullptr, wsb, nullptr)); }, 3, 1);
             printf("  attn[v%s] %-18s Lq=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s\n", var, s.what, s.Lq, s.Lk, s.H, ms, 4.0 * s.Lq * s.Lk * C / ms / 1e9);
         }
-        unsetenv("WAN_ATTN_TAIL"); unsetenv("WAN_ATTN_FAST");
+        WAN(wan_set_tuning("attn_tail", 1)); WAN(wan_set_tuning("attn_fast", 1));
     }
 }
 
@@ -433,6 +433,36 @@ int main(int argc, char** argv) {
             WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr));
         HIP(hipDeviceSynchronize());
         printf("attnprof done\n");
+    }
+    if (mode == "attnx") {        // in-process A/B of the self-attention launch at the bench shape: tuning key=value sets from argv
+        // usage: kernel_check attnx [H] "k1=v1,k2=v2" "k1=v1" ...   (each quoted group is one arm; "" = defaults)
+        const int L = 67080; int H = 40; int first = 2;
+        if (argc > 2 && atoi(argv[2]) > 0) { H = atoi(argv[2]); first = 3; }
+        const int C = H * 128; const int64_t ldvt = (L + 63) / 64 * 64;
+        auto hq = to_bf(randn((size_t)4096 * 128));
+        Dev<bf16> q((size_t)L * C), k((size_t)L * C), vt((size_t)C * ldvt), o((size_t)L * C);
+        auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
+        fill(k); fill(vt);
+        { std::vector<float> hf = bf_to_f(hq); for (auto& x : hf) x *= WAN_ATTN_QSCALE(0.0883883f); hq = to_bf(hf); }
+        fill(q);
+        const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
+        Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp"};
+        int defaults[4]; for (int i = 0; i < 4; ++i) defaults[i] = wan_get_tuning(keys[i]);
+        for (int round = 0; round < 2; ++round)
+        for (int ai = first; ai < argc; ++ai) {
+            for (int i = 0; i < 4; ++i) WAN(wan_set_tuning(keys[i], defaults[i]));
+            std::string arm = argv[ai], tok;
+            for (size_t p0 = 0; p0 < arm.size();) {
+                size_t p1 = arm.find(',', p0); if (p1 == std::string::npos) p1 = arm.size();
+                tok = arm.substr(p0, p1 - p0); p0 = p1 + 1;
+                const size_t eq = tok.find('=');
+                if (eq != std::string::npos) WAN(wan_set_tuning(tok.substr(0, eq).c_str(), atoi(tok.c_str() + eq + 1)));
+            }
+            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr)); }, 4, 1);
+            printf("  attnx[%-28s] L=%d H=%d: %.3f ms  %.0f TFLOP/s\n", arm.c_str(), L, H, ms, 4.0 * L * L * C / ms / 1e9);
+            fflush(stdout);
+        }
     }
     if (mode == "perf" || mode == "all") perf(big);
     return g_fail ? 1 : 0;

@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 
@@ -39,6 +39,8 @@ class ConvParams(Structure):
 SIGNATURES = {
     "wan_abi_version": (c_int, []),
     "wan_last_error": (c_char_p, []),
+    "wan_set_tuning": (c_int, [c_char_p, c_int]),
+    "wan_get_tuning": (c_int, [c_char_p]),
     "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64,
                                 c_float, c_void_p]),
     "wan_rmsnorm_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,

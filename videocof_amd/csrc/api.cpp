@@ -1,10 +1,15 @@
 // Error plumbing and ABI version of libwan_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
 
 #include <hip/hip_runtime.h>
 
-#include "../../include/wan_hip.h"
+#include "common.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -21,12 +26,78 @@ extern "C" int wan_abi_version(void) { return WAN_ABI_VERSION; }
 // Launch planning (tile quantisation) wants the CU count; it is host arithmetic and must also work where no GPU is
 // visible (the CPU-side ABI tests), hence the fallback.
 int wan_cu_count() {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, v = 0;
+    static std::atomic<int> ncu{0};
+    int v = ncu.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        ncu = v;
+        ncu.store(v, std::memory_order_relaxed);
     }
-    return ncu;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Developer switches.  The environment is read ONCE (first use, thread-safe function-local static); after that the
+// hot path only loads an atomic int.  wan_set_tuning() overrides a switch at run time (A/B harnesses).
+namespace {
+struct TuningKey { const char* key; const char* env; int def; };
+const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
+    {"attn_tail", "WAN_ATTN_TAIL", 1},          // split-KV tail round of wan_attention_fwd
+    {"attn_fast", "WAN_ATTN_FAST", 1},          // max-free first attempt (+ checked fix-up) for pre-scaled q
+    {"attn_xcd_map", "WAN_ATTN_XCD_MAP", 1},    // heads pinned to XCDs (one head's K/V per XCD L2 at a time)
+    {"gemm_gm", "WAN_GEMM_GM", 0},              // M tiles per rasterisation group of the 256^2 GEMM (0 = by shape)
+    {"gemm_phases", "WAN_GEMM_PHASES", 0},      // K-loop phasing of the 256^2 GEMM (0 = default)
+    {"debug_checks", "WAN_DEBUG_CHECKS", 0},    // synchronising contract checks (V^T padding finite, ...)
+    {"attn_exp", "WAN_ATTN_EXP", 0},            // experiment selector of the attention kernel (0 = product path)
+    {"gemm_variant", "WAN_GEMM_VARIANT", 0},    // 1 = force the 128^2 GEMM, 2 = force the 256^2 GEMM, 0 = by shape
+    {"conv_xcd", "WAN_CONV_XCD", 1},            // XCD slab rasterisation of wan_conv_cl
+};
+struct Tuning {
+    std::atomic<int> v[WAN_TUNE_COUNT];
+    Tuning() {
+        for (int i = 0; i < WAN_TUNE_COUNT; ++i) {
+            const char* e = getenv(kTuningKeys[i].env);
+            v[i].store(e ? atoi(e) : kTuningKeys[i].def, std::memory_order_relaxed);
+        }
+    }
+};
+Tuning& tuning() {
+    static Tuning t;
+    return t;
+}
+}  // namespace
+
+int wan_tune(int which) { return tuning().v[which].load(std::memory_order_relaxed); }
+
+extern "C" wan_status_t wan_set_tuning(const char* key, int value) {
+    WAN_REQUIRE(key != nullptr, WAN_ERR_INVALID, "wan_set_tuning: null key");
+    for (int i = 0; i < WAN_TUNE_COUNT; ++i)
+        if (!strcmp(key, kTuningKeys[i].key)) {
+            tuning().v[i].store(value, std::memory_order_relaxed);
+            return WAN_OK;
+        }
+    wan_set_error("wan_set_tuning: unknown key '%s'", key);
+    return WAN_ERR_INVALID;
+}
+
+extern "C" int wan_get_tuning(const char* key) {
+    if (key)
+        for (int i = 0; i < WAN_TUNE_COUNT; ++i)
+            if (!strcmp(key, kTuningKeys[i].key)) return wan_tune(i);
+    return -1;
+}
+
+// One-time, per-device kernel attribute set-up (hipFuncSetAttribute is per device).  `done` is a bit mask of devices.
+wan_status_t wan_once_per_device(std::atomic<uint64_t>& done, wan_status_t (*init)()) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return WAN_OK;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return WAN_OK;
+    const wan_status_t st = init();
+    if (st == WAN_OK) done.fetch_or(bit, std::memory_order_release);
+    return st;
 }

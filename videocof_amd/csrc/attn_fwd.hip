@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 
@@ -52,6 +53,12 @@ struct AttnArgs {
     float* ws_o;          // [batch][nsplit][H][rows_tail][128] un-normalised partial outputs
     float* ws_ml;         // [batch][nsplit][H][rows_tail][2]   running max (log2 units), sum
     int* flags;           // MODE 1 / 2: one word per workgroup of the main launch, != 0 -> recompute with the running max
+    // 1-D grid decode: workgroup w -> (query block, head, z) with z = batch (or batch * nsplit + split).
+    // xcd_map != 0 (needs nbh % 8 == 0): workgroups are dispatched round-robin over the 8 XCDs, so w & 7 IS the XCD;
+    // (head, z) pair bh = 8 * ((w >> 3) / nqb) + (w & 7) pins every head to one XCD, whose 32 CUs walk that head's query
+    // blocks together: one head's K / V^T (34 MB at L = 67 080) streams through ONE 4 MB L2 instead of all eight.
+    int nqb, nbh, xcd_map;
+    int tile_mask;        // developer experiment (attn_exp): staging reads tile (t & tile_mask); 0x7fffffff in product
 };
 
 // VARIANT (template parameter of the kernel below) only names the instantiation so profiles separate the two
@@ -143,7 +150,17 @@ __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
 template <int VARIANT, bool PRE, bool SPLIT = false, int MODE = 0>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     static_assert(MODE == 0 || (PRE && !SPLIT), "fast / fixup modes exist for the pre-scaled, unsplit launch only");
-    const int wg_linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int wg_linear = blockIdx.x;
+    int qblk_l, bh;
+    if (a.xcd_map) {
+        const int s_ = wg_linear >> 3, g_ = s_ / a.nqb;
+        qblk_l = s_ - g_ * a.nqb;
+        bh = g_ * 8 + (wg_linear & 7);
+    } else {
+        bh = wg_linear / a.nqb;
+        qblk_l = wg_linear - bh * a.nqb;
+    }
+    const int bz = bh / a.H;
     // scratch header (the 4 ints in front of the flags): [0] sticky "fast path off", [1] workgroups redone by this call
     int* const hdr = (MODE != 0) ? a.flags - 4 : nullptr;
     if constexpr (MODE == 2) {
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         if (threadIdx.x == 0) {
             // if more than 1/8 of a launch had to be redone, later calls on this scratch skip the max-free attempt
             const int redone = atomicAdd(&hdr[1], 1) + 1;
-            if (redone * 8 > (int)(gridDim.x * gridDim.y * gridDim.z)) hdr[0] = 1;
+            if (redone * 8 > (int)gridDim.x) hdr[0] = 1;
         }
     }
     if constexpr (MODE == 1) {
@@ -167,9 +184,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int qblk = blockIdx.x + (SPLIT ? a.qblk0 : 0), head = blockIdx.y;
-    const int batch = SPLIT ? blockIdx.z / a.nsplit : blockIdx.z;
-    const int split = SPLIT ? blockIdx.z - batch * a.nsplit : 0;
+    const int qblk = qblk_l + (SPLIT ? a.qblk0 : 0), head = bh - bz * a.H;
+    const int batch = SPLIT ? bz / a.nsplit : bz;
+    const int split = SPLIT ? bz - batch * a.nsplit : 0;
     const int t0 = split * a.tiles_per_split;                     // first KV tile of this split
     const int Lk = SPLIT ? min(a.Lk - t0 * kKV, a.tiles_per_split * kKV) : a.Lk;
     const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     }
     const int nkv_ = (Lk + kKV - 1) / kKV;
     auto stage_k = [&](int t) {
-        const int kv0 = t * kKV;
+        const int kv0 = (t & a.tile_mask) * kKV;
         if (t == nkv_ - 1) {            // wave-uniform
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         }
     };
     auto stage_v = [&](int t) {
-        const int kv0 = t * kKV;
+        const int kv0 = (t & a.tile_mask) * kKV;
 #pragma unroll
         for (int j = 0; j < 2; ++j) glds16(v_src[j] + kv0, vring + (t % kVRing) * kVTileBytes + (wid * 2 + j) * 1024);
     };
@@ -521,8 +538,7 @@ TailPlan plan_tail(int batch, int Lq, int Lk, int num_heads) {
     const int nqb = (Lq + kQPerWG - 1) / kQPerWG, nkv = (Lk + kKV - 1) / kKV;
     p.main_qb = nqb;
     const int64_t hb = (int64_t)num_heads * batch, items = hb * nqb;
-    const char* et = getenv("WAN_ATTN_TAIL");          // developer A/B switch: 0 disables
-    if ((et && atoi(et) == 0) || Lk <= 1024 || items <= ncu || items % ncu == 0) return p;
+    if (wan_tune(WAN_TUNE_ATTN_TAIL) == 0 || Lk <= 1024 || items <= ncu || items % ncu == 0) return p;
     const int64_t rem = items % ncu;
     const int cand = (int)((rem + hb - 1) / hb);        // query blocks per (batch, head) moved to the tail launch
     if (cand >= nqb) return p;
@@ -543,6 +559,42 @@ TailPlan plan_tail(int batch, int Lq, int Lk, int num_heads) {
 }  // namespace
 
 namespace {
+// Contract check behind the `debug_checks` switch: the V^T pad columns [Lk, roundup(Lk, 64)) of every row are read by
+// the last KV tile with probability 0, and 0 * NaN is NaN in the MFMA, so they must be finite.  One pass over the pad
+// columns, a device flag, a stream synchronise (developer / bring-up use only; the product path never synchronises).
+__global__ void vt_pad_check_kernel(const bf16_t* vt, int64_t ldvt, int64_t vt_bs, int rows, int Lk, int lk_pad, int* flag) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x, batch = blockIdx.y;
+    if (row >= rows) return;
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(vt + batch * vt_bs + (int64_t)row * ldvt);
+    bool bad = false;
+    for (int c = Lk; c < lk_pad; ++c) bad |= (p[c] & 0x7f80u) == 0x7f80u;       // exponent all ones: Inf / NaN
+    if (bad) atomicOr(flag, 1);
+}
+
+wan_status_t check_vt_padding(const AttnArgs& a, int batch, int64_t lk_pad, hipStream_t st) {
+    if (lk_pad == a.Lk) return WAN_OK;
+    int* flag = nullptr;
+    if (hipMalloc(&flag, sizeof(int)) != hipSuccess || hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) {
+        wan_set_error("wan_attention_fwd: debug check could not allocate its flag");
+        return WAN_ERR_LAUNCH;
+    }
+    const int rows = a.H * kD;
+    hipLaunchKernelGGL(vt_pad_check_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)batch), dim3(256), 0, st,
+                       a.vt, a.ldvt, a.vt_bs, rows, a.Lk, (int)lk_pad, flag);
+    int host = 0;
+    hipError_t e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(flag);
+    if (e != hipSuccess) {
+        wan_set_error("wan_attention_fwd: debug check failed to run: %s", hipGetErrorString(e));
+        return WAN_ERR_LAUNCH;
+    }
+    WAN_REQUIRE(host == 0, WAN_ERR_INVALID,
+                "wan_attention_fwd: V^T pad columns [%d, %lld) hold Inf/NaN (the caller must keep them finite, e.g. zero)",
+                a.Lk, (long long)lk_pad);
+    return WAN_OK;
+}
+
 // scratch layout: [16-byte header + one int per workgroup of the un-split grid, rounded up to 256 B][partials of the
 // split tail round].  The header must be zero when the scratch is first used (it carries the sticky switch).
 int64_t flag_bytes(int batch, int Lq, int num_heads) {
@@ -576,10 +628,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     WAN_REQUIRE(ldvt >= lk_pad && ldvt % 8 == 0, WAN_ERR_INVALID,
                 "wan_attention_fwd: ldvt=%lld must be >= roundup(Lk,64)=%lld and a multiple of 8",
                 (long long)ldvt, (long long)lk_pad);
-    WAN_REQUIRE(num_heads <= 65535 && batch <= 65535, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     if (Lq == 0) return WAN_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t ast = wan_once_per_device(attr_done, +[]() -> wan_status_t {
         const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>),
@@ -592,8 +643,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
                 return WAN_ERR_LAUNCH;
             }
         }
-        attr_set = true;
-    }
+        return WAN_OK;
+    });
+    if (ast != WAN_OK) return ast;
     AttnArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.q_bs = q_bstride;
     a.k = (const bf16_t*)k; a.ldk = ldk; a.k_bs = k_bstride;
@@ -603,12 +655,18 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     const bool pre = (flags & WAN_ATTN_Q_PRESCALED) != 0;
     a.scale_log2e = pre ? 1.0f : softmax_scale * 1.4426950408889634f;
     a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr; a.flags = nullptr;
-    dim3 grid((unsigned)((Lq + kQPerWG - 1) / kQPerWG), (unsigned)num_heads, (unsigned)batch), block(kThreads);
+    const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
+    dim3 block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     const bool self = Lk > 1024;
+    a.tile_mask = (wan_tune(WAN_TUNE_ATTN_EXP) & 1) ? 15 : 0x7fffffff;
+    if (wan_tune(WAN_TUNE_DEBUG_CHECKS) != 0) {       // synchronising contract check, developer builds / bring-up only
+        const wan_status_t cs = check_vt_padding(a, batch, lk_pad, st);
+        if (cs != WAN_OK) return cs;
+    }
     // With scratch memory: (1) pre-scaled q runs the max-free kernel (MODE 1) followed by the fix-up launch (MODE 2) that
     // recomputes flagged workgroups only; (2) the last partial round of a long launch is split over the keys (plan_tail).
-    // WAN_ATTN_FAST=0 / WAN_ATTN_TAIL=0 are developer A/B switches.
+    // attn_fast / attn_tail (wan_set_tuning, or WAN_ATTN_FAST / WAN_ATTN_TAIL read once at load) are developer A/B switches.
     TailPlan tp;
     bool fast = false;
     char* ws_tail = nullptr;
@@ -616,15 +674,20 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
         const int64_t fb = flag_bytes(batch, Lq, num_heads);
         if (workspace_bytes >= fb) {
-            const char* ef = getenv("WAN_ATTN_FAST");
-            fast = pre && !(ef && atoi(ef) == 0);
+            fast = pre && wan_tune(WAN_TUNE_ATTN_FAST) != 0;
             a.flags = (int*)workspace + 4;
             ws_tail = (char*)workspace + fb;
             tp = plan_tail(batch, Lq, Lk, num_heads);
-            if (tp.tq > 0 && (workspace_bytes - fb < tp.ws_bytes || (batch * (int64_t)tp.nsplit) > 65535)) tp = TailPlan();
+            if (tp.tq > 0 && workspace_bytes - fb < tp.ws_bytes) tp = TailPlan();
         }
     }
-    if (tp.tq > 0) grid.x = (unsigned)tp.main_qb;
+    a.nqb = tp.tq > 0 ? tp.main_qb : nqb_all;
+    a.nbh = num_heads * batch;
+    // heads pinned to XCDs: only worth it (and only balanced) when the (batch, head) pairs split evenly over the 8 XCDs
+    a.xcd_map = (wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && a.nbh % 8 == 0) ? 1 : 0;
+    const int64_t nwg = (int64_t)a.nqb * a.nbh;
+    WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
+    dim3 grid((unsigned)nwg);
     if (pre && fast) {
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 1>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 1>), grid, block, kLdsBytesV2, st, a);
@@ -646,7 +709,8 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         a.row0 = tp.main_qb * kQPerWG; a.rows_tail = tp.rows_tail;
         a.ws_o = (float*)ws_tail;
         a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
-        dim3 tgrid((unsigned)tp.tq, (unsigned)num_heads, (unsigned)(batch * tp.nsplit));
+        a.nqb = tp.tq; a.nbh = num_heads * batch * tp.nsplit; a.xcd_map = 0;
+        dim3 tgrid((unsigned)((int64_t)a.nqb * a.nbh));
         if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
         WAN_CHECK_LAUNCH("wan_attention_fwd (tail)");

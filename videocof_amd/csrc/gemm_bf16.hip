@@ -219,16 +219,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
 
 template <int EPI>
 wan_status_t launch(const GemmArgs& g, hipStream_t s, int batch = 1) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16: cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
             return WAN_ERR_LAUNCH;
         }
-        attr_set = true;
-    }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch), block(kThreads);
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, kLdsBytes, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16");
@@ -255,9 +256,8 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
     if (M == 0) return WAN_OK;
     {   // Large shapes -> 256^2 phased kernel (one workgroup per CU), unless its tiles would leave more than half of
         // the CUs idle (M ~ 1e3: the text encoder, the VAE's attention block): four times as many 128^2 tiles at two
-        // per CU fill the chip better.  WAN_GEMM_VARIANT=1|2 is a developer A/B switch, not a product option.
-        const char* ev = getenv("WAN_GEMM_VARIANT");
-        const int variant = ev ? atoi(ev) : 0;
+        // per CU fill the chip better.  gemm_variant = 1|2 is a developer A/B switch (wan_set_tuning), not a product option.
+        const int variant = wan_tune(WAN_TUNE_GEMM_VARIANT);
         const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
         const bool big = M >= 1024 && N >= 256 && 2 * tiles256 > wan_cu_count();
         if (variant == 2 || (variant == 0 && big))

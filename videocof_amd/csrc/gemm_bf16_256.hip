@@ -315,16 +315,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
 
 template <int EPI, int PHASES>
 wan_status_t launch256(const GemmArgs& g, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, PHASES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16(256): cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
             return WAN_ERR_LAUNCH;
         }
-        attr_set = true;
-    }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
     hipLaunchKernelGGL((gemm256_kernel<EPI, PHASES>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), kLdsBytes, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16(256)");
     return WAN_OK;
@@ -344,9 +345,8 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     // M tiles per rasterisation group, measured at M = 67 080 (profiles/r01/gemm_raster_group_ab.log): 2 for wide N
     // (qk projection +5 %, ffn.0 +2 % over the former 4), 3 otherwise (+2 %); 8 and 16 lose 10-15 %.
     g.gm = g.tiles_n >= 40 ? 2 : 3;
-    { const char* eg = getenv("WAN_GEMM_GM"); if (eg && atoi(eg) > 0) g.gm = atoi(eg); }     // developer A/B switch
-    const char* ev = getenv("WAN_GEMM_PHASES");          // developer A/B switch
-    const int phases = ev ? atoi(ev) : kDefaultPhases;
+    if (const int gm = wan_tune(WAN_TUNE_GEMM_GM); gm > 0) g.gm = gm;       // developer A/B switches (wan_set_tuning)
+    const int phases = wan_tune(WAN_TUNE_GEMM_PHASES) > 0 ? wan_tune(WAN_TUNE_GEMM_PHASES) : kDefaultPhases;
 #define WAN_G256(E) (phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
     switch (epilogue) {
         case WAN_EPI_BF16: return WAN_G256(WAN_EPI_BF16);

@@ -218,16 +218,17 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
 template <int NT>
 wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
     constexpr int lds = 2 * (kATile + 32 * NT * BK * 2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cl_kernel<NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             wan_set_error("wan_conv_cl: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
             return WAN_ERR_LAUNCH;
         }
-        attr_set = true;
-    }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
     hipLaunchKernelGGL(conv_cl_kernel<NT>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), lds, s, g);
     WAN_CHECK_LAUNCH("wan_conv_cl");
     return WAN_OK;
@@ -361,7 +362,7 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
     g.ups = p->upsample2x ? 1 : 0; g.interleave = p->time_interleave ? 1 : 0; g.hist_frames = hist_frames; g.silu = 0;
     g.M = (int)M; g.ntaps = ntaps; g.nk = Kpad / BK;
     g.cin_magic = (unsigned)((0x100000000ULL + p->Cin - 1) / p->Cin);
-    { const char* ex = getenv("WAN_CONV_XCD"); g.xcd_slabs = !(ex && atoi(ex) == 0); }      // developer A/B switch
+    g.xcd_slabs = wan_tune(WAN_TUNE_CONV_XCD) != 0;      // developer A/B switch (wan_set_tuning)
     g.tiles_m = (g.M + BM - 1) / BM;
     hipStream_t s = (hipStream_t)stream;
     if (p->Cout <= 32) { g.tiles_n = 1; return launch_conv<1>(g, s); }      // decoder head (3), latent convs (16 / 32)

@@ -6,7 +6,8 @@ Same contract as ``FlowUniPCMultistepScheduler`` of
 :208-211), ``.sigmas``, ``.order``, ``step(model_output, timestep, sample,
 return_dict=False)[0]``, ``scale_model_input``.  Supported configuration is the one
 the VideoCoF entry points build (fast_infer.py:328-337): ``flow_prediction``,
-``predict_x0``, ``solver_type='bh2'``, ``solver_order`` 1..3, ``lower_order_final``.
+``predict_x0``, ``solver_type='bh2'``, ``solver_order`` 1 or 2 (every reference entry point builds 2;
+order 3 is rejected in the constructor), ``lower_order_final``.
 
 Own formulation: every UniP / UniC update is a linear combination of at most four
 tensors, so the per-step scalar algebra (:378-470, :520-612) is done once in
@@ -51,6 +52,9 @@ class FlowUniPCMultistepScheduler:
             solver_type = "bh2"                                                  # :97-99
         if solver_type != "bh2" or prediction_type != "flow_prediction" or not predict_x0:
             raise NotImplementedError("only flow_prediction / predict_x0 / bh2 is built (fast_infer.py:328-337)")
+        if solver_order not in (1, 2):
+            raise NotImplementedError(f"solver_order={solver_order}: orders 1 and 2 are built (the reference's CLIs use 2, "
+                                      "fast_infer.py:328-337); order 3 needs a five-term update (:430-445, :590-600)")
         if use_dynamic_shifting or thresholding or solver_p is not None or final_sigmas_type != "zero":
             raise NotImplementedError("dynamic shifting / thresholding / solver_p / sigma_min are not on the VideoCoF path")
         self.config = type("Config", (), dict(
@@ -125,8 +129,6 @@ class FlowUniPCMultistepScheduler:
         if not corrector:
             if order == 2:
                 rhos = [0.5]                                                      # :437-438
-            elif order > 2:
-                raise NotImplementedError("solver_order > 2")
         else:
             if order == 1:
                 rhos = [0.5]                                                      # :597-598

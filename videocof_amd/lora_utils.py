@@ -20,6 +20,7 @@ per-token op) and the result is stored back in the weight's dtype.
 """
 from __future__ import annotations
 
+import warnings
 from collections import defaultdict
 from typing import Dict, Optional
 
@@ -111,9 +112,13 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
         n = _normalise(key)
         if n is not None:
             groups[n[0]][n[1]] = val
+    merged, unresolved = 0, []
     for flat, elems in groups.items():
+        if "lora_up.weight" not in elems or "lora_down.weight" not in elems:
+            continue                                   # norm-only entries etc., skipped like :476-479
         mod = index.get(flat)
-        if mod is None or "lora_up.weight" not in elems or "lora_down.weight" not in elems:
+        if mod is None:
+            unresolved.append(flat)
             continue
         w = weights[mod]
         up = elems["lora_up.weight"].to(w.device, torch.float32).flatten(1)
@@ -122,7 +127,16 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
         delta = torch.mm(up, down)
         if delta.shape != w.shape:
             raise ValueError(f"LoRA for {mod}: delta {tuple(delta.shape)} does not match weight {tuple(w.shape)}")
-        w.copy_((w.float() + multiplier * scale * delta).to(w.dtype))
+        # One bf16 rounding of the weight per merge call, as in the reference: its `weight.data += ...` runs on the bf16
+        # parameter (`dtype=weight_dtype`, fast_infer.py:366-386; lora_utils.py:466-496), where up, down and their
+        # product are bf16-rounded too -- here the delta stays fp32 until the single final rounding.  The time-MLP
+        # weights are stored fp32 (bf16-rounded values, see load_state_dict) and are re-rounded the same way.
+        w.copy_((w.float() + multiplier * scale * delta).to(torch.bfloat16).to(w.dtype))
+        merged += 1
+    if unresolved:
+        warnings.warn(f"merge_lora: {len(unresolved)} LoRA module(s) match no weight of the transformer and were "
+                      f"skipped (first: {unresolved[:3]}); {merged} merged", stacklevel=2)
+    model.lora_layers_merged = merged                 # the reference returns the pipeline, so the count rides here
     if hasattr(model, "_ctx_cache"):
         model._ctx_cache = None          # hoisted text K/V were built from the old cross-attention weights
     return pipeline

@@ -7,6 +7,7 @@ falls back to eager PyTorch: a CPU tensor raises ``RuntimeError``.
 from __future__ import annotations
 
 import ctypes
+import functools
 import math
 from typing import Optional, Tuple
 
@@ -21,6 +22,31 @@ EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32, EPI_BF16_T = (
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on_tensor_device(fn):
+    """Launch on the device that holds the operands: the kernels take raw pointers, so HIP's current device (and
+    torch's current stream, which is per device) must be the tensors' device.  Entering ``torch.cuda.device`` only when
+    it differs keeps the common single-device case free of extra calls."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = next((a for a in args if torch.is_tensor(a)), None)
+        if t is None and args and isinstance(args[0], (list, tuple)):       # lincomb: list of (coefficient, tensor)
+            t = next((x[1] for x in args[0] if isinstance(x, tuple) and torch.is_tensor(x[1])), None)
+        if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+            with torch.cuda.device(t.device):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+def set_tuning(key: str, value: int) -> None:
+    """Developer switch of the library (``wan_set_tuning``, include/wan_hip.h)."""
+    _lib.check(_lib.load().wan_set_tuning(key.encode(), int(value)), "wan_set_tuning")
+
+
+def get_tuning(key: str) -> int:
+    return int(_lib.load().wan_get_tuning(key.encode()))
 
 
 def _need(t: torch.Tensor, dtype, name: str) -> None:
@@ -41,6 +67,7 @@ def round_up(x: int, m: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+@_on_tensor_device
 def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
                 add_one: bool, rows_per_batch: int, eps: float,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -63,6 +90,7 @@ def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[
     return out
 
 
+@_on_tensor_device
 def rmsnorm_rope_(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor], w1: Optional[torch.Tensor],
                   head_dim: int, eps: float, rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                   rope_params: Optional[RopeParams] = None, x0_scale: float = 1.0) -> None:
@@ -100,6 +128,7 @@ def q_prescale(head_dim: int, softmax_scale: Optional[float] = None) -> float:
     return float(scale) * _lib.LOG2E
 
 
+@_on_tensor_device
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
          out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
          rows_per_batch: int = 0, ldo_t: int = 0) -> torch.Tensor:
@@ -150,15 +179,38 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     return out
 
 
-_ATTN_WS = {}
+class AttentionWorkspace:
+    """Scratch of one ``wan_attention_fwd`` CALL SITE (the flags of the max-free attempt, its sticky "fast path off"
+    word, the partial results of the split tail round).  One object per call site and stream: the sticky word then
+    describes the inputs of THAT site only (a self-attention layer with out-of-window scores does not switch the
+    kernel of cross-attention or of another model), and two streams never share flags.  Launches that use one
+    workspace must be stream-ordered."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        if self.buf is None or self.buf.device != device or self.buf.numel() < nbytes:
+            self.buf = torch.zeros(nbytes, device=device, dtype=torch.uint8)       # zeroed header (sticky word off)
+        return self.buf
+
+    def reset(self) -> None:
+        """Forget the sticky decision (e.g. after loading other weights)."""
+        if self.buf is not None:
+            self.buf[:16].zero_()
 
 
+_ATTN_WS = {}          # ad-hoc callers without their own workspace: one per (device, stream)
+
+
+@_on_tensor_device
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads: int, k_len: Optional[int] = None,
                   softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
-                  q_prescaled: bool = False) -> torch.Tensor:
+                  q_prescaled: bool = False, workspace: Optional[AttentionWorkspace] = None) -> torch.Tensor:
     """q bf16 [B,Lq,H*128], k bf16 [B,Lk,H*128], vt bf16 [B,H*128,ldvt] (V transposed, ldvt >=
     roundup(k_len,64), finite padding) -> bf16 [B,Lq,H*128].  Keys >= k_len are masked.
-    ``q_prescaled``: q already carries softmax_scale*log2(e) (see ``rmsnorm_rope_``'s x0_scale)."""
+    ``q_prescaled``: q already carries softmax_scale*log2(e) (see ``rmsnorm_rope_``'s x0_scale).
+    ``workspace``: the call site's ``AttentionWorkspace`` (default: one per device and stream)."""
     for nm, t in (("q", q), ("k", k), ("vt", vt)):
         _need(t, torch.bfloat16, "attention." + nm)
         if t.dim() != 3:
@@ -176,10 +228,13 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(head_dim)
     lib = _lib.load()
     ws, ws_bytes = None, int(lib.wan_attention_workspace_bytes(B, Lq, Lk, num_heads, head_dim))
-    if ws_bytes > 0:        # scratch for the split tail round; one growing buffer per device, reused stream-ordered
-        ws = _ATTN_WS.get(q.device)
-        if ws is None or ws.numel() < ws_bytes:
-            ws = _ATTN_WS[q.device] = torch.zeros(ws_bytes, device=q.device, dtype=torch.uint8)    # zeroed header
+    if ws_bytes > 0:
+        if workspace is None:
+            key = (q.device, _stream())
+            workspace = _ATTN_WS.get(key)
+            if workspace is None:
+                workspace = _ATTN_WS[key] = AttentionWorkspace()
+        ws = workspace.get(q.device, ws_bytes)
     _lib.check(lib.wan_attention_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
                                      _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
                                      B, Lq, Lk, num_heads, head_dim, float(scale),
@@ -188,6 +243,7 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
     return out
 
 
+@_on_tensor_device
 def transpose_pad(v: torch.Tensor, ldt: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 [rows, cols] -> [cols, ldt] (zero padded columns), ldt default roundup(rows, 64)."""
     _need(v, torch.bfloat16, "transpose.v")
@@ -202,6 +258,7 @@ def transpose_pad(v: torch.Tensor, ldt: Optional[int] = None, out: Optional[torc
     return out
 
 
+@_on_tensor_device
 def patchify(latent: torch.Tensor, patch: Tuple[int, int, int], out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """latent [Cin,F,H,W] fp32|bf16 -> bf16 tokens [L, Cin*pt*ph*pw]."""
     if latent.dtype not in (torch.float32, torch.bfloat16):
@@ -222,6 +279,7 @@ def patchify(latent: torch.Tensor, patch: Tuple[int, int, int], out: Optional[to
     return out
 
 
+@_on_tensor_device
 def unpatchify(tokens: torch.Tensor, grid: Tuple[int, int, int], patch: Tuple[int, int, int], cout: int,
                out_dtype: torch.dtype) -> torch.Tensor:
     """tokens fp32 [L, pt*ph*pw*Cout] -> [Cout, F*pt, Hp*ph, Wp*pw] in out_dtype (fp32|bf16)."""
@@ -242,6 +300,7 @@ def unpatchify(tokens: torch.Tensor, grid: Tuple[int, int, int], patch: Tuple[in
 # ---------------------------------------------------------------------------------------------
 # WanVAE kernels (channels-last bf16 activations [T, H, W, C])
 # ---------------------------------------------------------------------------------------------
+@_on_tensor_device
 def conv_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, kernel, stride=(1, 1, 1),
             pad=(0, 0, 0), out_thw=None, hist: Optional[torch.Tensor] = None, upsample2x: bool = False,
             time_interleave: bool = False, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -275,6 +334,7 @@ def conv_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cout
     return out
 
 
+@_on_tensor_device
 def rmsnorm_silu_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool) -> torch.Tensor:
     _need(x, torch.bfloat16, "rmsnorm_silu_cl.x")
     _need(gamma, torch.float32, "rmsnorm_silu_cl.gamma")
@@ -288,6 +348,7 @@ def rmsnorm_silu_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool) -> torch.T
     return out
 
 
+@_on_tensor_device
 def softmax_rows(scores: torch.Tensor, n: int, npad: int, scale: float) -> torch.Tensor:
     _need(scores, torch.float32, "softmax_rows.scores")
     rows = scores.shape[0]
@@ -298,6 +359,7 @@ def softmax_rows(scores: torch.Tensor, n: int, npad: int, scale: float) -> torch
     return out
 
 
+@_on_tensor_device
 def video_to_cl(video: torch.Tensor, cpad: int = 8) -> torch.Tensor:
     """[C,T,H,W] fp32|bf16 -> bf16 [T,H,W,cpad] (extra channels zero)."""
     if video.dtype not in (torch.float32, torch.bfloat16):
@@ -312,6 +374,7 @@ def video_to_cl(video: torch.Tensor, cpad: int = 8) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def cl_to_video(x: torch.Tensor, cv: int, out_dtype: torch.dtype, clamp: bool) -> torch.Tensor:
     """bf16 [T,H,W,C>=cv] -> [cv,T,H,W] in out_dtype (fp32|bf16), optional clamp to [-1,1]."""
     _need(x, torch.bfloat16, "cl_to_video.x")
@@ -326,6 +389,7 @@ def cl_to_video(x: torch.Tensor, cv: int, out_dtype: torch.dtype, clamp: bool) -
     return out.to(out_dtype)
 
 
+@_on_tensor_device
 def lincomb(terms, out_dtype: torch.dtype) -> torch.Tensor:
     """sum_i c_i * x_i over <= 4 same-shape CUDA tensors in one pass (fp32 accumulate); `terms` is a list
     of (coefficient, tensor).  Inputs are brought to `out_dtype` (fp32 or bf16) if they differ."""
@@ -353,6 +417,7 @@ def _avail(t: torch.Tensor) -> int:
     return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
 
 
+@_on_tensor_device
 def gemm_batched(a: torch.Tensor, stride_a: int, w: torch.Tensor, stride_w: int, out: torch.Tensor, stride_o: int,
                  M: int, N: int, K: int, batch: int, epilogue: int) -> torch.Tensor:
     """`batch` independent products out_z[m,n] = sum_k a_z[m,k] * w_z[n,k] (one per attention head).
@@ -376,6 +441,7 @@ def gemm_batched(a: torch.Tensor, stride_a: int, w: torch.Tensor, stride_w: int,
     return out
 
 
+@_on_tensor_device
 def embedding_rows(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     """ids int64 [n] -> fp32 [n, dim] rows of the bf16 table [vocab, dim]."""
     _need(ids, torch.int64, "embedding.ids")
@@ -389,6 +455,7 @@ def embedding_rows(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def rmsnorm_rows(x: torch.Tensor, w: torch.Tensor, eps: float, out_dtype: torch.dtype = torch.bfloat16,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """T5LayerNorm of fp32 rows [rows, dim] -> bf16 (GEMM input) or fp32."""
@@ -407,6 +474,7 @@ def rmsnorm_rows(x: torch.Tensor, w: torch.Tensor, eps: float, out_dtype: torch.
     return out
 
 
+@_on_tensor_device
 def t5_softmax_bias(scores: torch.Tensor, table: torch.Tensor, lut: torch.Tensor, num_heads: int, k_len: int,
                     npad: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """scores fp32 [H, L, L] -> probs bf16 [H, L, npad] = softmax_j(scores + rel-pos bias), keys >= k_len masked."""
@@ -427,6 +495,7 @@ def t5_softmax_bias(scores: torch.Tensor, table: torch.Tensor, lut: torch.Tensor
     return out
 
 
+@_on_tensor_device
 def mul_bf16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _need(a, torch.bfloat16, "mul.a")
     _need(b, torch.bfloat16, "mul.b")

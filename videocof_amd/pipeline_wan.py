@@ -197,6 +197,8 @@ class WanPipeline:
         prev_cache = getattr(self.transformer, "cache_context", False)
         if hasattr(self.transformer, "cache_context"):
             self.transformer.cache_context = cache_context    # the prompt is fixed across steps
+        if hasattr(self.transformer, "clear_context_cache"):
+            self.transformer.clear_context_cache()            # never reuse another call's text K/V
         prev_skip = getattr(self.transformer, "skip_source_frames", 0)
         if hasattr(self.transformer, "skip_source_frames"):
             # noise_pred[:, :, :condition_count] is zeroed below (:736): the last block need not produce it
@@ -212,6 +214,12 @@ class WanPipeline:
                 timestep = t.expand(latent_model_input.shape[0])                                # :705
                 nb = latent_model_input.shape[0]
                 fsi = gfi = None
+                # :713 is `if repeat_rope and video is not None`, and the reference cannot run without `video` at all
+                # (`video.to(...)` at :397 precedes the `latents` short-cut), so on every call the reference accepts
+                # the condition is just `repeat_rope`.  Here `video` may be omitted when `latents` (reference argument)
+                # or `source_latents` (extension) carry the encoded source: such calls are treated like the reference
+                # treats the same call WITH its video; a call with none of the three has no source segment and keeps
+                # plain T2V positions.  Documented in INTEGRATION.md section B.
                 if repeat_rope and (video is not None or source_latents is not None or latents is not None):
                     fsi = [condition_count] * nb                                                # :713
                     if cot:
@@ -231,6 +239,8 @@ class WanPipeline:
         finally:
             if hasattr(self.transformer, "cache_context"):
                 self.transformer.cache_context = prev_cache
+            if hasattr(self.transformer, "clear_context_cache"):
+                self.transformer.clear_context_cache()        # releases the hoisted K/V^T and the prompt embeddings
             if hasattr(self.transformer, "skip_source_frames"):
                 self.transformer.skip_source_frames = prev_skip
 

@@ -117,11 +117,16 @@ class WanTransformer3DModel(nn.Module):
         self._sp = None
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
         self._ctx_cache = None
+        self._bufs = None                   # cached activation workspaces of the last call shape (_workspaces)
         # Number of leading latent frames whose prediction the caller discards (WanPipeline zeroes
         # noise_pred[:, :, :condition_count], pipeline_wan.py:736).  When set (B = 1, no SP) the LAST block and
         # the head run only on the remaining tokens' query rows -- their keys/values still cover every token --
         # and the discarded frames come back as zeros.  Parity neutral for the pipeline.
         self.skip_source_frames = 0
+        # one attention scratch per call site: the sticky "max-free attempt off" word of one site never reaches another
+        self._ws_self, self._ws_cross = ops.AttentionWorkspace(), ops.AttentionWorkspace()
+        self._probe_layer = None            # bench.py / tests: keep a copy of the residual stream entering this block
+        self._probe = None
         self._attn_events = None            # bench.py: list collecting (start, end) HIP events per self-attn launch
         self._last_attn_rows = 0
 
@@ -163,6 +168,9 @@ class WanTransformer3DModel(nn.Module):
         def vec(k):
             return get(k).detach().to(device=dev, dtype=torch.float32).contiguous()
 
+        def bvec(k):        # fp32 storage of a bf16-rounded vector
+            return get(k).detach().to(device=dev, dtype=torch.bfloat16).to(torch.float32).contiguous()
+
         C = self.dim
         w = self._w = {}
         w["pe_w"] = get("patch_embedding.weight").detach().reshape(C, -1).to(device=dev, dtype=torch.bfloat16).contiguous()
@@ -170,11 +178,13 @@ class WanTransformer3DModel(nn.Module):
         for i in ("0", "2"):
             w[f"te_w{i}"] = mat(f"text_embedding.{i}.weight")
             w[f"te_b{i}"] = vec(f"text_embedding.{i}.bias")
-            # time MLP runs under autocast(float32) in the reference (:913-929): keep fp32
-            w[f"tm_w{i}"] = get(f"time_embedding.{i}.weight").detach().to(device=dev, dtype=torch.float32)
-            w[f"tm_b{i}"] = vec(f"time_embedding.{i}.bias")
-        w["tp_w"] = get("time_projection.1.weight").detach().to(device=dev, dtype=torch.float32)
-        w["tp_b"] = vec("time_projection.1.bias")
+            # The time MLP runs under autocast(float32) in the reference (:913-929) on a model loaded with
+            # torch_dtype=bf16 (fast_infer.py:282): fp32 arithmetic on bf16-ROUNDED parameters.  Round once here
+            # (like every other matrix), keep fp32 storage for the fp32 torch matmuls of _time_embed.
+            w[f"tm_w{i}"] = mat(f"time_embedding.{i}.weight").to(torch.float32)
+            w[f"tm_b{i}"] = bvec(f"time_embedding.{i}.bias")
+        w["tp_w"] = mat("time_projection.1.weight").to(torch.float32)
+        w["tp_b"] = bvec("time_projection.1.bias")
         w["head_w"] = mat("head.head.weight")
         w["head_b"] = vec("head.head.bias")
         w["head_mod"] = vec("head.modulation").reshape(2, C)
@@ -238,13 +248,15 @@ class WanTransformer3DModel(nn.Module):
         return sd
 
     def linear_weights(self):
-        """Reference module name (``blocks.3.self_attn.q`` ...) -> the packed bf16 [out, in] device weight of that
+        """Reference module name (``blocks.3.self_attn.q`` ...) -> the packed [out, in] device weight of that
         ``nn.Linear`` (a VIEW: in-place edits take effect at the next forward; used by ``lora_utils.merge_lora``)."""
         if not getattr(self, "_w", None):
             raise RuntimeError("load_state_dict first")
         C, w = self.dim, self._w
         out = {"text_embedding.0": w["te_w0"], "text_embedding.2": w["te_w2"], "head.head": w["head_w"],
-               "patch_embedding": w["pe_w"]}
+               "patch_embedding": w["pe_w"],
+               # fp32 storage of bf16-rounded values (see load_state_dict); merge_lora re-rounds them
+               "time_embedding.0": w["tm_w0"], "time_embedding.2": w["tm_w2"], "time_projection.1": w["tp_w"]}
         for i, b in enumerate(self.blocks):
             p = f"blocks.{i}."
             out.update({p + "self_attn.q": b.w_qk[:C], p + "self_attn.k": b.w_qk[C:], p + "self_attn.v": b.w_v,
@@ -286,6 +298,10 @@ class WanTransformer3DModel(nn.Module):
 
     def enable_teacache(self, *a, **k):
         raise NotImplementedError("TeaCache changes outputs and is dead in the CLI path (SURVEY.md section 2, row 7)")
+
+    def clear_context_cache(self):
+        """Drop the hoisted text K/V^T (0.8 GB at 14B) and the references that keep the prompt embeddings alive."""
+        self._ctx_cache = None
 
     def disable_teacache(self):
         self.teacache = None
@@ -338,13 +354,14 @@ class WanTransformer3DModel(nn.Module):
         ops.rmsnorm_rope_(qk[r0:, :C], blk.nq, qk[r0:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp2, x0_scale=self._qs)
         ops.gemm(h[:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[0])
         n = Ll - r0
-        ops.attention_fwd(qk[r0:, :C].unsqueeze(0), qk[:, C:].unsqueeze(0), vt, H, k_len=L, out=att[r0:].unsqueeze(0), q_prescaled=True)
+        ops.attention_fwd(qk[r0:, :C].unsqueeze(0), qk[:, C:].unsqueeze(0), vt, H, k_len=L, out=att[r0:].unsqueeze(0), q_prescaled=True,
+                          workspace=self._ws_self)
         ops.gemm(att[r0:], blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs[r0:], gate=em[2], rows_per_batch=n)
         ops.ln_modulate(xs[r0:], blk.n3w, blk.n3b, False, n, self.eps, out=h[r0:])
         ops.gemm(h[r0:], blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq[r0:])
         ops.rmsnorm_rope_(cq[r0:], blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
         ck, cvt = ctx_kv
-        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0), q_prescaled=True)
+        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0), q_prescaled=True, workspace=self._ws_cross)
         ops.gemm(att[r0:], blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs[r0:])
         ops.ln_modulate(xs[r0:], em[4], em[3], True, n, self.eps, out=h[r0:])
         ops.gemm(h[r0:], blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff[r0:])
@@ -362,6 +379,129 @@ class WanTransformer3DModel(nn.Module):
             ev[1].record()
             self._attn_events.append(ev)
             self._last_attn_rows = rows
+
+    def _rope_map(self, grid, frame_split_indices, ground_frame_indices, token_offset, rows):
+        """The temporal position map of rope_apply_qk (:160-179) as kernel parameters."""
+        mode, f_src, g_end = 0, 0, 0
+        if frame_split_indices is not None and len(frame_split_indices) > 0:
+            if len(set(frame_split_indices)) != 1:
+                raise NotImplementedError("all samples of a call must share frame_split_indices")
+            f_src, mode = int(frame_split_indices[0]), 1
+            if ground_frame_indices is not None and len(ground_frame_indices) > 0:
+                if len(set(tuple(g) for g in ground_frame_indices)) != 1:
+                    raise NotImplementedError("all samples of a call must share ground_frame_indices")
+                g0, g1 = ground_frame_indices[0]
+                if int(g0) != f_src:
+                    raise ValueError("ground frames must start at frame_split_indices (pipeline_wan.py:716-718)")
+                mode, g_end = 2, int(g1)
+        return RopeParams(grid[0], grid[1], grid[2], mode, f_src, g_end, token_offset, rows, self.freqs.shape[0])
+
+    def _workspaces(self, B, Ll, L, seq_len):
+        """Per-forward activation buffers (module docstring).  Kept across calls of one shape: the caching allocator
+        would hand the same blocks back anyway, and fixed addresses are what a captured hipGraph replays."""
+        key = (B, Ll, L, seq_len, self.sp_world_size, str(self._device))
+        if self._bufs is not None and self._bufs[0] == key:
+            return self._bufs[1]
+        C, dev, M = self.dim, self._device, B * Ll
+        b = SimpleNamespace()
+        b.h = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        b.qk = torch.empty(M, 2 * C, device=dev, dtype=torch.bfloat16)
+        b.att = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        b.cq = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        b.ff = torch.empty(M, self.ffn_dim, device=dev, dtype=torch.bfloat16)
+        # V^T pad columns [L, roundup(L, 64)) are never written and must stay finite: zero them once
+        b.vt = torch.zeros(B, C, ops.round_up(L, 64) if self.sp_world_size == 1 else Ll, device=dev, dtype=torch.bfloat16)
+        b.qk3 = b.qk.view(B, Ll, 2 * C)
+        self._bufs = (key, b)
+        return b
+
+    def release_workspaces(self):
+        """Free the cached activation buffers (7 GB at 14B / L = 67 080) and the hoisted text K/V."""
+        self._bufs = None
+        self._ctx_cache = None
+
+    def _run_block(self, blk: _Block, em, xs, bufs, ctx_kv, rp, B, Ll, L, seq_len):
+        """One WanAttentionBlock (:464-515) in place on the fp32 residual stream xs [B*Ll, C].
+        em: [6, B, C] = modulation + e0 (:495); ctx_kv: (k [B,512,C], v^T [B,C,512]) of the text tokens."""
+        C, H, P, M = self.dim, self.num_heads, self.sp_world_size, B * Ll
+        h, qk, att, cq, ff, vt, qk3 = bufs.h, bufs.qk, bufs.att, bufs.cq, bufs.ff, bufs.vt, bufs.qk3
+        # ---- self attention (:495-499)
+        ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
+        if P == 1:
+            ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
+            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+            for b in range(B):
+                ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
+            ev = self._event_pair()
+            ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True,
+                              workspace=self._ws_self)
+            self._event_done(ev, B * Ll)
+            o_in = att
+        else:
+            # Ulysses: each projection is followed at once by its own head exchange (async, on RCCL's stream), so
+            # the k exchange runs under the V projection and the V^T exchange under the q projection; only the q
+            # exchange is left exposed before the attention launch.
+            sp = self._sp
+            ops.gemm(h, blk.w_qk[C:], blk.b_qk[C:], ops.EPI_BF16, out=qk[:, C:])
+            ops.rmsnorm_rope_(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp)
+            fk = sp.scatter_heads(qk3[:, :, C:], async_op=True)
+            for b in range(B):
+                ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
+            fv = sp.scatter_heads_t(vt, ld=ops.round_up(seq_len, 64), async_op=True)
+            ops.gemm(h, blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[:, :C])
+            ops.rmsnorm_rope_(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+            fq = sp.scatter_heads(qk3[:, :, :C], async_op=True)
+            q_full, k_full, vt_full = fq().contiguous(), fk().contiguous(), fv()
+            ev = self._event_pair()
+            o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L, q_prescaled=True, workspace=self._ws_self)
+            self._event_done(ev, B * seq_len)
+            o_in = sp.gather_heads(o_full).reshape(M, C)
+        ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
+        # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
+        ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
+        ops.gemm(h, blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq)
+        ops.rmsnorm_rope_(cq, blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
+        ck, cvt = ctx_kv
+        ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C), q_prescaled=True, workspace=self._ws_cross)
+        ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
+        # ---- FFN (:507-511)
+        ops.ln_modulate(xs, em[4], em[3], True, Ll, self.eps, out=h)
+        ops.gemm(h, blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff)
+        ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
+
+    @torch.no_grad()
+    def head_forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+        """``Head.forward`` (:535-548): x fp32 [B, L, C], e fp32 [B, C] (the time embedding, not its projection)
+        -> fp32 [B, L, patch_volume * out_dim]."""
+        B, Ll, C = x.shape
+        w = self._w
+        xs = x.to(device=self._device, dtype=torch.float32).reshape(B * Ll, C).contiguous()
+        eh = (w["head_mod"][None] + e.to(self._device, torch.float32)[:, None]).permute(1, 0, 2).contiguous()   # [2, B, C]
+        h = ops.ln_modulate(xs, eh[1], eh[0], True, Ll, self.eps)
+        return ops.gemm(h, w["head_w"], w["head_b"], ops.EPI_F32).view(B, Ll, -1)
+
+    @torch.no_grad()
+    def block_forward(self, x: torch.Tensor, e: torch.Tensor, context: torch.Tensor, grid_sizes, block_index: int = 0,
+                      frame_split_indices=None, ground_frame_indices=None) -> torch.Tensor:
+        """``WanAttentionBlock.forward`` (:464-515) of block ``block_index`` on a given residual stream.
+        x fp32 [B, L, C]; e fp32 [B, 6, C] (the time projection; the block adds its own ``modulation``, :494);
+        context [B, text_len, C] (already through ``text_embedding``); grid_sizes (F, Hp, Wp) with F*Hp*Wp <= L.
+        Returns the new residual stream, fp32 [B, L, C].  Single device only."""
+        if self.sp_world_size != 1:
+            raise NotImplementedError("block_forward is the single-device composite")
+        B, Ll, C = x.shape
+        grid = tuple(int(v) for v in grid_sizes)
+        L = grid[0] * grid[1] * grid[2]
+        if L > Ll or C != self.dim or tuple(e.shape) != (B, 6, C) or tuple(context.shape) != (B, self.text_len, C):
+            raise ValueError("block_forward: shapes disagree")
+        blk = self.blocks[block_index]
+        xs = x.to(device=self._device, dtype=torch.float32).reshape(B * Ll, C).clone()
+        em = (blk.modulation[None] + e.to(self._device, torch.float32)).permute(1, 0, 2).contiguous()      # [6, B, C]
+        ctx = context.to(device=self._device, dtype=torch.bfloat16).reshape(B * self.text_len, C).contiguous()
+        rp = self._rope_map(grid, frame_split_indices, ground_frame_indices, 0, Ll)
+        bufs = self._workspaces(B, Ll, L, Ll)
+        self._run_block(blk, em, xs, bufs, self._context_kv(blk, ctx, B), rp, B, Ll, L, Ll)
+        return xs.view(B, Ll, C)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -404,17 +544,23 @@ class WanTransformer3DModel(nn.Module):
         emod = (w["mod_all"][:, None] + e0[None]).permute(0, 2, 1, 3).contiguous()      # [layers, 6, B, C]
         ehead = (w["head_mod"][None] + e[:, None]).permute(1, 0, 2).contiguous()         # [2, B, C]
 
-        ctx_key = None
-        if self.cache_context:
-            ctx_key = tuple((u.data_ptr(), tuple(u.shape), u._version) for u in context)
-        if self._ctx_cache is not None and self._ctx_cache[0] == ctx_key and ctx_key is not None:
-            ctx_kv = self._ctx_cache[1]
+        # The hoisted text K/V are keyed by the IDENTITY of the context tensors, and the cache entry keeps them alive:
+        # a freed prompt buffer whose address the allocator hands to the next prompt can therefore never match
+        # (tensors written by the ctypes kernels all carry _version 0, so (data_ptr, shape, version) is not a key).
+        hit = False
+        if self.cache_context and self._ctx_cache is not None:
+            held, vers, _ = self._ctx_cache
+            hit = (len(held) == len(context) and all(a is b for a, b in zip(held, context))
+                   and vers == tuple(u._version for u in context))
+        if hit:
+            ctx_kv = self._ctx_cache[2]
         else:
+            self._ctx_cache = None
             ctx = self._text_embed(context)
             ctx_kv = [None] * self.num_layers
             if self.cache_context:
                 ctx_kv = [self._context_kv(blk, ctx, B) for blk in self.blocks]
-                self._ctx_cache = (ctx_key, ctx_kv)
+                self._ctx_cache = (list(context), tuple(u._version for u in context), ctx_kv)
 
         # -- patch embedding into the fp32 residual stream (this rank's token rows only) --------
         xs = torch.zeros(M, C, device=dev, dtype=torch.float32)
@@ -425,85 +571,24 @@ class WanTransformer3DModel(nn.Module):
             if hi > lo:
                 ops.gemm(tok[lo:hi], w["pe_w"], w["pe_b"], ops.EPI_F32, out=xs[b * Ll: b * Ll + (hi - lo)])
 
-        # -- RoPE position map -------------------------------------------------------------------
-        mode, f_src, g_end = 0, 0, 0
-        if frame_split_indices is not None and len(frame_split_indices) > 0:
-            if len(set(frame_split_indices)) != 1:
-                raise NotImplementedError("all samples of a call must share frame_split_indices")
-            f_src, mode = int(frame_split_indices[0]), 1
-            if ground_frame_indices is not None and len(ground_frame_indices) > 0:
-                if len(set(tuple(g) for g in ground_frame_indices)) != 1:
-                    raise NotImplementedError("all samples of a call must share ground_frame_indices")
-                g0, g1 = ground_frame_indices[0]
-                if int(g0) != f_src:
-                    raise ValueError("ground frames must start at frame_split_indices (pipeline_wan.py:716-718)")
-                mode, g_end = 2, int(g1)
-        rp = RopeParams(grid[0], grid[1], grid[2], mode, f_src, g_end, rank * Ll, Ll, self.freqs.shape[0])
+        rp = self._rope_map(grid, frame_split_indices, ground_frame_indices, rank * Ll, Ll)
 
         # -- workspaces ----------------------------------------------------------------------------
-        h = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
-        qk = torch.empty(M, 2 * C, device=dev, dtype=torch.bfloat16)
-        att = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
-        cq = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
-        ff = torch.empty(M, self.ffn_dim, device=dev, dtype=torch.bfloat16)
-        if P == 1:
-            vt = torch.zeros(B, C, ops.round_up(L, 64), device=dev, dtype=torch.bfloat16)
-        else:
-            vt = torch.zeros(B, C, Ll, device=dev, dtype=torch.bfloat16)
-        qk3 = qk.view(B, Ll, 2 * C)
+        bufs = self._workspaces(B, Ll, L, seq_len)
+        h = bufs.h
 
         # rows whose output is needed after the last block (all of them unless skip_source_frames is set)
         r0 = 0
         if self.skip_source_frames and B == 1 and P == 1:
             r0 = min(int(self.skip_source_frames), grid[0]) * grid[1] * grid[2]
         for li, blk in enumerate(self.blocks):
-            em = emod[li]
+            kv = ctx_kv[li] if ctx_kv[li] is not None else self._context_kv(blk, ctx, B)
+            if self._probe_layer == li:
+                self._probe = xs.clone()
             if r0 and li == self.num_layers - 1:
-                self._last_block_suffix(blk, em, xs, h, qk, vt, att, cq, ff, ctx_kv[li] if ctx_kv[li] is not None
-                                        else self._context_kv(blk, ctx, B), rp, r0, L)
+                self._last_block_suffix(blk, emod[li], xs, bufs.h, bufs.qk, bufs.vt, bufs.att, bufs.cq, bufs.ff, kv, rp, r0, L)
                 break
-            # ---- self attention (:495-499)
-            ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
-            if P == 1:
-                ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
-                ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
-                for b in range(B):
-                    ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
-                ev = self._event_pair()
-                ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True)
-                self._event_done(ev, B * Ll)
-                o_in = att
-            else:
-                # Ulysses: each projection is followed at once by its own head exchange (async, on RCCL's stream), so
-                # the k exchange runs under the V projection and the V^T exchange under the q projection; only the q
-                # exchange is left exposed before the attention launch.
-                sp = self._sp
-                ops.gemm(h, blk.w_qk[C:], blk.b_qk[C:], ops.EPI_BF16, out=qk[:, C:])
-                ops.rmsnorm_rope_(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp)
-                fk = sp.scatter_heads(qk3[:, :, C:], async_op=True)
-                for b in range(B):
-                    ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
-                fv = sp.scatter_heads_t(vt, ld=ops.round_up(seq_len, 64), async_op=True)
-                ops.gemm(h, blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[:, :C])
-                ops.rmsnorm_rope_(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
-                fq = sp.scatter_heads(qk3[:, :, :C], async_op=True)
-                q_full, k_full, vt_full = fq().contiguous(), fk().contiguous(), fv()
-                ev = self._event_pair()
-                o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L, q_prescaled=True)
-                self._event_done(ev, B * seq_len)
-                o_in = sp.gather_heads(o_full).reshape(M, C)
-            ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
-            # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
-            ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
-            ops.gemm(h, blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq)
-            ops.rmsnorm_rope_(cq, blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
-            ck, cvt = ctx_kv[li] if ctx_kv[li] is not None else self._context_kv(blk, ctx, B)
-            ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C), q_prescaled=True)
-            ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
-            # ---- FFN (:507-511)
-            ops.ln_modulate(xs, em[4], em[3], True, Ll, self.eps, out=h)
-            ops.gemm(h, blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff)
-            ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
+            self._run_block(blk, emod[li], xs, bufs, kv, rp, B, Ll, L, seq_len)
 
         # -- head (:535-548) + unpatchify (:1108-1131)
         if r0:

@@ -93,15 +93,22 @@ def deterministic_dit_state_dict(**cfg) -> Dict[str, torch.Tensor]:
 
 
 @torch.no_grad()
-def random_dit_state_dict(device, dtype=torch.bfloat16, seed: int = 0, **cfg) -> Dict[str, torch.Tensor]:
+def random_dit_state_dict(device, dtype=torch.bfloat16, seed: int = 0, exercise_epilogues: bool = False,
+                          **cfg) -> Dict[str, torch.Tensor]:
+    """``exercise_epilogues``: non-zero biases and non-unit norm gains (the reference's init zeroes / ones them), for
+    parity tests at sizes where the integer-hash fill is too slow."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     sd = {}
     for name, shape in dit_param_shapes(**cfg).items():
         if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm3.weight"):
             t = torch.ones(shape, device=device, dtype=torch.float32)
+            if exercise_epilogues:
+                t = t + (torch.rand(shape, device=device, generator=g, dtype=torch.float32) - 0.5) * 0.5
         elif name.endswith(".bias"):
             t = torch.zeros(shape, device=device, dtype=torch.float32)
+            if exercise_epilogues:
+                t = (torch.rand(shape, device=device, generator=g, dtype=torch.float32) - 0.5) * 0.2
         elif name.endswith("modulation"):
             t = torch.randn(shape, device=device, generator=g, dtype=torch.float32) / shape[-1] ** 0.5
         elif name.startswith(("text_embedding", "time_embedding")) or name == "head.head.weight":
