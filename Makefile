@@ -3,20 +3,30 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := videocof_amd/csrc
 SRCS  := $(CSRC)/api.cpp $(wildcard $(CSRC)/*.hip)
-HDRS  := $(CSRC)/common.hpp include/wan_hip.h
+HDRS  := $(CSRC)/common.hpp include/wan_hip.h $(wildcard $(CSRC)/*.inc)
 LIB   := videocof_amd/libwan_hip.so
+OBJD  := build/obj
+OBJS  := $(patsubst $(CSRC)/%,$(OBJD)/%.o,$(SRCS))
 # -fno-honor-nans: lets fmaxf/fminf lower to one v_max/v_min (no canonicalising v_max on MFMA outputs)
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fno-honor-nans -Iinclude
+# attn_fwd.hip only: keep adjacent scalar f32 adds single-instruction -- under plain -O3 the SLP vectoriser packs the
+# row-sum adds of the two query blocks into v_pk_add_f32, which beside MFMAs costs more than it saves (CDNA4 guide,
+# per-instruction cycle constants).  The GEMM / norm epilogues keep their packed math.
+FLAGS_attn_fwd.hip := -fno-slp-vectorize
 
 all: $(LIB) tools/kernel_check
 
-$(LIB): $(SRCS) $(HDRS)
-	$(HIPCC) $(FLAGS) -shared $(SRCS) -o $@
+$(OBJD)/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p $(OBJD)
+	$(HIPCC) $(FLAGS) $(FLAGS_$*) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared $(OBJS) -o $@
 
 tools/kernel_check: tools/kernel_check.cpp $(LIB) include/wan_hip.h
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) tools/kernel_check.cpp -Iinclude -Lvideocof_amd -lwan_hip -Wl,-rpath,'$$ORIGIN/../videocof_amd' -o $@
 
 clean:
-	rm -f $(LIB) tools/kernel_check
+	rm -rf $(LIB) tools/kernel_check $(OBJD)
 
 .PHONY: all clean

@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of the last block")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the forward + CoF mask from a hipGraph (videocof_amd.GraphedForward; text K/V hoisted out of "
+                         "the step as WanPipeline does).  For launch-bound small shapes; never the headline line.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -298,13 +301,22 @@ def main():
     prof = [] if not args.no_kernel_events else None
     model._attn_events = prof
 
+    fwd = model
+    if args.graph:
+        if sp:
+            raise SystemExit("--graph covers the single-device forward")
+        from videocof_amd import GraphedForward
+        fwd = GraphedForward(model)
+        model.mask_source_frames = Fs                # the CoF mask inside the captured unpatchify kernel
+        prof = model._attn_events = None             # HIP events cannot be recorded inside a replayed graph
+
     def run(n_steps):
         nonlocal latents
         sched.set_timesteps(max(n_steps, 1), device=dev, shift=3)
         lat = latents
         for t in sched.timesteps[:n_steps]:
-            v = model(lat, t.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
-            if cof:
+            v = fwd(lat, t.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+            if cof and not args.graph:
                 v[:, :, :Fs] = 0
             lat = sched.step(v, t, lat, return_dict=False)[0]
         return lat
@@ -316,7 +328,7 @@ def main():
             torch.cuda.synchronize()
 
     if args.warmup > 0:
-        run(args.warmup)
+        run(max(args.warmup, 2) if args.graph else args.warmup)      # graph: one eager call + the capture
     if prof is not None:
         prof.clear()
     fence()
@@ -334,6 +346,7 @@ def main():
     parity = None
     if not args.no_verify and not sp and rank == 0:
         model._attn_events = None
+        model.mask_source_frames = 0
         model._probe_layer = wl["num_layers"] - 1
         tv = sched.timesteps[:1]
         v = model(latents, tv.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
@@ -383,6 +396,7 @@ def main():
         "mfma_frac_whole_step": round(units * tot_flop * args.steps / wall / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": roof,
         "parity": parity,
+        "graph": bool(args.graph),
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

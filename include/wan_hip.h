@@ -42,9 +42,9 @@ int wan_abi_version(void);
 const char* wan_last_error(void);
 
 /* Developer switches (A/B harnesses, bring-up).  The matching environment variables (WAN_ATTN_TAIL, WAN_ATTN_FAST,
- * WAN_ATTN_XCD_MAP, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
+ * WAN_ATTN_XCD_MAP, WAN_ATTN_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
  * read ONCE, at the first call into the library; the launch paths never call getenv().  Keys: "attn_tail",
- * "attn_fast", "attn_xcd_map", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
+ * "attn_fast", "attn_xcd_map", "attn_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
  * "debug_checks" = 1 turns on SYNCHRONISING contract checks (V^T pad columns of wan_attention_fwd are finite).
  * wan_set_tuning is an atomic store: safe against concurrent launches, which see the old or the new value.
  * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code). */
@@ -169,11 +169,14 @@ wan_status_t wan_transpose_bf16(const void* in, int64_t ld, void* out_t, int64_t
  *     (wan_transformer3d.py:662-663, 870-879).  in_dtype: 0 fp32, 1 bf16.
  * a14 unpatchify: head output fp32 [L, pt*ph*pw*Cout] (c fastest) -> [Cout, F*pt, H*ph, W*pw]
  *     (einsum 'fhwpqrc->cfphqwr', wan_transformer3d.py:1108-1131).  out_dtype: 0 fp32, 1 bf16.
+ *     zero_frames: output frames [0, zero_frames) are written as 0 and their token rows are not read -- the
+ *     VideoCoF mask `noise_pred[:, :, :condition_count] = 0` (pipeline_wan.py:736) folded into the store
+ *     (exact also under classifier-free guidance: 0 + s * (0 - 0) = 0); 0 = plain unpatchify.
  * ------------------------------------------------------------------------- */
 wan_status_t wan_patchify(const void* latent, int in_dtype, void* tokens_bf16, int64_t ldt,
                           int Cin, int F, int H, int W, int pt, int ph, int pw, void* stream);
 wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
-                            int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, void* stream);
+                            int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, int zero_frames, void* stream);
 
 /* a17  UniPC updates as one fused pass: out[i] = c0*x0[i] + c1*x1[i] + c2*x2[i] + c3*x3[i] (x1..x3 may be
  *      NULL), fp32 accumulate, all tensors of one dtype (0 fp32, 1 bf16).

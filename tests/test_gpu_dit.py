@@ -146,6 +146,51 @@ def test_pipeline_clears_the_context_cache(golden, model):
     assert torch.equal(b, b_ref) and not torch.equal(a, b)
 
 
+def test_graph_replay_is_bit_identical(golden, model):
+    """hipGraph capture of the denoise step (8f-1): a 4-step CoF loop replayed from the graph gives the SAME BITS as the
+    eager loop, for the call that captures (eager step, capture + replay, replays), for a later call with another prompt
+    (replays only; text K/V refreshed in place outside the graph) and with CFG (B = 2: its own graph)."""
+    from videocof_amd import GraphedForward
+    g = golden("dit_g8_cof_loop")
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    ctx_a = torch.from_numpy(g["ctx"]).to(DEV)
+    ctx_b = (ctx_a * 0.7).contiguous()
+    kw = dict(latents=lat, source_frames=9, reasoning_frames=4, num_inference_steps=4, shift=3, repeat_rope=True, cot=True,
+              output_type="latent", weight_dtype=torch.float32)
+
+    def run(pipe, ctx, graph, scale=1.0):
+        return pipe(prompt_embeds=[ctx], negative_prompt_embeds=[ctx_b * 0.5] if scale > 1 else None, guidance_scale=scale,
+                    capture_graph=graph, **kw).latents
+
+    eager = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    graphed = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    want_a, want_b, want_cfg = run(eager, ctx_a, False), run(eager, ctx_b, False), run(eager, ctx_a, False, 3.0)
+    got_a = run(graphed, ctx_a, True)
+    assert isinstance(graphed._graphed, GraphedForward) and graphed._graphed.replays == 3      # 1 eager + 3 replays
+    got_b = run(graphed, ctx_b, True)
+    assert graphed._graphed.replays == 7                                                      # 4 more, no new capture
+    got_cfg = run(graphed, ctx_a, True, 3.0)
+    assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b) and torch.equal(got_cfg, want_cfg)
+    assert not torch.equal(got_a, got_b)
+    assert float(got_a[:, :, :3].sub(lat[:, :, :3]).abs().max()) < 1e-5       # source frames: masked on the device
+    assert model.mask_source_frames == 0 and model._ctx_cache is None          # the pipeline restored the model
+
+
+def test_unpatchify_zero_frames_is_the_cof_mask(model):
+    lat = det_uniform("zf.lat", (1, 16, 5, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("zf.ctx", (9, 64), 1.0).to(DEV)]
+    t = torch.tensor([500], device=DEV)
+    plain = model(lat, t, ctx, 80, frame_split_indices=[2], ground_frame_indices=[(2, 3)])
+    model.mask_source_frames = 2
+    try:
+        masked = model(lat, t, ctx, 80, frame_split_indices=[2], ground_frame_indices=[(2, 3)])
+    finally:
+        model.mask_source_frames = 0
+    want = plain.clone()
+    want[:, :, :2] = 0
+    assert torch.equal(masked, want) and float(plain[:, :, :2].abs().max()) > 0
+
+
 def test_g7_sched50_on_device(golden):
     g50 = golden("dit_g7_sched50")
     s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)

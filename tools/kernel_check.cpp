@@ -324,7 +324,7 @@ static void check_layout() {
     report("patchify fp32 in", rel_l2(ref, got), 0.0);
     auto t = randn((size_t)L * 64);
     Dev<float> dt(t), dout((size_t)16 * F * H * W);
-    WAN(wan_unpatchify(dt.p, 64, dout.p, 0, 16, Fp, Hp, Wp, 1, 2, 2, nullptr));
+    WAN(wan_unpatchify(dt.p, 64, dout.p, 0, 16, Fp, Hp, Wp, 1, 2, 2, 0, nullptr));
     HIP(hipDeviceSynchronize());
     auto g2 = dout.host();
     std::vector<double> r2(g2.size());

@@ -55,7 +55,7 @@ SIGNATURES = {
     "wan_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_void_p]),
     "wan_unpatchify": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_int, c_void_p]),
+                               c_int, c_int, c_int, c_int, c_void_p]),
     "wan_lincomb": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                             c_int64, c_void_p]),
     "wan_gemm_bf16_batched": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,

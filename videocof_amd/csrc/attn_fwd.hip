@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -479,6 +480,281 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     }
 }
 
+// ====================================================================================================
+// 4-wave kernel: the main launch of the max-free (MODE 1) path.
+//
+// Same workgroup (256 queries of one (batch, head)), same LDS images, same products and key permutation as the 8-wave
+// kernel above, but FOUR waves of 64 query rows each -- one wave per SIMD with the whole 512-register file:
+//   * O^T accumulators (2 query blocks x 4 d-blocks x 16) and the Q fragments (2 x 8 x 4) live in AGPRs
+//     (192 of 256); the MFMAs are inline asm so that A/B/C operands can be named in either file -- hipcc's own
+//     allocation of this shape spills (576 B/lane) and copies every S tile through v_accvgpr_read;
+//   * every K / V^T fragment read from LDS feeds TWO MFMAs (one per query block): 32 ds_read_b128 per 64 MFMAs instead
+//     of 32 per 32, and fragments are requested 3 fragments (6+ MFMA slots) ahead of use -- the 8-wave kernel reads each
+//     fragment right before its MFMA (no registers left) and its waves sit in s_waitcnt lgkmcnt 31 % of the time;
+//   * with a single instruction stream per SIMD the order of the stream IS the schedule: one interval is 64 slots of
+//     `MFMA ; <= 5 fillers ; sched_barrier(0)` (attn_w4_sched.inc, emitted by tools/gen_attn_w4_sched.py).
+// Hazards that hipcc does not see for an asm MFMA are handled by construction (CDNA4 guide, section 5.7):
+//   * VALU-written P fragment -> MFMA B operand: every P fragment is complete at least one slot (an MFMA and a
+//     sched_barrier) before the first PV slot that reads it (asserted by the generator);
+//   * MFMA-written S -> VALU read: S(t+1) is produced in interval t and first read in interval t+1, behind the
+//     s_waitcnt + s_barrier of the fence; the prologue's S(0) and the final O are followed by an explicit s_nop;
+//   * accumulate chains (same D as C) have 4 (S) / 8 (O) independent MFMAs between links, far above the 43-cycle cliff.
+// Rows whose scores leave the checked window flag the workgroup exactly like the 8-wave MODE 1 kernel, and the
+// MODE 2 launch of the 8-wave kernel recomputes it (same 256-query workgroup <-> flag mapping).
+// ====================================================================================================
+constexpr int kW4Threads = 256;
+
+__device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+template <int VARIANT>
+__global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_fwd_w4_kernel(AttnArgs a) {
+    const int wg_linear = blockIdx.x;
+    int* const hdr = a.flags - 4;
+    if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;
+    if (hdr[0] != 0) {                                       // sticky "fast path off": hand everything to the fix-up launch
+        if (threadIdx.x == 0) a.flags[wg_linear] = 1;
+        return;
+    }
+    int qblk, bh;
+    if (a.xcd_map) {
+        const int s_ = wg_linear >> 3, g_ = s_ / a.nqb;
+        qblk = s_ - g_ * a.nqb;
+        bh = g_ * 8 + (wg_linear & 7);
+    } else {
+        bh = wg_linear / a.nqb;
+        qblk = wg_linear - bh * a.nqb;
+    }
+    const int batch = bh / a.H, head = bh - batch * a.H;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int Lk = a.Lk;
+    const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
+    const bf16_t* K = a.k + batch * a.k_bs + head * kD;
+    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt;
+    bf16_t* O = a.o + batch * a.o_bs + head * kD;
+
+    // ---- Q fragments of the wave's two query blocks (B operands of S^T = K.Q^T), kept in AGPRs by the "a" constraints
+    int qrow[2];
+    u32x4 qf[2][8];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qrow[qb] = qblk * kQPerWG + wid * 64 + qb * 32 + l31;
+        const bf16_t* qp = Q + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+    }
+
+    char* const kring = smem;
+    // ---- staging: this wave copies pieces 4*wid .. 4*wid+3 (1 KiB each) of every K and V^T tile
+    const int nkv = (Lk + kKV - 1) / kKV;
+    // K / V^T tiles are fetched with `buffer_load_dwordx4 ... lds` (LDS-DMA through a buffer descriptor): the tile origin
+    // is SCALAR state (descriptor base advanced per tile by SALU), each lane keeps one constant 32-bit byte offset per
+    // piece, and the descriptor's range check returns zeros for K rows >= Lk (they are masked in the peeled last tile)
+    // -- no per-lane address arithmetic and no clamp in the loop.  Piece j of this wave = K rows 16 wid + 4 j + lane/16
+    // (256-B rows, chunk' = chunk ^ (row & 15)) and V^T rows 32 wid + 8 j + lane/8 (128-B rows, chunk' = chunk ^ ((row>>1)&7)).
+    int k_voff[4], v_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kr = wid * 16 + 4 * j + (lane >> 4);
+        k_voff[j] = (int)((kr * a.ldk + ((lane & 15) ^ (kr & 15)) * 8) * 2);
+        const int vr = (wid * 4 + j) * 8 + (lane >> 3);
+        v_voff[j] = (int)((vr * a.ldvt + ((lane & 7) ^ ((vr >> 1) & 7)) * 8) * 2);
+    }
+    const int64_t k_tile_bytes = (int64_t)kKV * a.ldk * 2;
+    auto k_rsrc = [&](int t) {          // tile min(t, nkv-1): a request past the end re-stages the last tile into a dead slot
+        const int tc = min(t, nkv - 1);
+        const int64_t left = (int64_t)(Lk - tc * kKV) * a.ldk * 2;               // bytes from the tile origin to the end of row Lk-1
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)K + tc * k_tile_bytes), 0,
+                                                 (int)min(left, (int64_t)0x7fffffff), 0x00020000);
+    };
+    auto v_rsrc = [&](int t) {          // t <= nkv - 1 always; V^T pad columns exist up to roundup(Lk, 64)
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)t * kKV * 2), 0, 0x7fffffff, 0x00020000);
+    };
+    auto stage_k_piece = [&](__amdgpu_buffer_rsrc_t r, int t, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kring + (t & 1) * kKTileBytes + (wid * 4 + j) * 1024),
+                                                 16, k_voff[j], 0, 0, 0);
+    };
+    auto stage_v_piece = [&](__amdgpu_buffer_rsrc_t r, int t, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + 2 * kKTileBytes + (t & 1) * kVTileBytes + (wid * 4 + j) * 1024),
+                                                 16, v_voff[j], 0, 0, 0);
+    };
+
+    const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int k_rowoff = pi * 256, k_sw = pi & 15;
+    int k_off[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) k_off[ks] = k_rowoff + (((2 * ks + hi) ^ k_sw) << 4);
+    const int v_rowoff = l31 * 128, v_sw = (l31 >> 1) & 7;
+    int v_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v_off[t] = 2 * kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
+
+    f32x16 o[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    float l_run[2] = {0.f, 0.f};
+
+    auto fence = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    };
+
+    // ---- prologue: K(0), V(0), K(1) in flight; S(0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { stage_k_piece(k_rsrc(0), 0, j); stage_v_piece(v_rsrc(0), 0, j); }
+    if (nkv > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_k_piece(k_rsrc(1), 1, j);
+    }
+    fence();
+    f32x16 s0[2][2], s1[2][2];
+// "=&v": an 8-pass MFMA reads A/B over several passes, so D must not share registers with them (hipcc marks its own
+// MFMAs early-clobber for the same reason)
+#define W4_MFMA0(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(D) : "v"(A), "a"(B))
+#define W4_MFMA_S(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "a"(B))
+#define W4_MFMA_O(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B))
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const u32x4 kf0 = lds_read16(kring + kt * 32 * 256 + k_off[ks]);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                if (ks == 0) W4_MFMA0(s0[qb][kt], kf0, qf[qb][0]);
+                else W4_MFMA_S(s0[qb][kt], kf0, qf[qb][ks]);
+            }
+        }
+    __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // S(0) is read by VALU code below: cover the MFMA -> VALU wait states
+
+    // ---- one interval: tile t lives in `sc`; S(t+1) is produced into `sn`; K(t+2) and V(t+1) are staged
+    u32x4 pf[2][4];
+    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], int kslot_next, int vslot, int t) __attribute__((always_inline)) {
+        const char* kb = kring + kslot_next * kKTileBytes;
+        const char* vb = smem + vslot * kVTileBytes;          // + v_off (which carries the V ring base)
+        u32x4 kfr[4], vfr[4];
+        const __amdgpu_buffer_rsrc_t rk = k_rsrc(t + 2), rv = v_rsrc(t + 1);
+        float e[64];
+        float ps0 = 0.f, ps1 = 0.f;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define RDK(f) kfr[(f) & 3] = lds_read16(kb + ((f) & 1) * 32 * 256 + k_off[(f) >> 1])
+#define RDV(f) vfr[(f) & 3] = lds_read16(vb + ((f) & 3) * 32 * 128 + v_off[(f) >> 2])
+#define QK(qb, kt, ks, f) do { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } while (0)
+#define PV(qb, dt, tt, f) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf[qb][tt])
+#define G(j) do { if ((j) < 4) stage_k_piece(rk, t + 2, (j)); else stage_v_piece(rv, t + 1, (j) - 4); } while (0)
+#define E(i) e[i] = __builtin_amdgcn_exp2f(sc[(i) >> 5][((i) >> 4) & 1][(i) & 15])
+#define A(i) do { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } while (0)
+#define C(w) pf[(w) >> 4][((w) >> 2) & 3][(w) & 3] = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1])
+#include "attn_w4_sched.inc"
+#undef RDK
+#undef RDV
+#undef QK
+#undef PV
+#undef G
+#undef E
+#undef A
+#undef C
+        l_run[0] += ps0;
+        l_run[1] += ps1;
+    };
+    const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
+    int it = 0;
+    bool last_in_s1 = false;
+    for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
+        interval(s0, s1, 1, 0, it);
+        fence();
+        interval(s1, s0, 0, 1, it + 1);
+        fence();
+    }
+    if (it < nfull) {
+        interval(s0, s1, 1, 0, it);
+        fence();
+        ++it;
+        last_in_s1 = true;
+    }
+    // ---- peeled last tile (it == nkv - 1): mask keys >= Lk, no staging, no next S
+    {
+        const int kv0 = it * kKV;
+        const char* vb = smem + (it & 1) * kVTileBytes;
+        if (last_in_s1) {                                  // value copies (a select of array lvalues would pin both in memory)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) s0[qb][kt] = s1[qb][kt];
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 sl = s0[qb][kt];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= Lk) sl[r] = -INFINITY;
+                }
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    float p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(sl[8 * t2 + j]); psum += p[j]; }
+                    u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+                    pf[qb][2 * kt + t2] = w;
+                }
+            }
+            l_run[qb] += psum;
+        }
+        SB();
+        asm volatile("s_nop 1" ::: "memory");             // VALU-written P fragments -> MFMA B operand
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x4 vf0 = lds_read16(vb + dt * 32 * 128 + v_off[tt]);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) W4_MFMA_O(o[qb][dt], vf0, pf[qb][tt]);
+            }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' D -> the accumulator reads below
+    }
+#undef SB
+#undef W4_MFMA0
+#undef W4_MFMA_S
+#undef W4_MFMA_O
+
+    bool ok = true;
+    float inv[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        ok = ok && ((l_tot >= 0x1p-90f && l_tot <= 0x1p100f) || qrow[qb] >= a.Lq);     // NaN fails both comparisons
+        inv[qb] = 1.0f / l_tot;
+    }
+    const int bad = __syncthreads_or(!ok);
+    if (tid == 0) a.flags[wg_linear] = bad;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (qrow[qb] >= a.Lq) continue;
+        bf16_t* op = O + (int64_t)qrow[qb] * a.ldo + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w = {pack_bf16x2(o[qb][dt][4 * g + 0] * inv[qb], o[qb][dt][4 * g + 1] * inv[qb]),
+                           pack_bf16x2(o[qb][dt][4 * g + 2] * inv[qb], o[qb][dt][4 * g + 3] * inv[qb])};
+                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+            }
+    }
+}
+
 // merge the nsplit partial results of the tail rows: out = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
 __global__ __launch_bounds__(kD) void attn_combine_kernel(AttnArgs a) {
     const int row = blockIdx.x, head = blockIdx.y, batch = blockIdx.z, d = threadIdx.x;
@@ -635,7 +911,8 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 1>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 1>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 2>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 2>)};
+                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 2>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 2>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1>)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
             if (e != hipSuccess) {
@@ -688,7 +965,10 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     const int64_t nwg = (int64_t)a.nqb * a.nbh;
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     dim3 grid((unsigned)nwg);
-    if (pre && fast) {
+    if (pre && fast && wan_tune(WAN_TUNE_ATTN_W4) != 0) {
+        if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0>), grid, dim3(kW4Threads), kLdsBytesV2, st, a);
+        else hipLaunchKernelGGL((attn_fwd_w4_kernel<1>), grid, dim3(kW4Threads), kLdsBytesV2, st, a);
+    } else if (pre && fast) {
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 1>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 1>), grid, block, kLdsBytesV2, st, a);
     } else if (pre) {

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIn* __restrict__ x
 template <typename TOut>
 __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ tok, int64_t ldt,
                                                          TOut* __restrict__ out, int Cout, int Fp, int Hp, int Wp,
-                                                         int pt, int ph, int pw) {
+                                                         int pt, int ph, int pw, int zero_frames) {
     // one thread per OUTPUT element (coalesced writes along W); 'fhwpqrc->cfphqwr'
     const int F = Fp * pt, H = Hp * ph, W = Wp * pw;
     const int64_t total = (int64_t)Cout * F * H * W;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict
         const int wq = w / pw, d = w - wq * pw;
         const int64_t t = ((int64_t)fq * Hp + hq) * Wp + wq;
         const int col = ((a * ph + b) * pw + d) * Cout + c;
-        out[i] = (TOut)tok[t * ldt + col];
+        out[i] = f < zero_frames ? (TOut)0.f : (TOut)tok[t * ldt + col];    // CoF mask (pipeline_wan.py:736), no token read
     }
 }
 
@@ -72,20 +72,22 @@ extern "C" wan_status_t wan_patchify(const void* latent, int in_dtype, void* tok
 }
 
 extern "C" wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
-                                       int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, void* stream) {
+                                       int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, int zero_frames,
+                                       void* stream) {
     WAN_REQUIRE(tokens && out, WAN_ERR_INVALID, "wan_unpatchify: null tensor");
     WAN_REQUIRE(Cout > 0 && F > 0 && Hp > 0 && Wp > 0 && pt > 0 && ph > 0 && pw > 0, WAN_ERR_INVALID, "wan_unpatchify: bad shape");
     WAN_REQUIRE(ldt >= (int64_t)Cout * pt * ph * pw, WAN_ERR_INVALID, "wan_unpatchify: ldt too small");
     WAN_REQUIRE(out_dtype == 0 || out_dtype == 1, WAN_ERR_INVALID, "wan_unpatchify: out_dtype=%d", out_dtype);
+    WAN_REQUIRE(zero_frames >= 0, WAN_ERR_INVALID, "wan_unpatchify: zero_frames=%d", zero_frames);
     const int64_t total = (int64_t)Cout * F * pt * Hp * ph * Wp * pw;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == 0)
         hipLaunchKernelGGL(unpatchify_kernel<float>, dim3(blocks), dim3(256), 0, s, tokens, ldt, (float*)out,
-                           Cout, F, Hp, Wp, pt, ph, pw);
+                           Cout, F, Hp, Wp, pt, ph, pw, zero_frames);
     else
         hipLaunchKernelGGL(unpatchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, tokens, ldt, (bf16_t*)out,
-                           Cout, F, Hp, Wp, pt, ph, pw);
+                           Cout, F, Hp, Wp, pt, ph, pw, zero_frames);
     WAN_CHECK_LAUNCH("wan_unpatchify");
     return WAN_OK;
 }

@@ -1,0 +1,87 @@
+"""hipGraph replay of the DiT forward (the loop of pipeline_wan.py:694-740).
+
+One denoise step launches ~15 kernels per layer (600 at 40 layers) plus torch glue; at the 14B / 67k-token shape that
+is 0.1 % of a 4.4 s step, at small shapes (BASELINE configs[0], the 1.3B model) it is most of the step.
+``GraphedForward`` captures ``WanTransformer3DModel.forward`` -- every HIP kernel of libwan_hip.so is enqueued on
+torch's current stream, so stream capture records them like torch's own kernels -- for one call shape and replays it
+with new latents / timestep / prompt:
+
+* latents and timestep live in static buffers that are overwritten before each replay;
+* the step-invariant text K/V are hoisted (``cache_context``) and recomputed EAGERLY, in place, when the prompt changes,
+  so the graph never contains them and stays valid across prompts of the same batch size;
+* activation workspaces and the attention scratch are the model's cached buffers (fixed addresses);
+* the CoF mask is part of the captured unpatchify kernel (``mask_source_frames``).
+
+A replay executes the same kernels with the same arguments in the same order as the eager call: the result is
+bit-identical (``tests/test_gpu_dit.py::test_graph_replay_is_bit_identical``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+__all__ = ["GraphedForward"]
+
+
+class _Entry:
+    __slots__ = ("x", "t", "graph", "out", "calls", "kv")
+
+
+class GraphedForward:
+    """Callable with the signature of ``WanTransformer3DModel.forward`` (T2V / CoF arguments)."""
+
+    def __init__(self, model, warmup_calls: int = 1):
+        if model.sp_world_size != 1:
+            raise NotImplementedError("graph capture covers the single-device forward (collectives stay eager)")
+        self.model = model
+        self.warmup_calls = max(1, int(warmup_calls))
+        self._entries: Dict[tuple, _Entry] = {}
+        self.replays = 0
+
+    def reset(self) -> None:
+        self._entries.clear()
+
+    @torch.no_grad()
+    def __call__(self, x, t, context, seq_len, frame_split_indices=None, ground_frame_indices=None, **kw):
+        m = self.model
+        if any(v is not None for v in kw.values()):
+            raise NotImplementedError("graph capture supports the T2V / CoF arguments only")
+        if isinstance(x, (list, tuple)):
+            x = torch.stack(list(x))
+        key = (tuple(x.shape), x.dtype, int(seq_len), tuple(frame_split_indices or ()),
+               tuple(tuple(g) for g in (ground_frame_indices or ())), int(m.skip_source_frames),
+               int(m.mask_source_frames), len(context), torch.cuda.current_device())
+        ent = self._entries.get(key)
+        if ent is None:
+            ent = self._entries[key] = _Entry()
+            ent.x, ent.t = torch.empty_like(x), torch.empty(x.shape[0], device=x.device, dtype=torch.int64)
+            ent.graph, ent.out, ent.calls, ent.kv = None, None, 0, None
+        ent.x.copy_(x)
+        ent.t.copy_(t.reshape(-1).to(torch.int64).expand(x.shape[0]))
+        prev = m.cache_context
+        m.cache_context = True
+        try:
+            # eager, outside the graph; in place (into the buffers the graph reads) when the prompt changed or the
+            # model's cache was cleared in between
+            ent.kv = m._hoisted_context(context, x.shape[0], into=ent.kv)
+            args = (ent.x, ent.t, context, seq_len)
+            kwargs = dict(frame_split_indices=frame_split_indices, ground_frame_indices=ground_frame_indices)
+            if ent.graph is None:
+                ent.calls += 1
+                if ent.calls <= self.warmup_calls:           # eager: allocates workspaces, sets kernel attributes
+                    return m(*args, **kwargs)
+                events, m._attn_events = m._attn_events, None
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(graph):
+                        ent.out = m(*args, **kwargs)
+                finally:
+                    m._attn_events = events
+                ent.graph = graph
+            ent.graph.replay()
+            self.replays += 1
+            return ent.out.clone()
+        finally:
+            m.cache_context = prev

@@ -281,8 +281,9 @@ def patchify(latent: torch.Tensor, patch: Tuple[int, int, int], out: Optional[to
 
 @_on_tensor_device
 def unpatchify(tokens: torch.Tensor, grid: Tuple[int, int, int], patch: Tuple[int, int, int], cout: int,
-               out_dtype: torch.dtype) -> torch.Tensor:
-    """tokens fp32 [L, pt*ph*pw*Cout] -> [Cout, F*pt, Hp*ph, Wp*pw] in out_dtype (fp32|bf16)."""
+               out_dtype: torch.dtype, zero_frames: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tokens fp32 [L, pt*ph*pw*Cout] -> [Cout, F*pt, Hp*ph, Wp*pw] in out_dtype (fp32|bf16); output frames
+    < zero_frames are written as zeros (the CoF mask of pipeline_wan.py:736)."""
     _need(tokens, torch.float32, "unpatchify.tokens")
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise ValueError(f"unpatchify: out dtype {out_dtype} not supported")
@@ -290,10 +291,15 @@ def unpatchify(tokens: torch.Tensor, grid: Tuple[int, int, int], patch: Tuple[in
     pt, ph, pw = patch
     if tokens.shape[0] < F * Hp * Wp:
         raise ValueError("unpatchify: fewer token rows than the grid")
-    out = torch.empty(cout, F * pt, Hp * ph, Wp * pw, device=tokens.device, dtype=out_dtype)
+    shape = (cout, F * pt, Hp * ph, Wp * pw)
+    if out is None:
+        out = torch.empty(shape, device=tokens.device, dtype=out_dtype)
+    _need(out, out_dtype, "unpatchify.out")
+    if tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError(f"unpatchify: out must be contiguous {shape}")
     lib = _lib.load()
     _lib.check(lib.wan_unpatchify(_p(tokens), tokens.stride(0), _p(out), 0 if out_dtype == torch.float32 else 1,
-                                  cout, F, Hp, Wp, pt, ph, pw, _stream()), "wan_unpatchify")
+                                  cout, F, Hp, Wp, pt, ph, pw, int(zero_frames), _stream()), "wan_unpatchify")
     return out
 
 

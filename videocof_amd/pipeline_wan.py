@@ -51,6 +51,7 @@ class WanPipeline:
         self._guidance_scale = 1.0
         self._num_timesteps = 0
         self._interrupt = False
+        self._graphed = None
 
     guidance_scale = property(lambda self: self._guidance_scale)
     num_timesteps = property(lambda self: self._num_timesteps)
@@ -159,7 +160,7 @@ class WanPipeline:
                  # extensions of this package (keyword-only in spirit; the names above are the reference's, :516-548)
                  source_latents: Optional[torch.Tensor] = None, device=None,
                  weight_dtype: torch.dtype = torch.bfloat16, cache_context: bool = True,
-                 skip_source_prediction: bool = True):
+                 skip_source_prediction: bool = True, capture_graph: bool = False):
         if timesteps is not None:
             raise NotImplementedError("custom `timesteps` are not supported (the reference's CLIs never pass them)")
         if num_videos_per_prompt != 1:
@@ -204,6 +205,19 @@ class WanPipeline:
             # noise_pred[:, :, :condition_count] is zeroed below (:736): the last block need not produce it
             self.transformer.skip_source_frames = condition_count if skip_source_prediction else 0
 
+        # the CoF mask of :736 on the device: the unpatchify kernel writes zeros for the source frames
+        prev_mask = getattr(self.transformer, "mask_source_frames", None)
+        if prev_mask is not None:
+            self.transformer.mask_source_frames = condition_count
+        forward = self.transformer
+        if capture_graph:
+            # one hipGraph per call shape, kept across calls (videocof_amd/graph.py): step 0 of the first call runs
+            # eagerly, step 1 is captured, every later step (and call) is a replay -- bit-identical latents
+            if self._graphed is None or self._graphed.model is not self.transformer:
+                from .graph import GraphedForward
+                self._graphed = GraphedForward(self.transformer)
+            forward = self._graphed
+
         try:
             for i, t in enumerate(timesteps):                                                   # :694
                 self.transformer.current_steps = i
@@ -224,13 +238,15 @@ class WanPipeline:
                     fsi = [condition_count] * nb                                                # :713
                     if cot:
                         gfi = [(condition_count, condition_count + ground_latent_count)] * nb  # :716-718
-                noise_pred = self.transformer(x=latent_model_input, context=in_prompt_embeds, t=timestep,
-                                              seq_len=seq_len, frame_split_indices=fsi,
-                                              ground_frame_indices=gfi)                         # :721-728
+                noise_pred = forward(x=latent_model_input, context=in_prompt_embeds, t=timestep,
+                                     seq_len=seq_len, frame_split_indices=fsi,
+                                     ground_frame_indices=gfi)                                  # :721-728
                 if do_cfg:
                     nu, nt = noise_pred.chunk(2)
                     noise_pred = nu + self.guidance_scale * (nt - nu)                           # :731-733
-                noise_pred[:, :, :condition_count] = 0                                          # :736
+                if prev_mask is None:
+                    noise_pred[:, :, :condition_count] = 0                                      # :736
+                # else: already zero -- written by wan_unpatchify(zero_frames); CFG keeps it (0 + s * (0 - 0))
                 latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]     # :740
                 if callback_on_step_end is not None:
                     out = callback_on_step_end(self, i, t, {"latents": latents})
@@ -243,6 +259,8 @@ class WanPipeline:
                 self.transformer.clear_context_cache()        # releases the hoisted K/V^T and the prompt embeddings
             if hasattr(self.transformer, "skip_source_frames"):
                 self.transformer.skip_source_frames = prev_skip
+            if prev_mask is not None:
+                self.transformer.mask_source_frames = prev_mask
 
         # -- decode (:757-790)
         ground_video = edit_video = video_out = None

@@ -123,6 +123,10 @@ class WanTransformer3DModel(nn.Module):
         # the head run only on the remaining tokens' query rows -- their keys/values still cover every token --
         # and the discarded frames come back as zeros.  Parity neutral for the pipeline.
         self.skip_source_frames = 0
+        # The CoF mask itself on the device: output frames [0, mask_source_frames) are written as zeros by the
+        # unpatchify kernel (wan_unpatchify's zero_frames) instead of a separate slice-assign on the result
+        # (`noise_pred[:, :, :condition_count] = 0`, pipeline_wan.py:736).  0 = plain forward.
+        self.mask_source_frames = 0
         # one attention scratch per call site: the sticky "max-free attempt off" word of one site never reaches another
         self._ws_self, self._ws_cross = ops.AttentionWorkspace(), ops.AttentionWorkspace()
         self._probe_layer = None            # bench.py / tests: keep a copy of the residual stream entering this block
@@ -333,14 +337,39 @@ class WanTransformer3DModel(nn.Module):
         hid = ops.gemm(ctx, w["te_w0"], w["te_b0"], ops.EPI_GELU_BF16)
         return ops.gemm(hid, w["te_w2"], w["te_b2"], ops.EPI_BF16)       # [B*512, C]
 
-    def _context_kv(self, blk: _Block, ctx: torch.Tensor, B: int):
+    def _context_kv(self, blk: _Block, ctx: torch.Tensor, B: int, out=None):
+        """k [B, text_len, C] (RMS-normed) and v^T [B, C, text_len] of the text tokens (:321-322); `out` = an earlier
+        result of the same batch size to overwrite in place (stable addresses for a captured graph)."""
         C, T = self.dim, self.text_len
-        ck = ops.gemm(ctx, blk.w_ck, blk.b_ck, ops.EPI_BF16)
+        ck, cvt = out if out is not None else (None, None)
+        ck = ops.gemm(ctx, blk.w_ck, blk.b_ck, ops.EPI_BF16, out=None if ck is None else ck.view(B * T, C))
         ops.rmsnorm_rope_(ck, blk.nck, None, None, self.d, self.eps)
-        cvt = torch.empty(B, C, T, device=self._device, dtype=torch.bfloat16)
+        if cvt is None:
+            cvt = torch.empty(B, C, T, device=self._device, dtype=torch.bfloat16)
         for b in range(B):
             ops.gemm(ctx[b * T:(b + 1) * T], blk.w_cv, blk.b_cv, ops.EPI_BF16_T, out=cvt[b])
         return ck.view(B, T, C), cvt
+
+    def _hoisted_context(self, context, B, into=None):
+        """Step-invariant text K/V of every block (cache_context), keyed by the IDENTITY of the context tensors; the
+        entry keeps them alive, so a freed prompt buffer whose address the allocator hands to the next prompt can never
+        match (tensors written by the ctypes kernels all carry _version 0, so (data_ptr, shape, version) is no key).
+        On a miss the K/V of the previous prompt (same batch size) -- or the buffers `into`, which a captured graph
+        reads -- are overwritten in place."""
+        vers = tuple(u._version for u in context)
+        if self._ctx_cache is not None:
+            held, v0, kv = self._ctx_cache
+            if (len(held) == len(context) and all(a is b for a, b in zip(held, context)) and v0 == vers
+                    and (into is None or kv is into)):
+                return kv
+        old = into
+        if old is None and self._ctx_cache is not None and self._ctx_cache[2][0][0].shape[0] == B:
+            old = self._ctx_cache[2]
+        self._ctx_cache = None
+        ctx = self._text_embed(context)
+        kv = [self._context_kv(blk, ctx, B, out=None if old is None else old[i]) for i, blk in enumerate(self.blocks)]
+        self._ctx_cache = (list(context), vers, kv)
+        return kv
 
     def _last_block_suffix(self, blk, em, xs, h, qk, vt, att, cq, ff, ctx_kv, rp, r0, L):
         """The last WanAttentionBlock for B = 1 when only rows >= r0 feed the output: K / V^T are built
@@ -544,23 +573,12 @@ class WanTransformer3DModel(nn.Module):
         emod = (w["mod_all"][:, None] + e0[None]).permute(0, 2, 1, 3).contiguous()      # [layers, 6, B, C]
         ehead = (w["head_mod"][None] + e[:, None]).permute(1, 0, 2).contiguous()         # [2, B, C]
 
-        # The hoisted text K/V are keyed by the IDENTITY of the context tensors, and the cache entry keeps them alive:
-        # a freed prompt buffer whose address the allocator hands to the next prompt can therefore never match
-        # (tensors written by the ctypes kernels all carry _version 0, so (data_ptr, shape, version) is not a key).
-        hit = False
-        if self.cache_context and self._ctx_cache is not None:
-            held, vers, _ = self._ctx_cache
-            hit = (len(held) == len(context) and all(a is b for a, b in zip(held, context))
-                   and vers == tuple(u._version for u in context))
-        if hit:
-            ctx_kv = self._ctx_cache[2]
+        if self.cache_context:
+            ctx_kv = self._hoisted_context(context, B)
         else:
             self._ctx_cache = None
             ctx = self._text_embed(context)
             ctx_kv = [None] * self.num_layers
-            if self.cache_context:
-                ctx_kv = [self._context_kv(blk, ctx, B) for blk in self.blocks]
-                self._ctx_cache = (list(context), tuple(u._version for u in context), ctx_kv)
 
         # -- patch embedding into the fp32 residual stream (this rank's token rows only) --------
         xs = torch.zeros(M, C, device=dev, dtype=torch.float32)
@@ -601,5 +619,8 @@ class WanTransformer3DModel(nn.Module):
         if P > 1:
             yt = self._sp.all_gather_tokens(yt)                                        # :1085-1086
         out_dtype = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
-        outs = [ops.unpatchify(yt[b], grid, self.patch_size, self.out_dim, out_dtype) for b in range(B)]
-        return torch.stack(outs).to(dtype)
+        out = torch.empty(B, self.out_dim, grid[0] * pt, grid[1] * ph, grid[2] * pw, device=dev, dtype=out_dtype)
+        for b in range(B):
+            ops.unpatchify(yt[b], grid, self.patch_size, self.out_dim, out_dtype,
+                           zero_frames=min(int(self.mask_source_frames), grid[0]) * pt, out=out[b])
+        return out.to(dtype)
