@@ -506,6 +506,16 @@ constexpr int kW4Threads = 256;
 
 __device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 
+// Pipeline: K(t+2) / V(t+1) are requested (LDS-DMA) during the S segment of interval t and waited for (vmcnt(0) + barrier)
+// at its end; rings K 2 x 16 KiB + V 2 x 16 KiB, as in the 8-wave kernel.  Measured alternative that did not pay
+// (profiles/r02/attn_w4_ab.log): requesting K(t+3) / V(t+2) in the PV segment, waiting for them at ONE barrier between the two
+// segments of the next interval (V ring of 3) and fetching the first K fragments of an interval before the previous one
+// ends -- no LDS latency exposed at the seam -- 68.7 vs 68.5 ms: the seam is not where the time goes.
+// Also without effect: moving one softmax micro-op between the two slots of a fragment pair (gaps of 3|4 instead of 2|5
+// fillers): 66.9 vs 66.8 ms.  At 85 % matrix-pipe occupancy the kernel sits on the chip's power limit (sustained clock
+// 1.66 GHz, profiles/r02/attn_w4_pmc.json); what is left is energy per tile, not issue slots.
+constexpr int kLdsBytesW4 = 2 * kKTileBytes + 2 * kVTileBytes;
+
 template <int VARIANT>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {
@@ -572,15 +582,15 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)K + tc * k_tile_bytes), 0,
                                                  (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
-    auto v_rsrc = [&](int t) {          // t <= nkv - 1 always; V^T pad columns exist up to roundup(Lk, 64)
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)t * kKV * 2), 0, 0x7fffffff, 0x00020000);
+    auto v_rsrc = [&](int t) {          // tile min(t, nkv-1) (t <= nkv - 1 on every call); V^T pad columns exist up to roundup(Lk, 64)
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)min(t, nkv - 1) * kKV * 2), 0, 0x7fffffff, 0x00020000);
     };
-    auto stage_k_piece = [&](__amdgpu_buffer_rsrc_t r, int t, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kring + (t & 1) * kKTileBytes + (wid * 4 + j) * 1024),
+    auto stage_k_piece = [&](__amdgpu_buffer_rsrc_t r, int kslot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kring + kslot * kKTileBytes + (wid * 4 + j) * 1024),
                                                  16, k_voff[j], 0, 0, 0);
     };
-    auto stage_v_piece = [&](__amdgpu_buffer_rsrc_t r, int t, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + 2 * kKTileBytes + (t & 1) * kVTileBytes + (wid * 4 + j) * 1024),
+    auto stage_v_piece = [&](__amdgpu_buffer_rsrc_t r, int vslot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + 2 * kKTileBytes + vslot * kVTileBytes + (wid * 4 + j) * 1024),
                                                  16, v_voff[j], 0, 0, 0);
     };
 
@@ -636,24 +646,48 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // S(0) is read by VALU code below: cover the MFMA -> VALU wait states
 
-    // ---- one interval: tile t lives in `sc`; S(t+1) is produced into `sn`; K(t+2) and V(t+1) are staged
-    u32x4 pf[2][4];
-    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], int kslot_next, int vslot, int t) __attribute__((always_inline)) {
+    // ---- softmax bookkeeping.  The 160 micro-ops of a tile run as one continuous stream of 2.5 per MFMA slot that starts in
+    // the PV segment of the PREVIOUS interval (P fragments tt = 0, 1 -> `pn`, their row sums -> `carry`) and ends in the S
+    // segment of the tile's own interval (tt = 2, 3 -> `pf23`).  pa / pb ping-pong between "consumed now" and "produced for
+    // the next tile"; tile 0's first half is produced here.
+    u32x4 pa[2][2], pb[2][2], pf23[2][2];
+    float carry[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(s0[qb][0][8 * tt + j]); carry[qb] += p[j]; }
+            u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+            pa[qb][tt] = w;
+        }
+
+    // ---- one interval: tile t lives in `sc` (its P fragments 0, 1 in `pc`); S(t+1) is produced into `sn` and its P
+    // fragments 0, 1 into `pn`; K(t+2) and V(t+1) are staged.  kslot_next = (t + 1) & 1 and vslot = t & 1 are literals at
+    // every call site, so every ds_read address is a loop-invariant VGPR + an immediate.
+    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], u32x4 (&pn)[2][2], int kslot_next, int vslot,
+                        int t) __attribute__((always_inline)) {
         const char* kb = kring + kslot_next * kKTileBytes;
         const char* vb = smem + vslot * kVTileBytes;          // + v_off (which carries the V ring base)
         u32x4 kfr[4], vfr[4];
         const __amdgpu_buffer_rsrc_t rk = k_rsrc(t + 2), rv = v_rsrc(t + 1);
         float e[64];
-        float ps0 = 0.f, ps1 = 0.f;
+        float ps0 = carry[0], ps1 = carry[1];                // this tile's row sums so far (first key half)
+        float cn0 = 0.f, cn1 = 0.f;                           // the next tile's
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define RDK(f) kfr[(f) & 3] = lds_read16(kb + ((f) & 1) * 32 * 256 + k_off[(f) >> 1])
 #define RDV(f) vfr[(f) & 3] = lds_read16(vb + ((f) & 3) * 32 * 128 + v_off[(f) >> 2])
-#define QK(qb, kt, ks, f) do { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } while (0)
-#define PV(qb, dt, tt, f) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf[qb][tt])
-#define G(j) do { if ((j) < 4) stage_k_piece(rk, t + 2, (j)); else stage_v_piece(rv, t + 1, (j) - 4); } while (0)
-#define E(i) e[i] = __builtin_amdgcn_exp2f(sc[(i) >> 5][((i) >> 4) & 1][(i) & 15])
-#define A(i) do { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } while (0)
-#define C(w) pf[(w) >> 4][((w) >> 2) & 3][(w) & 3] = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1])
+// the MFMA is pinned at the head of its slot (a sched_barrier on both sides): left free, hipcc sinks the fillers of every
+// other slot above their MFMA, which pairs the MFMAs up (gap 0) and doubles the fillers of the next gap (8-10 > the ~5 that hide)
+#define QK(qb, kt, ks, f) do { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); SB(); } while (0)
+#define PV(qb, dt, tt, f) do { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); SB(); } while (0)
+#define G(j) do { if ((j) < 4) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 4); } while (0)
+// score i = 32 qb + 8 tt + j: tt >= 2 reads the current tile (key half kt = 1), tt < 2 the next tile (kt = 0)
+#define E(i) e[i] = __builtin_amdgcn_exp2f((((i) >> 4) & 1) ? sc[(i) >> 5][1][(i) & 15] : sn[(i) >> 5][0][(i) & 15])
+#define A(i) do { if (((i) >> 4) & 1) { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } else { if ((i) < 32) cn0 += e[i]; else cn1 += e[i]; } } while (0)
+#define C(w) do { const unsigned pk_ = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1]); \
+                  if (((w) >> 3) & 1) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; else pn[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; } while (0)
 #include "attn_w4_sched.inc"
 #undef RDK
 #undef RDV
@@ -665,24 +699,29 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #undef C
         l_run[0] += ps0;
         l_run[1] += ps1;
+        carry[0] = cn0;
+        carry[1] = cn1;
     };
+
     const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
     int it = 0;
     bool last_in_s1 = false;
     for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
-        interval(s0, s1, 1, 0, it);
+        interval(s0, s1, pa, pb, 1, 0, it);
         fence();
-        interval(s1, s0, 0, 1, it + 1);
+        interval(s1, s0, pb, pa, 0, 1, it + 1);
         fence();
     }
     if (it < nfull) {
-        interval(s0, s1, 1, 0, it);
+        interval(s0, s1, pa, pb, 1, 0, it);
         fence();
         ++it;
         last_in_s1 = true;
     }
-    // ---- peeled last tile (it == nkv - 1): mask keys >= Lk, no staging, no next S
+    // ---- peeled last tile (it == nkv - 1): mask keys >= Lk, no staging, no next S.  All four P fragments are recomputed
+    // here with the mask (the first two that the last interval produced ahead of time, and `carry`, are dropped).
     {
+        u32x4 pf[2][4];
         const int kv0 = it * kKV;
         const char* vb = smem + (it & 1) * kVTileBytes;
         if (last_in_s1) {                                  // value copies (a select of array lvalues would pin both in memory)
@@ -966,8 +1005,8 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     dim3 grid((unsigned)nwg);
     if (pre && fast && wan_tune(WAN_TUNE_ATTN_W4) != 0) {
-        if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0>), grid, dim3(kW4Threads), kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_w4_kernel<1>), grid, dim3(kW4Threads), kLdsBytesV2, st, a);
+        if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0>), grid, dim3(kW4Threads), kLdsBytesW4, st, a);
+        else hipLaunchKernelGGL((attn_fwd_w4_kernel<1>), grid, dim3(kW4Threads), kLdsBytesW4, st, a);
     } else if (pre && fast) {
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 1>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 1>), grid, block, kLdsBytesV2, st, a);
