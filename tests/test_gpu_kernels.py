@@ -540,3 +540,37 @@ def test_lincomb_and_fused_unipc(golden):
     for i, t in enumerate(s.timesteps):
         cur = s.step(torch.from_numpy(gg["v"][i]).to(DEV), t, cur, return_dict=False)[0]
         assert rel_l2(cur, gg["traj"][i]) < 2e-6
+
+
+@pytest.mark.parametrize("w4", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(1100, 520, 512), (2048, 256, 128), (1500, 1536, 1024)])
+def test_gemm_256_tile_kernels_all_epilogues(M, N, K, w4):
+    """Both 256^2 kernels (8-wave phased, 4-wave with AGPR accumulators) on ragged M / N with K % 128 == 0: every epilogue
+    against an fp64 product of the same bf16 operands."""
+    g = torch.Generator().manual_seed(M + N + K + w4)
+    a, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g) * 0.5
+    gate = torch.randn(2, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    acc = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    ops.set_tuning("gemm_variant", 2)
+    ops.set_tuning("gemm_w4", w4)
+    try:
+        o_bf = ops.gemm(ad, wd, bd, ops.EPI_BF16)
+        o_ge = ops.gemm(ad, wd, bd, ops.EPI_GELU_BF16)
+        o_f32 = ops.gemm(ad, wd, bd, ops.EPI_F32)
+        o_res = resid.to(DEV).clone()
+        rpb = (M + 1) // 2
+        ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=o_res, gate=gate.to(DEV), rows_per_batch=rpb)
+        o_t = ops.gemm(ad, wd, bd, ops.EPI_BF16_T)
+    finally:
+        ops.set_tuning("gemm_variant", 0)
+        ops.set_tuning("gemm_w4", 2)
+    assert rel_l2(o_bf, acc) < 4e-3 and rel_l2(o_f32, acc) < 1e-5
+    x = acc.float().double()
+    assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3
+    gsel = gate.double()[torch.arange(M) // rpb]
+    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
+    assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc) < 4e-3
+    assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True

@@ -172,12 +172,12 @@ static void check_rmsnorm_rope() {
 }
 
 static void check_gemm() {
-  for (const char* var : {"1", "2", "2p4"}) {
-    setenv("WAN_GEMM_VARIANT", var[0] == '1' ? "1" : "2", 1);
-    setenv("WAN_GEMM_PHASES", strlen(var) > 1 ? "4" : "2", 1);
+  for (const char* var : {"1", "2", "2w"}) {       // 1 = 128^2, 2 = 256^2 8-wave phased, 2w = 256^2 4-wave (K % 128 == 0 shapes)
+    WAN(wan_set_tuning("gemm_variant", var[0] == '1' ? 1 : 2));
+    WAN(wan_set_tuning("gemm_w4", strlen(var) > 1 ? 1 : 0));
     printf("wan_gemm_bf16 variant %s\n", var);
     struct Shape { int M, N, K; };
-    for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}, Shape{1100, 520, 448}}) {
+    for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}, Shape{1100, 520, 448}, Shape{1100, 520, 512}}) {
         const int M = sh.M, N = sh.N, K = sh.K;
         auto A = bf_round(randn((size_t)M * K)), W = bf_round(randn((size_t)N * K, 0.1f));
         auto bias = randn(N, 0.5f);
@@ -370,14 +370,14 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
         Dev<char> out(osz); out.zero();
         for (int round = 0; round < 2; ++round)
-        for (const char* var : {"1", "2", "2p4"}) {
+        for (const char* var : {"1", "2", "2w"}) {           // 1 = 128^2 kernel, 2 = 256^2 8-wave phased, 2w = 256^2 4-wave
             WAN(wan_set_tuning("gemm_variant", var[0] == '1' ? 1 : 2));
-            WAN(wan_set_tuning("gemm_phases", strlen(var) > 1 ? 4 : 2));
+            WAN(wan_set_tuning("gemm_w4", strlen(var) > 1 ? 1 : 0));
             double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
                                                         g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
             printf("  gemm[v%s] %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", var, g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
         }
-        WAN(wan_set_tuning("gemm_variant", 0)); WAN(wan_set_tuning("gemm_phases", 0));
+        WAN(wan_set_tuning("gemm_variant", 0)); WAN(wan_set_tuning("gemm_w4", 2));
     }
     struct A_ { int Lq, Lk, H; const char* what; };
     if (gemm_only) return;

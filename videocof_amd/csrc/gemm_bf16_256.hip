@@ -28,6 +28,8 @@
 // shape (profiles/r01/gemm_mfma32x32_ab.log).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -313,6 +315,252 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     }
 }
 
+// ====================================================================================================
+// 4-wave variant of the same 256 x 256 x 64 tile: one wave per SIMD with the whole 512-register file.
+//
+//   * a wave owns 128 x 128 outputs = 4 x 4 MFMA 32x32x16 tiles = 256 accumulator registers: 192 in AGPRs, 64 in VGPRs
+//     (the MFMAs are inline asm so that C/D can be named in either file while A/B come from VGPRs; hipcc's own allocation
+//     of a 256-register accumulator tile does not fit the 256 arch VGPRs);
+//   * per 16-deep k-step a wave reads 4 A + 4 W fragments (ds_read_b128) for 16 MFMAs -- 0.5 LDS reads per MFMA of 32
+//     cycles, against 0.375 per 16-cycle MFMA in the 8-wave kernel above -- one k-step ahead of their use;
+//   * ONE barrier per K tile, placed after k-step 2 of 4: the next K tile has been in flight since k-step 3 of the previous
+//     tile (>= 48 MFMA slots of flight time), `s_waitcnt vmcnt(0)` + `s_barrier` publish it, the fragments of its k-step 0
+//     are fetched during k-step 3 of this tile (no LDS latency exposed at the seam), and the buffer this tile occupied
+//     is handed to tile t+2 at the same barrier (every fragment of tile t has been read by then);
+//   * tiles are fetched with `buffer_load_dwordx4 ... lds`: the descriptor base advances by SALU, each lane keeps two
+//     constant byte offsets per operand, and the descriptor's range check zero-fills rows past M / N (no clamp);
+//   * the schedule is program order: `MFMA ; sched_barrier ; <= 1 filler ; sched_barrier` per slot.
+// Hazards hipcc does not see for an asm MFMA (CDNA4 guide 5.7): A/B operands only ever come from ds_read (waited for by
+// the compiler's own lgkmcnt tracking), accumulate chains are 16 MFMAs apart, and the accumulators are first read by
+// VALU code after an explicit 16-state s_nop.
+// Measured (profiles/r02/gemm_w4_ab.log): a tie with the 8-wave phased kernel at K = 5120 (1.25-1.29 PFLOP/s), +4-6 % at
+// K = 13 824, -10-15 % at K = 1536.  Unlike in attention, where the same structure gained 9 %, a GEMM K tile carries 16 LDS-DMA
+// instructions per wave for 64 MFMAs and almost nothing else: each DMA costs the wave ~60-100 cycles of issue (CDNA4 guide,
+// per-instruction constants) that a single wave per SIMD cannot hide behind a partner, which is what the two wave groups of
+// the 8-wave kernel do for each other.  Used for deep-K shapes only (see the dispatcher).
+// ====================================================================================================
+constexpr int kW4Threads = 256;
+
+__device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+template <int EPI>
+__global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
+    int tm, tn;
+    tile_coords(g, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int nk = g.K / BK;
+
+    // ---- LDS-DMA: an operand tile is 32 pieces of 1 KiB (8 rows x 128 B); wave w copies pieces 8 w .. 8 w + 7.
+    // Piece j covers rows 64 w + 8 j + lane / 8; LDS position (lane & 7) of a row holds source chunk (lane & 7) ^ ((row >> 1) & 7).
+    // Rows 8 apart differ by 4 in the swizzle, so two per-lane byte offsets (even / odd j) + a scalar row offset cover all 8.
+    int a_voff[2], w_voff[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = wid * 64 + p * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        a_voff[p] = (int)(((int64_t)row * g.lda + c * 8) * 2);
+        w_voff[p] = (int)(((int64_t)row * g.ldw + c * 8) * 2);
+    }
+    const char* a_tile = (const char*)(g.A + (int64_t)m0 * g.lda);
+    const char* w_tile = (const char*)(g.W + (int64_t)n0 * g.ldw);
+    // bytes from the tile origin (row m0, column 0) to the end of the last valid row; 0 for K tiles past the end
+    const int64_t a_bytes = ((int64_t)(min(g.M - m0, BM) - 1) * g.lda + g.K) * 2;
+    const int64_t w_bytes = ((int64_t)(min(g.N - n0, BN) - 1) * g.ldw + g.K) * 2;
+    auto rsrc = [&](const char* tile, int64_t bytes, int kt) {
+        const int64_t left = kt < nk ? bytes - (int64_t)kt * BK * 2 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)min(kt, nk - 1) * BK * 2), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
+    };
+    auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
+            operand ? w_voff[j & 1] : a_voff[j & 1], (int)((j >> 1) * 16 * ld * 2), 0, 0);
+    };
+
+    // ---- fragment reads: 32 rows x 16 k per fragment; lane = (row l31, k half hi); logical chunk 2 s + hi of a 128-B row
+    const int sw = (l31 >> 1) & 7;
+    int koff[2][4];                          // [LDS buffer][k-step]: the buffer base (64 KiB) does not fit a ds_read immediate
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) koff[b][s4] = b * kBufBytes + l31 * 128 + (((2 * s4 + hi) ^ sw) << 4);
+    const int a_base = wr * 128 * 128, w_base = kOperandBytes + wc * 128 * 128;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 af[2][4], wf[2][4];                // [k-step parity][block]
+
+#define GW4_SB() __builtin_amdgcn_sched_barrier(0)
+// 12 of the 16 accumulator tiles (192 registers) are pinned to AGPRs, the last M block (4 tiles, 64 registers) to VGPRs:
+// with all 256 AGPRs claimed by "+a" operands hipcc's allocator has no slack left and shuffles tiles through scratch.
+#define GW4_MFMA_A(ACC, X, Y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(X), "v"(Y))
+#define GW4_MFMA_V(ACC, X, Y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(X), "v"(Y))
+#define GW4_MFMA(ACC, X, Y) do { if (i < 3) GW4_MFMA_A(ACC, X, Y); else GW4_MFMA_V(ACC, X, Y); } while (0)
+    // k-step S of the K tile in LDS buffer `buf`: 16 MFMAs; the even slots fetch the fragments of the NEXT k-step (from
+    // `nbuf`, k-step NS), the odd slots of the steps that carry DMA issue one piece each.
+    auto kstep = [&](auto S_, int buf, int nbuf, auto NS_, auto DMA_, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int dbuf)
+                     __attribute__((always_inline)) {
+        constexpr int S = decltype(S_)::value, NS = decltype(NS_)::value, DMA = decltype(DMA_)::value;   // DMA: 0 none, 1 pieces 0..7 (A), 2 pieces 8..15 (W)
+        (void)buf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = i * 4 + j;
+                if constexpr (kTransposed) GW4_MFMA(acc[i][j], af[S & 1][i], wf[S & 1][j]);
+                else GW4_MFMA(acc[i][j], wf[S & 1][j], af[S & 1][i]);
+                GW4_SB();
+                if (slot % 2 == 0) {
+                    const int f = slot / 2;
+                    if (f < 4) af[NS & 1][f] = lds16(smem + a_base + f * 32 * 128 + koff[nbuf][NS]);
+                    else wf[NS & 1][f - 4] = lds16(smem + w_base + (f - 4) * 32 * 128 + koff[nbuf][NS]);
+                } else if (DMA != 0) {
+                    const int pj = slot / 2;
+                    if (DMA == 1) stage_piece(ra, dbuf, 0, pj, g.lda);
+                    else stage_piece(rw, dbuf, 1, pj, g.ldw);
+                }
+                GW4_SB();
+            }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: K tile 0 -> buffer 0 (waited for), the A half of K tile 1 -> buffer 1 (in flight), fragments of k-step 0
+    {
+        const __amdgpu_buffer_rsrc_t ra = rsrc(a_tile, a_bytes, 0), rw = rsrc(w_tile, w_bytes, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { stage_piece(ra, 0, 0, j, g.lda); stage_piece(rw, 0, 1, j, g.ldw); }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        const __amdgpu_buffer_rsrc_t ra1 = rsrc(a_tile, a_bytes, 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage_piece(ra1, 1, 0, j, g.lda);       // its W half goes out in k-step 0 of tile 0
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            af[0][f] = lds16(smem + a_base + f * 32 * 128 + koff[0][0]);
+            wf[0][f] = lds16(smem + w_base + f * 32 * 128 + koff[0][0]);
+        }
+    }
+    // K tile kt in buffer b (a literal at the call site).  DMA rule: the A pieces of tile kt+2 go out in k-step 3 of tile kt
+    // (right after the barrier that frees buffer b), its W pieces in k-step 0 of tile kt+1; both are waited for at the
+    // barrier of tile kt+1.  Requests past the last tile carry a zero-length descriptor (no memory traffic).
+    auto ktile = [&](int kt, int b) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rw_prev = rsrc(w_tile, w_bytes, kt + 1);      // W of tile kt+1 -> buffer 1-b (its A went out in tile kt-1)
+        const __amdgpu_buffer_rsrc_t ra_next = rsrc(a_tile, a_bytes, kt + 2);      // A of tile kt+2 -> buffer b, after the barrier
+        kstep(I0{}, b, b, I1{}, I2{}, ra_next, rw_prev, 1 - b);
+        kstep(I1{}, b, b, I2{}, I0{}, ra_next, rw_prev, b);
+        kstep(I2{}, b, b, I3{}, I0{}, ra_next, rw_prev, b);
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // my pieces of tile kt+1 have landed ...
+        __builtin_amdgcn_s_barrier();            // ... everybody's have, and every wave has read the last fragment of tile kt
+        GW4_SB();
+        kstep(I3{}, b, 1 - b, I0{}, I1{}, ra_next, rw_prev, b);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {          // nk is even (the dispatcher sends K % 128 != 0 to the 8-wave kernel)
+        ktile(kt, 0);
+        ktile(kt + 1, 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // zero-length requests past the last tile still write LDS: let them finish
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads of the epilogue
+#undef GW4_MFMA
+#undef GW4_MFMA_A
+#undef GW4_MFMA_V
+#undef GW4_SB
+
+    // ---- epilogue.  Swapped product (W fragment as A operand): lane (l31, hi) holds output row m = .. + l31 and, per
+    // accumulator register quad q, the 4 consecutive columns n = .. + 8 q + 4 hi .. + 3.  Transposed store: roles exchanged.
+    if constexpr (!kTransposed) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 128 + i * 32 + l31;
+            if (m >= g.M) continue;
+            const int64_t b = g.gate ? (int64_t)m / g.rows_per_batch : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wc * 128 + j * 32 + 8 * q + 4 * hi;
+                    if (n >= g.N) continue;
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    if (g.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
+                    if constexpr (EPI == WAN_EPI_GELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
+                    }
+                    if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
+                        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)m * g.ldo + n) = o;
+                    } else if constexpr (EPI == WAN_EPI_F32) {
+                        *reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        float4* p = reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n);
+                        float4 x = *p;
+                        if (g.gate) {
+                            const float4 gv = *reinterpret_cast<const float4*>(g.gate + b * g.N + n);
+                            x.x += v[0] * gv.x; x.y += v[1] * gv.y; x.z += v[2] * gv.z; x.w += v[3] * gv.w;
+                        } else {
+                            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+                        }
+                        *p = x;
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 128 + j * 32 + l31;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + wr * 128 + i * 32 + 8 * q + 4 * hi;
+                    if (m >= g.M) continue;
+                    bf16_t* p = (bf16_t*)g.out + (int64_t)n * g.ldo + m;
+                    const float v0 = acc[i][j][4 * q] + bv, v1 = acc[i][j][4 * q + 1] + bv, v2 = acc[i][j][4 * q + 2] + bv, v3 = acc[i][j][4 * q + 3] + bv;
+                    if (m + 3 < g.M) {
+                        u32x2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                        *reinterpret_cast<u32x2*>(p) = o;
+                    } else {
+                        const float vv[4] = {v0, v1, v2, v3};
+                        for (int r = 0; r < 4 && m + r < g.M; ++r) p[r] = (bf16_t)vv[r];
+                    }
+                }
+        }
+    }
+}
+
+template <int EPI>
+wan_status_t launch_w4(const GemmArgs& g, hipStream_t s) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) {
+            wan_set_error("wan_gemm_bf16(w4): cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
+    hipLaunchKernelGGL((gemm_w4_kernel<EPI>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kW4Threads), kLdsBytes, s, g);
+    WAN_CHECK_LAUNCH("wan_gemm_bf16(w4)");
+    return WAN_OK;
+}
+
 template <int EPI, int PHASES>
 wan_status_t launch256(const GemmArgs& g, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
@@ -347,7 +595,12 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     g.gm = g.tiles_n >= 40 ? 2 : 3;
     if (const int gm = wan_tune(WAN_TUNE_GEMM_GM); gm > 0) g.gm = gm;       // developer A/B switches (wan_set_tuning)
     const int phases = wan_tune(WAN_TUNE_GEMM_PHASES) > 0 ? wan_tune(WAN_TUNE_GEMM_PHASES) : kDefaultPhases;
-#define WAN_G256(E) (phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
+    // gemm_w4: 0 never, 1 whenever the shape allows (K % 128 == 0), 2 (default) where it measured faster: deep K (ffn.2,
+    // K = 13 824: 1.20 vs 1.16 PFLOP/s; 8-way shard 1.05 vs 0.99).  At K = 5120 the two kernels tie (1.25-1.30) and at
+    // K = 1536 the 4-wave one loses 10-15 %: profiles/r02/gemm_w4_ab.log.
+    const int w4mode = wan_tune(WAN_TUNE_GEMM_W4);
+    const bool w4 = K % (2 * BK) == 0 && (w4mode == 1 || (w4mode == 2 && K >= 8192));
+#define WAN_G256(E) (w4 ? launch_w4<E>(g, s) : phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
     switch (epilogue) {
         case WAN_EPI_BF16: return WAN_G256(WAN_EPI_BF16);
         case WAN_EPI_GELU_BF16: return WAN_G256(WAN_EPI_GELU_BF16);
