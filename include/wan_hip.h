@@ -125,6 +125,26 @@ wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ld
                            const float* gate, int64_t rows_per_batch, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * 8f-4  FP8 (OCP e4m3) projections -- an explicit, lossy option of the host model (`enable_fp8_linear`); never the default.
+ *     replaces: the reference keeps e4m3 only as a STORAGE format and up-casts every weight to bf16 for the matmul
+ *               (convert_weight_dtype_wrapper, videox_fun/utils/fp8_optimization.py:19-57).  Here both operands stay
+ *               e4m3 into the matrix pipe: out = (A_q . W_q^T) * a_row_scale[m] * w_row_scale[n]  (+ bias, epilogue),
+ *               A_q = e4m3(A / a_row_scale) per token row, W_q = e4m3(W / w_row_scale) per output channel.
+ *     wan_gemm_fp8: same tile kernel, epilogues and argument meaning as wan_gemm_bf16; A [M,K] and W [N,K] are e4m3 bytes
+ *               (lda / ldw in bytes = elements, multiples of 16), K % 128 == 0; products accumulate in fp32 on
+ *               v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 MFMA rate).
+ *     wan_quantize_rows_fp8: bf16 [rows, cols] -> e4m3 + one scale per row (max|x| / 448; round-to-nearest-even).
+ *     wan_ln_modulate_fp8:  wan_ln_modulate with the quantisation fused into the row kernel (e4m3 out + row scales).
+ * ------------------------------------------------------------------------- */
+wan_status_t wan_gemm_fp8(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
+                          const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
+                          int epilogue, const float* gate, int64_t rows_per_batch, void* stream);
+wan_status_t wan_quantize_rows_fp8(const void* x_bf16, int64_t ldx, void* out_fp8, int64_t ldo, float* out_row_scale,
+                                   int64_t rows, int cols, void* stream);
+wan_status_t wan_ln_modulate_fp8(const float* x, const float* scale, const float* shift, int add_one, void* out_fp8,
+                                 float* out_row_scale, int64_t rows, int dim, int64_t rows_per_batch, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------
  * a9  attention(): softmax(q k^T * scale) v, non-causal, head_dim 128, bf16 in/out,
  *     fp32 softmax and accumulation (flash-style, never materialises Lq x Lk).
  *     replaces: attention()/flash_attention() (attention_utils.py:43-211) as called from

@@ -299,11 +299,40 @@ def head_forward(x: Tensor, e: Tensor, sd, cfg: DiTConfig) -> Tensor:
     return linear(ln_modulate(x, m[1], m[0], cfg.eps), sd, "head.head")
 
 
+class TeaCacheOracle:
+    """Restatement of TeaCache (videox_fun/models/cache_utils.py:21-76) and of its hook in the forward
+    (wan_transformer3d.py:956-1031, 1101-1104), conditional branch only (WanPipeline batches cond/uncond in one call)."""
+
+    def __init__(self, coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int):
+        self.poly = np.poly1d(coefficients)
+        self.num_steps, self.thresh, self.skip_start = num_steps, rel_l1_thresh, num_skip_start_steps
+        self.cnt, self.acc, self.prev_e0, self.residual = 0, 0.0, None, None
+        self.decisions: List[bool] = []
+
+    def run_blocks(self, e0: Tensor) -> bool:
+        if self.cnt < self.skip_start:                       # :962-965
+            calc, self.acc = True, 0.0
+        else:                                                # :967-974
+            d = float((e0 - self.prev_e0).abs().mean() / self.prev_e0.abs().mean())
+            self.acc += float(self.poly(d))
+            calc = not (self.acc < self.thresh)
+            if calc:
+                self.acc = 0.0
+        self.prev_e0 = e0
+        self.decisions.append(calc)
+        return calc
+
+    def done(self) -> None:                                  # :1101-1104
+        self.cnt += 1
+        if self.cnt == self.num_steps:
+            self.cnt, self.acc, self.prev_e0, self.residual = 0, 0.0, None, None
+
+
 def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor,
                 context: Sequence[Tensor], seq_len: int,
                 frame_split_indices: Optional[List[int]] = None,
                 ground_frame_indices: Optional[List[Tuple[int, int]]] = None,
-                return_tokens: bool = False) -> Tensor:
+                return_tokens: bool = False, teacache: Optional[TeaCacheOracle] = None) -> Tensor:
     """WanTransformer3DModel.forward for the T2V/CoF path.  x [B,Cin,F,H,W]."""
     B = x.shape[0]
     angles = rope_angles(cfg.head_dim)
@@ -311,6 +340,8 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor,
     e, e0 = time_embed(t, sd, cfg)
     ctx = text_embed(context, sd, cfg)
     outs = []
+    calc = teacache.run_blocks(e0) if teacache is not None else True
+    residual = []
     for b in range(B):
         tok, grid = patchify(x[b], cfg)
         L = tok.shape[0]
@@ -321,10 +352,19 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor,
         fs = frame_split_indices[b] if frame_split_indices is not None and b < len(frame_split_indices) else None
         gr = ground_frame_indices[b] if (fs is not None and ground_frame_indices is not None
                                          and b < len(ground_frame_indices)) else None
-        for i in range(cfg.num_layers):
-            h = block_forward(h, e0[b], ctx[b], sd, i, cfg, grid, angles, fs, gr, L)
+        if calc:
+            h_in = h
+            for i in range(cfg.num_layers):
+                h = block_forward(h, e0[b], ctx[b], sd, i, cfg, grid, angles, fs, gr, L)
+            residual.append(h - h_in)                         # :1028-1031
+        else:
+            h = h + teacache.residual[b]                      # :983-984
         y = head_forward(h, e[b], sd, cfg)
         outs.append(y if return_tokens else unpatchify(y, grid, cfg))
+    if teacache is not None:
+        if calc:
+            teacache.residual = residual
+        teacache.done()
     return torch.stack(outs)
 
 

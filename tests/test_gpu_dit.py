@@ -191,6 +191,35 @@ def test_unpatchify_zero_frames_is_the_cof_mask(model):
     assert torch.equal(masked, want) and float(plain[:, :, :2].abs().max()) > 0
 
 
+def test_g14_teacache_sequence(golden, model):
+    """TeaCache (opt-in, lossy): the HIP model against the 8-step sequence captured from the reference with enable_teacache --
+    same run / skip decisions, outputs within the bf16 forward tolerance; then off again == the plain forward."""
+    g = golden("dit_g14_teacache")
+    lat0, dl = torch.from_numpy(g["lat0"]).to(DEV), torch.from_numpy(g["dlat"]).to(DEV)
+    ctx = [torch.from_numpy(g["ctx"]).to(DEV)]
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    for key, skip in (("", 1), ("_skip3", 3)):
+        model.enable_teacache(g["coeff"].tolist(), len(g["ts"]), float(g["thresh"]), num_skip_start_steps=skip, offload=False)
+        decisions = []
+        try:
+            for i, t in enumerate(g["ts"]):
+                out = model(lat0 + i * dl, torch.tensor([int(t)], device=DEV), ctx, 420, **kw)
+                decisions.append(bool(model.should_calc))
+                assert rel_l2(out, g["out" + key][i]) < 1.2e-2 and cosine(out, g["out" + key][i]) > 0.9999, (key, i)
+            assert model.teacache.cnt == 0                     # reset after num_steps forwards
+        finally:
+            model.disable_teacache()
+        assert decisions == g["calc" + key].tolist()
+    plain = model(lat0, torch.tensor([999], device=DEV), ctx, 420, **kw)
+    assert rel_l2(plain, g["out"][0]) < 1e-2
+    model.enable_teacache(g["coeff"].tolist(), 4, 0.1, num_skip_start_steps=0)
+    try:
+        with pytest.raises(TypeError, match="num_skip_start_steps"):       # the reference fails at the same point (cache_utils.py:65)
+            model(lat0, torch.tensor([999], device=DEV), ctx, 420, **kw)
+    finally:
+        model.disable_teacache()
+
+
 def test_g7_sched50_on_device(golden):
     g50 = golden("dit_g7_sched50")
     s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)

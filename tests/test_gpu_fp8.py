@@ -1,0 +1,133 @@
+"""-m gpu: the opt-in FP8 (OCP e4m3) projection path (reference: videox_fun/utils/fp8_optimization.py:19-57).
+
+Two different statements are tested:
+
+* KERNEL parity (exact arithmetic): ``wan_gemm_fp8`` computes the product of the QUANTISED operands with fp32 accumulation,
+  so against an fp64 product of the de-quantised operands it must agree like an fp32 GEMM (rel-L2 <= 1e-5 on fp32
+  epilogues, bf16 rounding on bf16 ones); the two quantisers must reproduce torch's own ``float8_e4m3fn`` cast
+  (round-to-nearest-even) of x / scale bit for bit, with scale = max|row| / 448.
+* MODE error (lossy, stated, not a parity claim): a 14B-width block and a small model with ``enable_fp8_linear`` against
+  the bf16 path and the fp32 oracle -- e4m3 keeps 3 mantissa bits, so the block's update is expected at a few percent;
+  the bounds below are what this build measures with margin, and DESIGN.md section 13 quotes the measured values.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+from videocof_amd import WanTransformer3DModel, ops
+from videocof_amd.weights import deterministic_dit_state_dict, det_uniform, random_dit_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+def test_quantisers_match_torch_e4m3_cast():
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.randn(300, 1536, device=DEV, generator=g) * torch.rand(300, 1, device=DEV, generator=g) * 5).bfloat16()
+    x[7] = 0                                                   # an all-zero row: scale floor, zeros out
+    q, s = ops.quantize_rows_fp8(x)
+    want_s = x.float().abs().amax(dim=1).clamp_min(1e-12) / 448.0
+    assert torch.allclose(s, want_s, rtol=1e-6, atol=0)
+    want_q = (x.float() * (448.0 / x.float().abs().amax(dim=1, keepdim=True).clamp_min(1e-12))).clamp(-448, 448).to(ops.FP8)
+    assert torch.equal(q.view(torch.uint8), want_q.view(torch.uint8))
+    assert float((q.float() * s[:, None] - x.float()).abs().max() / x.float().abs().max()) < 2 ** -4   # 3 mantissa bits
+    # fused LN-modulate + quantise == quantise(LN-modulate in fp32)
+    xs = torch.randn(75, 5120, device=DEV, generator=g) * 3 + 1
+    sc, sh = torch.randn(1, 5120, device=DEV, generator=g) * 0.3, torch.randn(1, 5120, device=DEV, generator=g) * 0.2
+    q2, s2 = ops.ln_modulate_fp8(xs, sc, sh, True, 75, 1e-6)
+    y = O.ln_modulate(xs.double(), sc[0].double(), sh[0].double(), 1e-6)
+    assert rel_l2(q2.float() * s2[:, None], y) < 3.5e-2        # e4m3 rounding of a row: ~ 2^-4 / sqrt(3) per element
+    assert torch.allclose(s2, (y.abs().amax(dim=1) / 448).float(), rtol=1e-4)
+    # not worse than quantising the bf16 ln_modulate output with the row kernel
+    q3, s3 = ops.quantize_rows_fp8(ops.ln_modulate(xs, sc, sh, True, 75, 1e-6))
+    assert rel_l2(q2.float() * s2[:, None], y) <= rel_l2(q3.float() * s3[:, None], y) * 1.02
+
+
+@pytest.mark.parametrize("M,N,K", [(1100, 520, 512), (300, 256, 128), (2048, 1536, 1024)])
+def test_gemm_fp8_is_exact_on_the_quantised_operands(M, N, K):
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 2).bfloat16()
+    w = torch.randn(N, K, device=DEV, generator=g) * 0.05
+    bias = torch.randn(N, device=DEV, generator=g) * 0.5
+    gate = torch.randn(2, N, device=DEV, generator=g)
+    resid = torch.randn(M, N, device=DEV, generator=g)
+    aq, sa = ops.quantize_rows_fp8(a)
+    wq, sw = ops.quantize_weight_fp8(w)
+    acc = (aq.double() * sa[:, None].double()) @ (wq.double() * sw[:, None].double()).t() + bias.double()
+    o_f32 = ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_F32)
+    assert rel_l2(o_f32, acc) < 1e-5
+    o_bf = ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_BF16)
+    assert rel_l2(o_bf, acc) < 4e-3
+    o_ge = ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_GELU_BF16)
+    x = acc
+    assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3
+    o_res = resid.clone()
+    rpb = (M + 1) // 2
+    ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_RESID_F32, out=o_res, gate=gate, rows_per_batch=rpb)
+    gsel = gate.double()[torch.arange(M, device=DEV) // rpb]
+    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
+    o_t = ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_BF16_T)
+    assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc) < 4e-3
+    # the quantisation error itself (the lossy part), for the record: a few percent of the product
+    exact = a.double() @ w.double().t() + bias.double()
+    assert 5e-3 < rel_l2(o_f32, exact) < 6e-2
+
+
+def test_fp8_mode_small_model_vs_oracle_and_bf16():
+    tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    sd = deterministic_dit_state_dict(**tiny)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(sd, device=DEV)
+    lat = det_uniform("fp8.lat", (1, 16, 7, 12, 20), 1.0)
+    ctx = [det_uniform("fp8.ctx", (37, 64), 1.0)]
+    t = torch.tensor([899])
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    bf = m(lat.to(DEV), t.to(DEV), [c.to(DEV) for c in ctx], 420, **kw)
+    m.enable_fp8_linear(("qkv", "ffn"))
+    f8 = m(lat.to(DEV), t.to(DEV), [c.to(DEV) for c in ctx], 420, **kw)
+    m.disable_fp8_linear()
+    again = m(lat.to(DEV), t.to(DEV), [c.to(DEV) for c in ctx], 420, **kw)
+    assert torch.equal(again, bf) and not torch.equal(f8, bf)        # the switch really switches, and back
+    ref = O.dit_forward(sd, cfg, lat, t, ctx, 420, [3], [(3, 4)])
+    e8, eb = rel_l2(f8.cpu(), ref), rel_l2(bf.cpu(), ref)
+    print(f"tiny DiT forward vs oracle: bf16 rel-L2 {eb:.2e}, fp8 (qkv+ffn) rel-L2 {e8:.2e}")
+    assert eb < 1e-2 and e8 < 8e-2 and e8 > eb
+
+
+def test_fp8_mode_14b_width_block_error_statement():
+    """One 14B-width block at 8 192 tokens: the fp8 (qkv + ffn) path against the bf16 path and the fp32 oracle (evaluated by
+    torch on the GPU, as in tests/test_gpu_fullsize.py).  Prints the numbers DESIGN.md quotes."""
+    W14 = dict(dim=5120, ffn_dim=13824, num_heads=40)
+    m = WanTransformer3DModel(num_layers=1, **W14)
+    sd = random_dit_state_dict(DEV, seed=3, exercise_epilogues=True, dim=5120, ffn_dim=13824, num_layers=1)
+    m.load_state_dict(sd, device=DEV)
+    cfg = O.DiTConfig(num_layers=1, **W14)
+    grid, L, C = (8, 32, 32), 8192, 5120
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(1, L, C, device=DEV, generator=g)
+    e = torch.randn(1, 6, C, device=DEV, generator=g) * 0.3
+    ctx = torch.randn(1, 512, C, device=DEV, generator=g).bfloat16().float()
+    bf = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
+    m.enable_fp8_linear(("qkv", "ffn"))
+    f8 = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
+    m.enable_fp8_linear(("ffn",))
+    f8_ffn = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
+    m.disable_fp8_linear()
+    osd = {k: v.detach().float() for k, v in m.state_dict().items()}
+    ref = O.block_forward(x[0], e[0], ctx[0], osd, 0, cfg, grid, O.rope_angles(128), 4, (4, 5), L)
+    m.release_workspaces()
+    u_ref = ref - x[0]
+    res = {name: (rel_l2(out, ref), rel_l2(out - x[0], u_ref)) for name, out in (("bf16", bf), ("fp8 ffn", f8_ffn), ("fp8 qkv+ffn", f8))}
+    for name, (s_, u_) in res.items():
+        print(f"14B-width block, L=8192, {name:12s}: residual stream rel-L2 {s_:.2e}, block update rel-L2 {u_:.2e}")
+    assert res["bf16"][1] < 3e-2
+    assert res["fp8 ffn"][1] < 8e-2 and res["fp8 qkv+ffn"][1] < 1.2e-1
+    assert res["fp8 qkv+ffn"][0] < 5e-2

@@ -179,3 +179,26 @@ def test_unipc_rejects_orders_it_does_not_build():
     with pytest.raises(NotImplementedError, match="solver_order=3"):
         FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=3)
     FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=1)
+
+
+def test_teacache_host_logic():
+    """videocof_amd.cache_utils.TeaCache: constructor checks, the published coefficient table and the decision rule
+    (cache_utils.py:21-76, wan_transformer3d.py:956-978) on CPU tensors."""
+    from videocof_amd import TeaCache, get_teacache_coefficients
+    assert get_teacache_coefficients("Wan2.1-T2V-14B")[0] == pytest.approx(-3.03318725e+05)
+    assert get_teacache_coefficients("models/Wan2.1-T2V-1.3B")[-1] == pytest.approx(-4.99875664e-02)
+    assert get_teacache_coefficients("some-other-model") is None
+    for bad in (dict(num_steps=0), dict(num_steps=4, rel_l1_thresh=-1.0), dict(num_steps=4, num_skip_start_steps=5)):
+        with pytest.raises(ValueError):
+            TeaCache([1.0, 0.0], **bad)
+    tc = TeaCache([1.0, 0.0], num_steps=5, rel_l1_thresh=0.25, num_skip_start_steps=1)      # rescale = identity
+    e = torch.ones(1, 6, 8)
+    got = []
+    for k in range(5):
+        got.append(tc.decide(e * (1.0 + 0.1 * k)))        # relative change 0.1/(1+0.1(k-1)): 0.1, 0.0909, 0.0833, 0.0769
+        tc.step_done()
+    # step 0: inside the skip window -> run; 0.1, 0.191 accumulate below 0.25 -> skip, skip; 0.274 >= 0.25 -> run (reset); 0.077 -> skip
+    assert got == [True, False, False, True, False]
+    assert tc.cnt == 0 and tc.previous_modulated_input is None                               # reset after num_steps
+    with pytest.raises(TypeError):
+        TeaCache([1.0, 0.0], num_steps=3, rel_l1_thresh=0.1).decide(e)

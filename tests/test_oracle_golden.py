@@ -172,3 +172,17 @@ def test_g11_sp_rope_slice(golden):
     for r in range(2):
         out = O.rope_apply(x, grid, O.rope_angles(128), token_offset=r * Lr)
         assert rel_l2(out, g[f"rank{r}"][0]) < 1e-6
+
+
+def test_g14_teacache_sequence(golden, sd):
+    """TeaCache: the oracle's restatement against an 8-step sequence captured from the reference model with enable_teacache
+    (decisions, accumulated distances via the decisions, outputs), num_skip_start_steps = 1 and 3."""
+    g = golden("dit_g14_teacache")
+    lat0, dl, ctx = torch.from_numpy(g["lat0"]), torch.from_numpy(g["dlat"]), [torch.from_numpy(g["ctx"])]
+    for key, skip in (("", 1), ("_skip3", 3)):
+        tc = O.TeaCacheOracle(g["coeff"], len(g["ts"]), float(g["thresh"]), skip)
+        for i, t in enumerate(g["ts"]):
+            out = O.dit_forward(sd, CFG, lat0 + i * dl, torch.tensor([int(t)]), ctx, 420, [3], [(3, 4)], teacache=tc)
+            assert rel_l2(out, g["out" + key][i]) < 1e-5, (key, i)
+        assert tc.decisions == g["calc" + key].tolist()
+        assert tc.cnt == 0 and tc.prev_e0 is None           # reset after num_steps forwards

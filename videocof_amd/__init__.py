@@ -9,6 +9,7 @@ Host side mirrors the reference's interface for this path only:
     videocof_amd.AutoencoderKLWan           <- videox_fun/models/wan_vae.py
     videocof_amd.WanT5EncoderModel          <- videox_fun/models/wan_text_encoder.py (umT5 encoder)
     videocof_amd.lora_utils                 <- videox_fun/utils/lora_utils.py (merge_lora on state dicts)
+    videocof_amd.cache_utils                <- videox_fun/models/cache_utils.py (TeaCache, opt-in)
     videocof_amd.dist                       <- videox_fun/dist/{fuser,wan_xfuser}.py (Ulysses on RCCL)
 
 Device arithmetic lives in ``libwan_hip.so`` (csrc/, C ABI in include/wan_hip.h).
@@ -17,6 +18,7 @@ from .fm_solvers_unipc import FlowUniPCMultistepScheduler  # noqa: F401
 from .pipeline_wan import WanPipeline, WanPipelineOutput  # noqa: F401
 from .wan_transformer3d import WanTransformer3DModel  # noqa: F401
 from .graph import GraphedForward  # noqa: F401
+from .cache_utils import TeaCache, get_teacache_coefficients  # noqa: F401
 from .attention_utils import attention, flash_attention  # noqa: F401
 from .wan_vae import AutoencoderKLWan  # noqa: F401
 from .wan_text_encoder import WanT5EncoderModel  # noqa: F401

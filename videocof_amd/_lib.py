@@ -47,6 +47,11 @@ SIGNATURES = {
                                  c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_void_p]),
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                               c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_quantize_rows_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "wan_ln_modulate_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int64,
+                                    c_float, c_void_p]),
     "wan_attention_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),

@@ -76,6 +76,36 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide max for blockDim.x = NW*64 (same protocol as block_sum).
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// four fp32 -> four OCP e4m3 bytes (v_cvt_pk_fp8_f32 x 2, round-to-nearest-even); inputs are clamped to the finite range
+// +-448 first (e4m3fn has no infinity: an overflowing conversion would give NaN)
+__device__ __forceinline__ unsigned int pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned int)w;
+}
+
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
     // 0.5 x (1 + tanh(u)),  u = sqrt(2/pi) (x + 0.044715 x^3)   ==   x * sigmoid(2u) = x / (1 + 2^(-2 u log2 e))
     // 7 VALU (v_exp_f32 + v_rcp_f32, 1 ulp each) instead of the ~18 of expf() and an IEEE division; the result is

@@ -51,6 +51,9 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int gm;               // M tiles per rasterisation group (see wan_gemm_bf16_256)
+    // FP8 instantiation (wan_gemm_fp8): A / W point at e4m3 bytes, lda / ldw count bytes = elements; the product of the
+    // quantised operands is scaled by sa[m] * sw[n] (per-token, per-output-channel) before bias and epilogue
+    const float* sa; const float* sw;
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -74,10 +77,18 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn)
 #define RAW_BARRIER() __builtin_amdgcn_s_barrier()
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI, int PHASES>
+// FP8 = true: the SAME kernel on e4m3 operands.  A K tile is then 128 elements -- still 128 bytes per LDS row, so staging,
+// swizzle, fragment addresses and barriers are unchanged -- and the two 16x16x32 bf16 MFMAs per (m, n) tile and K tile become
+// ONE v_mfma_scale_f32_16x16x128_f8f6f4 (MX-scaled form, the only fp8 MFMA above the bf16 rate on gfx950) with every block
+// scale = 2^0: 32 cycles for 4x the K of a 16-cycle bf16 MFMA, i.e. the same matrix-pipe cycles, LDS bytes and DMA count per
+// K tile for twice the FLOPs.  A lane's 32-byte operand = the two 16-byte chunks 2 kg, 2 kg + 1 of its row; A and W use the
+// same lane -> k assignment, which is all the dot product needs.
+template <int EPI, int PHASES, bool FP8 = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
+    constexpr int kEl = FP8 ? 1 : 2;                 // bytes per operand element
+    constexpr int kTileK = FP8 ? 2 * BK : BK;        // elements per K tile (128 bytes either way)
 
     int tm, tn;
     tile_coords(g, tm, tn);
@@ -88,18 +99,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
 
     // ---- LDS-DMA sources: per operand half-tile (128 rows) wave w copies pieces 2w, 2w+1 (8 rows each)
     const int srow = lane >> 3, spc = lane & 7;
-    const bf16_t* a_src[2][2];
-    const bf16_t* w_src[2][2];
+    const char* a_src[2][2];
+    const char* w_src[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = h * 128 + (wid * 2 + j) * 8 + srow;     // row inside the 256-row tile
             const int c = spc ^ ((row >> 1) & 7);
-            a_src[h][j] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
-            w_src[h][j] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+            a_src[h][j] = (const char*)g.A + ((int64_t)min(m0 + row, g.M - 1) * g.lda) * kEl + c * 16;
+            w_src[h][j] = (const char*)g.W + ((int64_t)min(n0 + row, g.N - 1) * g.ldw) * kEl + c * 16;
         }
-    auto stage_a = [&](int buf, int koff) {
+    auto stage_a = [&](int buf, int koff) {           // koff: byte offset of the K tile inside a row
         char* base = smem + buf * kBufBytes;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -116,7 +127,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
 
     // ---- fragment read offsets: row = base + 16*i + (l&15), logical chunk = 4*kk + (l>>4)
     const int frow = lane & 15, kg = lane >> 4, swz = (lane >> 1) & 7;
-    const int off_kk[2] = {frow * 128 + ((kg ^ swz) << 4), frow * 128 + (((kg + 4) ^ swz) << 4)};
+    // bf16: the two k-steps of a tile read chunks kg and kg + 4; fp8: the one MFMA reads the adjacent chunks 2 kg, 2 kg + 1
+    const int off_kk[2] = {frow * 128 + (((FP8 ? 2 * kg : kg) ^ swz) << 4), frow * 128 + (((FP8 ? 2 * kg + 1 : kg + 4) ^ swz) << 4)};
     const int a_base = wr * kHalfBytes;                       // this wave's 128 A rows
     const int w_base = kOperandBytes + wc * 64 * 128;         // this wave's 64 W rows
 
@@ -142,21 +154,47 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
             for (int kk = 0; kk < 2; ++kk)
                 wf[j][kk] = *reinterpret_cast<const bf16x8*>(sb + w_base + (ni * 2 + j) * 2048 + off_kk[kk]);
     };
+    // one (m, n) 16 x 16 tile of the K tile: two bf16 MFMAs (k-steps kk = 0, 1) or one MX-scaled fp8 MFMA over both fragments
+    auto mma_tile = [&](f32x4& c, const bf16x8 (&a2)[2], const bf16x8 (&w2)[2]) {
+        if constexpr (FP8) {
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
+            const u32x4 a0 = __builtin_bit_cast(u32x4, a2[0]), a1 = __builtin_bit_cast(u32x4, a2[1]);
+            const u32x4 w0 = __builtin_bit_cast(u32x4, w2[0]), w1 = __builtin_bit_cast(u32x4, w2[1]);
+            const i32x8 av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+            const i32x8 wv = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+            // formats 0, 0 = e4m3 x e4m3; block scales: byte 0 of 0x7f7f7f7f = E8M0 127 = 2^0 for every 32-element block
+            if constexpr (kTransposed) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, wv, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            else c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (kTransposed) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[kk], w2[kk], c, 0, 0, 0);
+                else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], a2[kk], c, 0, 0, 0);
+            }
+        }
+    };
     auto mma = [&](int mi, int ni) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        if constexpr (FP8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (kTransposed)
-                        acc[mi * 4 + i][ni * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            af[i][kk], wf[j][kk], acc[mi * 4 + i][ni * 2 + j], 0, 0, 0);
-                    else
-                        acc[mi * 4 + i][ni * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            wf[j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j) mma_tile(acc[mi * 4 + i][ni * 2 + j], af[i], wf[j]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (kTransposed)
+                            acc[mi * 4 + i][ni * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                af[i][kk], wf[j][kk], acc[mi * 4 + i][ni * 2 + j], 0, 0, 0);
+                        else
+                            acc[mi * 4 + i][ni * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                wf[j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j], 0, 0, 0);
+                    }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -170,7 +208,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
         }
     };
     auto mma_half = [&](int mi) {           // 32 MFMAs: 4 m-tiles x 4 n-tiles x 2 kk
-        if constexpr (PHASES == 2) {
+        if constexpr (PHASES == 2 && FP8) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma_tile(acc[mi * 4 + i][j], af[i], wf[j]);
+            __builtin_amdgcn_s_setprio(0);
+        } else if constexpr (PHASES == 2) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
         }
     };
 
-    const int nk = g.K / BK;
+    const int nk = g.K / kTileK;
     stage_a(0, 0);
     stage_w(0, 0);
     WAIT_VM0();
@@ -204,7 +249,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
             const char* sb = smem + (kt & 1) * kBufBytes;
             const int nxt = (kt & 1) ^ 1;
             const bool more = kt + 1 < nk;
-            const int koff = (kt + 1) * BK;
+            const int koff = (kt + 1) * 128;           // bytes: one K tile is 128 bytes of a row in either element type
             load_w_all(sb);
             load_a(sb, 0);
             if (more) { stage_w(nxt, koff); if (late) stage_a(nxt, koff); }
@@ -224,7 +269,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
         const char* sb = smem + (kt & 1) * kBufBytes;
         const int nxt = (kt & 1) ^ 1;
         const bool more = kt + 1 < nk;
-        const int koff = (kt + 1) * BK;
+        const int koff = (kt + 1) * 128;
         // ---- phase 1: quadrant (0,0)
         load_w(sb, 0);
         load_a(sb, 0);
@@ -266,6 +311,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
                 const int n = n0 + wc * 64 + j * 16 + l4;
                 if (n >= g.N) continue;
                 f32x4 v = acc[i][j];
+                if constexpr (FP8) {
+                    const float sm = g.sa[m];
+                    const float4 sn = *reinterpret_cast<const float4*>(g.sw + n);
+                    v[0] *= sm * sn.x; v[1] *= sm * sn.y; v[2] *= sm * sn.z; v[3] *= sm * sn.w;
+                }
                 if (g.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
@@ -298,11 +348,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
             const int n = n0 + wc * 64 + j * 16 + l15;
             if (n >= g.N) continue;
             const float bv = g.bias ? g.bias[n] : 0.f;
+            const float sn = FP8 ? g.sw[n] : 1.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = m0 + wr * 128 + i * 16 + l4;
                 if (m >= g.M) continue;
                 f32x4 v = acc[i][j];
+                if constexpr (FP8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= sn * g.sa[min(m + r, g.M - 1)];
+                }
                 bf16_t* p = (bf16_t*)g.out + (int64_t)n * g.ldo + m;
                 if (m + 3 < g.M) {
                     u32x2 o = {pack_bf16x2(v[0] + bv, v[1] + bv), pack_bf16x2(v[2] + bv, v[3] + bv)};
@@ -579,7 +634,58 @@ wan_status_t launch256(const GemmArgs& g, hipStream_t s) {
     return WAN_OK;
 }
 
+template <int EPI>
+wan_status_t launch256_fp8(const GemmArgs& g, hipStream_t s) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 2, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) {
+            wan_set_error("wan_gemm_fp8: cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
+    hipLaunchKernelGGL((gemm256_kernel<EPI, 2, true>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), kLdsBytes, s, g);
+    WAN_CHECK_LAUNCH("wan_gemm_fp8");
+    return WAN_OK;
+}
+
 }  // namespace
+
+extern "C" wan_status_t wan_gemm_fp8(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
+                                     const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
+                                     int epilogue, const float* gate, int64_t rows_per_batch, void* stream) {
+    WAN_REQUIRE(A_fp8 && W_fp8 && out && a_row_scale && w_row_scale, WAN_ERR_INVALID, "wan_gemm_fp8: null tensor");
+    WAN_REQUIRE(M >= 0 && N > 0 && K > 0, WAN_ERR_INVALID, "wan_gemm_fp8: M=%d N=%d K=%d", M, N, K);
+    WAN_REQUIRE(K % 128 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_fp8: K=%d must be a multiple of 128", K);
+    WAN_REQUIRE(N % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_fp8: N=%d must be a multiple of 4", N);
+    WAN_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K, WAN_ERR_INVALID,
+                "wan_gemm_fp8: lda=%lld ldw=%lld must be multiples of 16 and >= K", (long long)lda, (long long)ldw);
+    if (epilogue == WAN_EPI_BF16_T)
+        WAN_REQUIRE(ldo >= M && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_fp8: transposed ldo=%lld < M=%d or not a multiple of 4", (long long)ldo, M);
+    else
+        WAN_REQUIRE(ldo >= N && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_fp8: ldo=%lld < N=%d or not a multiple of 4", (long long)ldo, N);
+    WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
+                "wan_gemm_fp8: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
+    if (M == 0) return WAN_OK;
+    GemmArgs g;
+    g.A = (const bf16_t*)A_fp8; g.lda = lda; g.W = (const bf16_t*)W_fp8; g.ldw = ldw; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    g.M = M; g.N = N; g.K = K; g.sa = a_row_scale; g.sw = w_row_scale;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    g.gm = g.tiles_n >= 40 ? 2 : 3;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case WAN_EPI_BF16: return launch256_fp8<WAN_EPI_BF16>(g, s);
+        case WAN_EPI_GELU_BF16: return launch256_fp8<WAN_EPI_GELU_BF16>(g, s);
+        case WAN_EPI_F32: return launch256_fp8<WAN_EPI_F32>(g, s);
+        case WAN_EPI_RESID_F32: return launch256_fp8<WAN_EPI_RESID_F32>(g, s);
+        case WAN_EPI_BF16_T: return launch256_fp8<WAN_EPI_BF16_T>(g, s);
+        default: wan_set_error("wan_gemm_fp8: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
+    }
+}
 
 // called by wan_gemm_bf16 (gemm_bf16.hip) for large shapes; arguments already validated there
 wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -588,7 +694,7 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     GemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-    g.M = M; g.N = N; g.K = K;
+    g.M = M; g.N = N; g.K = K; g.sa = nullptr; g.sw = nullptr;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     // M tiles per rasterisation group, measured at M = 67 080 (profiles/r01/gemm_raster_group_ab.log): 2 for wide N
     // (qk projection +5 %, ffn.0 +2 % over the former 4), 3 otherwise (+2 %); 8 and 16 lose 10-15 %.

@@ -12,10 +12,13 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 
 // ------------------------------------------------------------------ LN + modulate
-template <int NV>   // float4 per thread
+// FP8 = true (wan_ln_modulate_fp8): the row is written as OCP e4m3 bytes with ONE scale per token row,
+// q[c] = cvt(y[c] / s), s = max_c |y[c]| / 448 -- the activation operand of wan_gemm_fp8.  The row is in registers anyway, so the
+// quantisation costs one more block reduction (max) and no memory pass.
+template <int NV, bool FP8 = false>   // float4 per thread
 __global__ __launch_bounds__(kThreads) void ln_modulate_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-    float add_one, bf16_t* __restrict__ out, int dim, int64_t rows_per_batch, float eps) {
+    float add_one, bf16_t* __restrict__ out, int dim, int64_t rows_per_batch, float eps, float* __restrict__ row_scale = nullptr) {
     __shared__ float red[kWaves];
     const int64_t row = blockIdx.x;
     const int64_t b = row / rows_per_batch;
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(kThreads) void ln_modulate_kernel(
     const float4* sc = scale ? reinterpret_cast<const float4*>(scale + b * dim) : nullptr;
     const float4* sh = shift ? reinterpret_cast<const float4*>(shift + b * dim) : nullptr;
     u32x2* orow = reinterpret_cast<u32x2*>(out + row * (int64_t)dim);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * kThreads;
@@ -60,8 +64,24 @@ __global__ __launch_bounds__(kThreads) void ln_modulate_kernel(
             const float y1 = (v[i].y - mean) * rstd * a.y + c.y;
             const float y2 = (v[i].z - mean) * rstd * a.z + c.z;
             const float y3 = (v[i].w - mean) * rstd * a.w + c.w;
-            u32x2 o = {pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
-            orow[idx] = o;
+            if constexpr (FP8) {
+                v[i] = make_float4(y0, y1, y2, y3);
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3)));
+            } else {
+                u32x2 o = {pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
+                orow[idx] = o;
+            }
+        }
+    }
+    if constexpr (FP8) {
+        amax = fmaxf(block_max<kWaves>(amax, red), 1e-12f);
+        const float s = amax * (1.0f / 448.0f), inv = 448.0f / amax;
+        if (threadIdx.x == 0) row_scale[row] = s;
+        unsigned int* qrow = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(out) + row * (int64_t)dim);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * kThreads;
+            if (idx < nvec) qrow[idx] = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
         }
     }
 }
@@ -169,6 +189,66 @@ extern "C" wan_status_t wan_ln_modulate(const float* x, const float* scale, cons
     switch (nv) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
 #undef LN_CASE
     WAN_CHECK_LAUNCH("wan_ln_modulate");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_ln_modulate_fp8(const float* x, const float* scale, const float* shift, int add_one,
+                                            void* out_fp8, float* out_row_scale, int64_t rows, int dim,
+                                            int64_t rows_per_batch, float eps, void* stream) {
+    WAN_REQUIRE(x && out_fp8 && out_row_scale, WAN_ERR_INVALID, "wan_ln_modulate_fp8: null tensor");
+    WAN_REQUIRE(dim > 0 && dim % 16 == 0, WAN_ERR_INVALID, "wan_ln_modulate_fp8: dim=%d must be a multiple of 16", dim);
+    WAN_REQUIRE(dim <= 8192, WAN_ERR_UNSUPPORTED, "wan_ln_modulate_fp8: dim=%d > 8192", dim);
+    WAN_REQUIRE(rows >= 0 && rows_per_batch > 0, WAN_ERR_INVALID, "wan_ln_modulate_fp8: rows=%lld rows_per_batch=%lld",
+                (long long)rows, (long long)rows_per_batch);
+    if (rows == 0) return WAN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (dim / 4 + kThreads - 1) / kThreads;
+    dim3 grid((unsigned)rows), block(kThreads);
+    const float ao = add_one ? 1.f : 0.f;
+#define LN_CASE(N) case N: hipLaunchKernelGGL((ln_modulate_kernel<N, true>), grid, block, 0, s, x, scale, shift, ao, (bf16_t*)out_fp8, dim, rows_per_batch, eps, out_row_scale); break;
+    switch (nv) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
+#undef LN_CASE
+    WAN_CHECK_LAUNCH("wan_ln_modulate_fp8");
+    return WAN_OK;
+}
+
+namespace {
+// bf16 [rows, cols] (row stride ldx) -> e4m3 [rows, cols] (row stride ldo bytes) + one scale per row: s = max|x| / 448.
+// One workgroup per row; the row is read twice (max, then convert) -- the second read hits L2.
+__global__ __launch_bounds__(kThreads) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                                     unsigned char* __restrict__ out, int64_t ldo,
+                                                                     float* __restrict__ row_scale, int cols) {
+    __shared__ float red[kWaves];
+    const int64_t row = blockIdx.x;
+    const u32x2* xr = reinterpret_cast<const u32x2*>(x + row * ldx);      // 4 bf16 per item
+    const int n4 = cols >> 2;
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < n4; i += kThreads) {
+        const u32x2 w = xr[i];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(bf16lo_to_f32(w[0])), fabsf(bf16hi_to_f32(w[0])))),
+                     fmaxf(fabsf(bf16lo_to_f32(w[1])), fabsf(bf16hi_to_f32(w[1]))));
+    }
+    amax = fmaxf(block_max<kWaves>(amax, red), 1e-12f);
+    const float inv = 448.0f / amax;
+    if (threadIdx.x == 0) row_scale[row] = amax * (1.0f / 448.0f);
+    unsigned int* qr = reinterpret_cast<unsigned int*>(out + row * ldo);
+    for (int i = threadIdx.x; i < n4; i += kThreads) {
+        const u32x2 w = xr[i];
+        qr[i] = pack_fp8x4(bf16lo_to_f32(w[0]) * inv, bf16hi_to_f32(w[0]) * inv, bf16lo_to_f32(w[1]) * inv, bf16hi_to_f32(w[1]) * inv);
+    }
+}
+}  // namespace
+
+extern "C" wan_status_t wan_quantize_rows_fp8(const void* x_bf16, int64_t ldx, void* out_fp8, int64_t ldo,
+                                              float* out_row_scale, int64_t rows, int cols, void* stream) {
+    WAN_REQUIRE(x_bf16 && out_fp8 && out_row_scale, WAN_ERR_INVALID, "wan_quantize_rows_fp8: null tensor");
+    WAN_REQUIRE(cols > 0 && cols % 4 == 0 && ldx >= cols && ldx % 4 == 0 && ldo >= cols && ldo % 4 == 0, WAN_ERR_INVALID,
+                "wan_quantize_rows_fp8: cols=%d ldx=%lld ldo=%lld must be multiples of 4 with ld >= cols", cols, (long long)ldx, (long long)ldo);
+    WAN_REQUIRE(rows >= 0, WAN_ERR_INVALID, "wan_quantize_rows_fp8: rows=%lld", (long long)rows);
+    if (rows == 0) return WAN_OK;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)rows), dim3(kThreads), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                       ldx, (unsigned char*)out_fp8, ldo, out_row_scale, cols);
+    WAN_CHECK_LAUNCH("wan_quantize_rows_fp8");
     return WAN_OK;
 }
 

@@ -47,6 +47,8 @@ class GraphedForward:
         m = self.model
         if any(v is not None for v in kw.values()):
             raise NotImplementedError("graph capture supports the T2V / CoF arguments only")
+        if m.teacache is not None:
+            raise NotImplementedError("TeaCache decides per step on the host whether the blocks run: not capturable")
         if isinstance(x, (list, tuple)):
             x = torch.stack(list(x))
         key = (tuple(x.shape), x.dtype, int(seq_len), tuple(frame_split_indices or ()),

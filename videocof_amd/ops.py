@@ -200,6 +200,118 @@ class AttentionWorkspace:
             self.buf[:16].zero_()
 
 
+# ---------------------------------------------------------------------------------------------
+# FP8 (OCP e4m3) projections -- SURVEY.md 8f-4; an explicit, lossy option (WanTransformer3DModel.enable_fp8_linear)
+# ---------------------------------------------------------------------------------------------
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+@_on_tensor_device
+def ln_modulate_fp8(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], add_one: bool,
+                    rows_per_batch: int, eps: float, out: Optional[torch.Tensor] = None,
+                    out_scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``ln_modulate`` with per-token-row e4m3 quantisation fused in: returns (q [rows, dim] float8_e4m3fn, s fp32 [rows])
+    with y ~= q * s[:, None]."""
+    _need(x, torch.float32, "ln_modulate_fp8.x")
+    if not x.is_contiguous() or x.dim() != 2:
+        raise ValueError("ln_modulate_fp8.x must be a contiguous [rows, dim] tensor")
+    rows, dim = x.shape
+    for nm, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _need(t, torch.float32, "ln_modulate_fp8." + nm)
+            if not t.is_contiguous() or t.shape[-1] != dim or t.numel() * rows_per_batch < rows * dim:
+                raise ValueError(f"ln_modulate_fp8.{nm}: shape {tuple(t.shape)} does not cover {rows} rows of {dim}")
+    if out is None:
+        out = torch.empty(rows, dim, device=x.device, dtype=FP8)
+    if out_scale is None:
+        out_scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _need(out, FP8, "ln_modulate_fp8.out")
+    _need(out_scale, torch.float32, "ln_modulate_fp8.out_scale")
+    if not out.is_contiguous() or tuple(out.shape) != (rows, dim) or out_scale.numel() < rows:
+        raise ValueError("ln_modulate_fp8: out must be contiguous [rows, dim] and out_scale hold one value per row")
+    lib = _lib.load()
+    _lib.check(lib.wan_ln_modulate_fp8(_p(x), _p(scale), _p(shift), int(bool(add_one)), _p(out), _p(out_scale), rows, dim,
+                                       int(rows_per_batch), float(eps), _stream()), "wan_ln_modulate_fp8")
+    return out, out_scale
+
+
+@_on_tensor_device
+def quantize_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None,
+                      out_scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bf16 [rows, cols] -> (e4m3 [rows, cols], fp32 row scales = max|x| / 448)."""
+    _need(x, torch.bfloat16, "quantize_rows_fp8.x")
+    if x.dim() != 2:
+        raise ValueError("quantize_rows_fp8.x must be 2-D")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=FP8)
+    if out_scale is None:
+        out_scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _need(out, FP8, "quantize_rows_fp8.out")
+    _need(out_scale, torch.float32, "quantize_rows_fp8.out_scale")
+    lib = _lib.load()
+    _lib.check(lib.wan_quantize_rows_fp8(_p(x), x.stride(0), _p(out), out.stride(0), _p(out_scale), rows, cols, _stream()),
+               "wan_quantize_rows_fp8")
+    return out, out_scale
+
+
+def quantize_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One-off weight preparation (torch): [N, K] -> (e4m3 [N, K], fp32 per-output-channel scales = max|w[n,:]| / 448)."""
+    wf = w.float()
+    s = wf.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX
+    return (wf / s[:, None]).clamp(-FP8_MAX, FP8_MAX).to(FP8).contiguous(), s.contiguous()
+
+
+@_on_tensor_device
+def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor],
+             epilogue: int, out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+             rows_per_batch: int = 0, ldo_t: int = 0) -> torch.Tensor:
+    """acc = (a_q @ w_q.T) * a_scale[:, None] * w_scale[None, :] (+ bias) with the epilogues of ``gemm``.
+    a e4m3 [M, K] (row stride free), w e4m3 [N, K]; K % 128 == 0."""
+    _need(a, FP8, "gemm_fp8.a")
+    _need(w, FP8, "gemm_fp8.w")
+    _need(a_scale, torch.float32, "gemm_fp8.a_scale")
+    _need(w_scale, torch.float32, "gemm_fp8.w_scale")
+    M, K = a.shape
+    N, Kw = w.shape
+    if K != Kw or a_scale.numel() < M or w_scale.numel() != N:
+        raise ValueError(f"gemm_fp8: a is [{M},{K}], w is [{N},{Kw}], scales {a_scale.numel()} / {w_scale.numel()}")
+    if bias is not None:
+        _need(bias, torch.float32, "gemm_fp8.bias")
+        if bias.numel() != N:
+            raise ValueError("gemm_fp8: bias length != N")
+    dev = a.device
+    if epilogue in (EPI_BF16, EPI_GELU_BF16):
+        if out is None:
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        _need(out, torch.bfloat16, "gemm_fp8.out")
+    elif epilogue == EPI_F32:
+        if out is None:
+            out = torch.empty(M, N, device=dev, dtype=torch.float32)
+        _need(out, torch.float32, "gemm_fp8.out")
+    elif epilogue == EPI_RESID_F32:
+        if out is None:
+            raise ValueError("gemm_fp8: EPI_RESID_F32 needs the residual stream as `out`")
+        _need(out, torch.float32, "gemm_fp8.out")
+        if gate is not None:
+            _need(gate, torch.float32, "gemm_fp8.gate")
+    elif epilogue == EPI_BF16_T:
+        if out is None:
+            out = torch.zeros(N, ldo_t or round_up(M, 64), device=dev, dtype=torch.bfloat16)
+        _need(out, torch.bfloat16, "gemm_fp8.out")
+        if out.shape[0] != N or out.shape[1] < M:
+            raise ValueError(f"gemm_fp8: transposed out must be [N={N}, >= M={M}], got {tuple(out.shape)}")
+    else:
+        raise ValueError(f"gemm_fp8: unknown epilogue {epilogue}")
+    if epilogue != EPI_BF16_T and tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm_fp8: out shape {tuple(out.shape)} != ({M},{N})")
+    lib = _lib.load()
+    _lib.check(lib.wan_gemm_fp8(_p(a), a.stride(0), _p(a_scale), _p(w), w.stride(0), _p(w_scale), _p(bias), _p(out),
+                                out.stride(0), M, N, K, epilogue, _p(gate), int(rows_per_batch), _stream()), "wan_gemm_fp8")
+    return out
+
+
 _ATTN_WS = {}          # ad-hoc callers without their own workspace: one per (device, stream)
 
 

@@ -67,7 +67,7 @@ class _Block:
     """Packed weights of one WanAttentionBlock (device tensors; bf16 matrices, fp32 vectors)."""
     __slots__ = ("w_qk", "b_qk", "w_v", "b_v", "w_o", "b_o", "nq", "nk",
                  "w_cq", "b_cq", "w_ck", "b_ck", "w_cv", "b_cv", "w_co", "b_co", "ncq", "nck",
-                 "n3w", "n3b", "w1", "b1", "w2", "b2", "modulation")
+                 "n3w", "n3b", "w1", "b1", "w2", "b2", "modulation", "f8")
 
 
 class WanTransformer3DModel(nn.Module):
@@ -109,6 +109,7 @@ class WanTransformer3DModel(nn.Module):
         self._dtype = torch.bfloat16
         self._device = torch.device("cpu")
         self.teacache = None
+        self.should_calc = True
         self.cfg_skip_ratio = None
         self.current_steps = 0
         self.num_inference_steps = None
@@ -117,6 +118,7 @@ class WanTransformer3DModel(nn.Module):
         self._sp = None
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
         self._ctx_cache = None
+        self._fp8 = ()                      # enable_fp8_linear: which projections run in e4m3 (lossy, opt-in)
         self._bufs = None                   # cached activation workspaces of the last call shape (_workspaces)
         # Number of leading latent frames whose prediction the caller discards (WanPipeline zeroes
         # noise_pred[:, :, :condition_count], pipeline_wan.py:736).  When set (B = 1, no SP) the LAST block and
@@ -210,6 +212,7 @@ class WanTransformer3DModel(nn.Module):
             b.w1, b.b1 = mat(p + "ffn.0.weight"), vec(p + "ffn.0.bias")
             b.w2, b.b2 = mat(p + "ffn.2.weight"), vec(p + "ffn.2.bias")
             b.modulation = vec(p + "modulation").reshape(6, C)
+            b.f8 = None
             self.blocks.append(b)
         w["mod_all"] = torch.stack([b.modulation for b in self.blocks])        # [layers, 6, C]
         extra = [k for k in sd.keys() if k not in used]
@@ -220,6 +223,8 @@ class WanTransformer3DModel(nn.Module):
                           ang[..., 1].to(torch.float32).contiguous().to(dev))
         self._device = dev
         self._ctx_cache = None
+        if self._fp8:
+            self.enable_fp8_linear(self._fp8)          # re-quantise from the new bf16 weights
         return IncompatibleKeys(missing, extra)
 
     def state_dict(self, *args, **kwargs):  # type: ignore[override]
@@ -302,6 +307,36 @@ class WanTransformer3DModel(nn.Module):
 
     def enable_teacache(self, *a, **k):
         raise NotImplementedError("TeaCache changes outputs and is dead in the CLI path (SURVEY.md section 2, row 7)")
+
+    def enable_fp8_linear(self, layers=("qkv", "ffn")):
+        """FP8 (OCP e4m3) projections, SURVEY.md 8f-4 -- an explicit LOSSY option, off by default and never used by a
+        parity statement or the headline benchmark.  The reference's fp8 mode (``convert_model_weight_to_float8`` +
+        ``convert_weight_dtype_wrapper``, videox_fun/utils/fp8_optimization.py:19-57; ``GPU_memory_mode =
+        "model_cpu_offload_and_qfloat8"``) stores weights as e4m3 and up-casts them to bf16 for every matmul; here the named
+        projections run on the fp8 matrix pipe: weights e4m3 with one scale per output channel (quantised once, now),
+        activations e4m3 with one scale per token row (quantised inside the LN-modulate kernel, or by a row kernel for the
+        GELU output), fp32 accumulation.  ``layers``: "qkv" (self-attention q | k and v), "ffn" (ffn.0 and ffn.2).
+        The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
+        Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
+        layers = tuple(layers)
+        if not set(layers) <= {"qkv", "ffn"} or not layers:
+            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn'), got {layers}")
+        if self.dim % 128 or self.ffn_dim % 128:
+            raise NotImplementedError("fp8 projections need dim and ffn_dim to be multiples of 128")
+        for blk in self.blocks:
+            blk.f8 = {}
+            if "qkv" in layers:
+                blk.f8["qk"], blk.f8["v"] = ops.quantize_weight_fp8(blk.w_qk), ops.quantize_weight_fp8(blk.w_v)
+            if "ffn" in layers:
+                blk.f8["w1"], blk.f8["w2"] = ops.quantize_weight_fp8(blk.w1), ops.quantize_weight_fp8(blk.w2)
+        self._fp8 = layers
+        self._bufs = None
+
+    def disable_fp8_linear(self):
+        for blk in self.blocks:
+            blk.f8 = None
+        self._fp8 = ()
+        self._bufs = None
 
     def clear_context_cache(self):
         """Drop the hoisted text K/V^T (0.8 GB at 14B) and the references that keep the prompt embeddings alive."""
@@ -441,6 +476,12 @@ class WanTransformer3DModel(nn.Module):
         # V^T pad columns [L, roundup(L, 64)) are never written and must stay finite: zero them once
         b.vt = torch.zeros(B, C, ops.round_up(L, 64) if self.sp_world_size == 1 else Ll, device=dev, dtype=torch.bfloat16)
         b.qk3 = b.qk.view(B, Ll, 2 * C)
+        if self._fp8:
+            b.hq = torch.empty(M, C, device=dev, dtype=ops.FP8)
+            b.rs = torch.empty(M, device=dev, dtype=torch.float32)
+            if "ffn" in self._fp8:
+                b.ffq = torch.empty(M, self.ffn_dim, device=dev, dtype=ops.FP8)
+                b.ffs = torch.empty(M, device=dev, dtype=torch.float32)
         self._bufs = (key, b)
         return b
 
@@ -454,13 +495,24 @@ class WanTransformer3DModel(nn.Module):
         em: [6, B, C] = modulation + e0 (:495); ctx_kv: (k [B,512,C], v^T [B,C,512]) of the text tokens."""
         C, H, P, M = self.dim, self.num_heads, self.sp_world_size, B * Ll
         h, qk, att, cq, ff, vt, qk3 = bufs.h, bufs.qk, bufs.att, bufs.cq, bufs.ff, bufs.vt, bufs.qk3
+        f8 = blk.f8 if (blk.f8 and P == 1) else {}
         # ---- self attention (:495-499)
-        ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
-        if P == 1:
+        if "qk" in f8:
+            ops.ln_modulate_fp8(xs, em[1], em[0], True, Ll, self.eps, out=bufs.hq, out_scale=bufs.rs)
+        else:
+            ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
+        if P == 1 and "qk" in f8:
+            ops.gemm_fp8(bufs.hq, bufs.rs, *f8["qk"], blk.b_qk, ops.EPI_BF16, out=qk)
+            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+            for b in range(B):
+                ops.gemm_fp8(bufs.hq[b * Ll:(b + 1) * Ll][:L], bufs.rs[b * Ll:(b + 1) * Ll][:L], *f8["v"], blk.b_v,
+                             ops.EPI_BF16_T, out=vt[b])
+        elif P == 1:
             ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
             ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
             for b in range(B):
                 ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
+        if P == 1:
             ev = self._event_pair()
             ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True,
                               workspace=self._ws_self)
@@ -494,9 +546,15 @@ class WanTransformer3DModel(nn.Module):
         ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C), q_prescaled=True, workspace=self._ws_cross)
         ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
         # ---- FFN (:507-511)
-        ops.ln_modulate(xs, em[4], em[3], True, Ll, self.eps, out=h)
-        ops.gemm(h, blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff)
-        ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
+        if "w1" in f8:
+            ops.ln_modulate_fp8(xs, em[4], em[3], True, Ll, self.eps, out=bufs.hq, out_scale=bufs.rs)
+            ops.gemm_fp8(bufs.hq, bufs.rs, *f8["w1"], blk.b1, ops.EPI_GELU_BF16, out=ff)
+            ops.quantize_rows_fp8(ff, out=bufs.ffq, out_scale=bufs.ffs)
+            ops.gemm_fp8(bufs.ffq, bufs.ffs, *f8["w2"], blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
+        else:
+            ops.ln_modulate(xs, em[4], em[3], True, Ll, self.eps, out=h)
+            ops.gemm(h, blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff)
+            ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
 
     @torch.no_grad()
     def head_forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
@@ -599,7 +657,17 @@ class WanTransformer3DModel(nn.Module):
         r0 = 0
         if self.skip_source_frames and B == 1 and P == 1:
             r0 = min(int(self.skip_source_frames), grid[0]) * grid[1] * grid[2]
-        for li, blk in enumerate(self.blocks):
+        # TeaCache (:956-1031): skip the blocks and re-apply the residual they produced the last time they ran
+        run_blocks, ori_x = True, None
+        if self.teacache is not None:
+            run_blocks = self.teacache.decide(e0, cond_flag)
+            self.should_calc = run_blocks
+            if not run_blocks:
+                prev = self.teacache.previous_residual_cond if cond_flag else self.teacache.previous_residual_uncond
+                xs.add_(prev[-xs.shape[0]:])
+            else:
+                ori_x = xs.clone()
+        for li, blk in enumerate(self.blocks if run_blocks else ()):
             kv = ctx_kv[li] if ctx_kv[li] is not None else self._context_kv(blk, ctx, B)
             if self._probe_layer == li:
                 self._probe = xs.clone()
@@ -607,6 +675,11 @@ class WanTransformer3DModel(nn.Module):
                 self._last_block_suffix(blk, emod[li], xs, bufs.h, bufs.qk, bufs.vt, bufs.att, bufs.cq, bufs.ff, kv, rp, r0, L)
                 break
             self._run_block(blk, emod[li], xs, bufs, kv, rp, B, Ll, L, seq_len)
+        if ori_x is not None:
+            if cond_flag:
+                self.teacache.previous_residual_cond = xs - ori_x
+            else:
+                self.teacache.previous_residual_uncond = xs - ori_x
 
         # -- head (:535-548) + unpatchify (:1108-1131)
         if r0:
@@ -623,4 +696,6 @@ class WanTransformer3DModel(nn.Module):
         for b in range(B):
             ops.unpatchify(yt[b], grid, self.patch_size, self.out_dim, out_dtype,
                            zero_frames=min(int(self.mask_source_frames), grid[0]) * pt, out=out[b])
+        if self.teacache is not None:
+            self.teacache.step_done(cond_flag)                                        # :1101-1104
         return out.to(dtype)
