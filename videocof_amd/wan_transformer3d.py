@@ -305,9 +305,6 @@ class WanTransformer3DModel(nn.Module):
             raise ValueError(f"num_heads={self.num_heads} is not divisible by ulysses degree {sp.world_size}")
         self._sp, self.sp_world_size, self.sp_world_rank = sp, sp.world_size, sp.rank
 
-    def enable_teacache(self, *a, **k):
-        raise NotImplementedError("TeaCache changes outputs and is dead in the CLI path (SURVEY.md section 2, row 7)")
-
     def enable_fp8_linear(self, layers=("qkv", "ffn")):
         """FP8 (OCP e4m3) projections, SURVEY.md 8f-4 -- an explicit LOSSY option, off by default and never used by a
         parity statement or the headline benchmark.  The reference's fp8 mode (``convert_model_weight_to_float8`` +
@@ -341,6 +338,16 @@ class WanTransformer3DModel(nn.Module):
     def clear_context_cache(self):
         """Drop the hoisted text K/V^T (0.8 GB at 14B) and the references that keep the prompt embeddings alive."""
         self._ctx_cache = None
+
+    def enable_teacache(self, coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int = 0,
+                        offload: bool = True):
+        """wan_transformer3d.py:731-741.  Lossy and opt-in (videocof_amd/cache_utils.py); off by default."""
+        from .cache_utils import TeaCache
+        self.teacache = TeaCache(coefficients, num_steps, rel_l1_thresh=rel_l1_thresh,
+                                 num_skip_start_steps=num_skip_start_steps, offload=offload)
+
+    def share_teacache(self, transformer=None):
+        self.teacache = transformer.teacache            # :743-747
 
     def disable_teacache(self):
         self.teacache = None
