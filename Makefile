@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := videocof_amd/csrc
-SRCS  := $(CSRC)/api.cpp $(wildcard $(CSRC)/*.hip)
+SRCS  := $(wildcard $(CSRC)/*.cpp) $(wildcard $(CSRC)/*.hip)
 HDRS  := $(CSRC)/common.hpp include/wan_hip.h $(wildcard $(CSRC)/*.inc)
 LIB   := videocof_amd/libwan_hip.so
 OBJD  := build/obj

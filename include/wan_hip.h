@@ -198,6 +198,43 @@ wan_status_t wan_patchify(const void* latent, int in_dtype, void* tokens_bf16, i
 wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out_dtype,
                             int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, int zero_frames, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * a11  One WanAttentionBlock as a single call (WanAttentionBlock.forward, wan_transformer3d.py:464-515) -- the
+ *      composite a non-Python host drives: LN-modulate -> q|k GEMM -> RMSNorm+RoPE (q pre-scaled) -> V^T GEMM ->
+ *      self-attention -> o GEMM (+gate, +residual) -> LN-affine -> q GEMM -> RMSNorm -> cross-attention over the text
+ *      K / V^T -> o GEMM (+residual) -> LN-modulate -> ffn.0 (+GELU) -> ffn.2 (+gate, +residual); the kernels above,
+ *      enqueued in that order on `stream` (host code only, no extra arithmetic).  Single device (no sequence parallelism).
+ *      x      fp32 [batch * rows_per_batch, dim]   residual stream, updated IN PLACE
+ *      emod   fp32 [6][batch][dim]                 modulation + time projection (`(self.modulation + e).chunk(6)`, :494)
+ *      ctx_k  bf16 [batch][text_len][dim]          RMS-normed text keys   (cross_attn.norm_k(k(context)), :321)
+ *      ctx_vt bf16 [batch][dim][text_len]          text values, transposed (cross_attn.v(context), :322)
+ *      valid_tokens = F*Hp*Wp <= rows_per_batch: keys beyond it (sequence padding) are masked, V^T covers them only.
+ *      Workspaces are caller-owned (sizes: wan_dit_block_workspace_bytes); vt's pad columns [valid_tokens, ldvt) must be
+ *      finite (zero them once); the two attention scratches follow wan_attention_workspace_bytes and may be NULL.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int dim, ffn_dim, num_heads, text_len;
+    float eps;
+    const void *w_qk, *w_v, *w_o, *w_cq, *w_co, *w_ffn0, *w_ffn2;      /* bf16 [out, in]; w_qk = q rows then k rows */
+    const float *b_qk, *b_v, *b_o, *b_cq, *b_co, *b_ffn0, *b_ffn2;
+    const float *norm_q, *norm_k, *norm_cq;                           /* WanRMSNorm gains */
+    const float *norm3_w, *norm3_b;                                   /* LayerNorm (affine) before cross-attention */
+} wan_block_weights;
+
+typedef struct {
+    void *h, *qk, *att, *cq, *ff, *vt;        /* bf16: [M,dim] [M,2 dim] [M,dim] [M,dim] [M,ffn] [batch][dim][ldvt] */
+    int64_t ldvt;
+    void* attn_ws_self; int64_t attn_ws_self_bytes;
+    void* attn_ws_cross; int64_t attn_ws_cross_bytes;
+} wan_block_workspace;
+
+wan_status_t wan_dit_block_forward(float* x, const float* emod, const void* ctx_k, const void* ctx_vt,
+                                   const wan_block_weights* w, const wan_block_workspace* ws,
+                                   const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                   int batch, int64_t rows_per_batch, int64_t valid_tokens, void* stream);
+wan_status_t wan_dit_block_workspace_bytes(int dim, int ffn_dim, int batch, int64_t rows_per_batch, int64_t valid_tokens,
+                                           int64_t* bytes /* [6]: h, qk, att, cq, ff, vt */, int64_t* ldvt);
+
 /* a17  UniPC updates as one fused pass: out[i] = c0*x0[i] + c1*x1[i] + c2*x2[i] + c3*x3[i] (x1..x3 may be
  *      NULL), fp32 accumulate, all tensors of one dtype (0 fp32, 1 bf16).
  *      replaces: the elementwise chains of convert_model_output / multistep_uni_p_bh_update /

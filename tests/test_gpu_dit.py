@@ -220,6 +220,35 @@ def test_g14_teacache_sequence(golden, model):
         model.disable_teacache()
 
 
+def test_block_composite_is_the_python_launch_sequence(golden, model):
+    """wan_dit_block_forward (one C call per block) enqueues the same kernels with the same arguments as the per-op Python
+    sequence: bit-identical outputs, B = 1 and B = 2, padded sequence; and the raw C ABI rejects inconsistent arguments."""
+    g = golden("dit_g6_forward")
+    lat2 = torch.from_numpy(g["lat2"]).to(DEV)
+    ctx2 = [torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx2"]).to(DEV)]
+    outs = {}
+    for flag in (True, False):
+        model.use_block_composite = flag
+        try:
+            outs[flag] = (model(lat2[:1], torch.tensor([899], device=DEV), ctx2[:1], 448, frame_split_indices=[3],
+                                ground_frame_indices=[(3, 4)]),
+                          model(lat2, torch.tensor([749, 749], device=DEV), ctx2, 420, frame_split_indices=[3, 3],
+                                ground_frame_indices=[(3, 4), (3, 4)]))
+        finally:
+            model.use_block_composite = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert rel_l2(outs[True][1], g["out_b2"]) < 1e-2
+    from videocof_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    bytes6, ldvt = (ctypes.c_int64 * 6)(), ctypes.c_int64()
+    assert lib.wan_dit_block_workspace_bytes(256, 512, 2, 420, 420, bytes6, ctypes.byref(ldvt)) == 0
+    assert ldvt.value == 448 and list(bytes6) == [2 * 420 * 256 * 2, 2 * 420 * 512 * 2, 2 * 420 * 256 * 2, 2 * 420 * 256 * 2,
+                                                  2 * 420 * 512 * 2, 2 * 256 * 448 * 2]
+    st = lib.wan_dit_block_forward(None, None, None, None, None, None, None, None, None, 1, 420, 420, None)
+    assert st == _lib.WAN_ERR_INVALID
+
+
 def test_g7_sched50_on_device(golden):
     g50 = golden("dit_g7_sched50")
     s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)

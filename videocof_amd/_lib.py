@@ -35,6 +35,21 @@ class ConvParams(Structure):
                                      "upsample2x", "time_interleave")]
 
 
+class BlockWeights(Structure):
+    """``wan_block_weights`` of include/wan_hip.h."""
+    _fields_ = ([(n, c_int) for n in ("dim", "ffn_dim", "num_heads", "text_len")] + [("eps", c_float)] +
+                [(n, c_void_p) for n in ("w_qk", "w_v", "w_o", "w_cq", "w_co", "w_ffn0", "w_ffn2",
+                                         "b_qk", "b_v", "b_o", "b_cq", "b_co", "b_ffn0", "b_ffn2",
+                                         "norm_q", "norm_k", "norm_cq", "norm3_w", "norm3_b")])
+
+
+class BlockWorkspace(Structure):
+    """``wan_block_workspace`` of include/wan_hip.h."""
+    _fields_ = ([(n, c_void_p) for n in ("h", "qk", "att", "cq", "ff", "vt")] + [("ldvt", c_int64)] +
+                [("attn_ws_self", c_void_p), ("attn_ws_self_bytes", c_int64),
+                 ("attn_ws_cross", c_void_p), ("attn_ws_cross_bytes", c_int64)])
+
+
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "wan_abi_version": (c_int, []),
@@ -47,6 +62,9 @@ SIGNATURES = {
                                  c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_void_p]),
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                               c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_dit_block_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockWeights), POINTER(BlockWorkspace),
+                                      c_void_p, c_void_p, POINTER(RopeParams), c_int, c_int64, c_int64, c_void_p]),
+    "wan_dit_block_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64)]),
     "wan_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                              c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "wan_quantize_rows_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
