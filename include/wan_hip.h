@@ -199,6 +199,30 @@ wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out
                             int Cout, int F, int Hp, int Wp, int pt, int ph, int pw, int zero_frames, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * a21  Ulysses sequence parallelism: the wire layouts of the head all-to-all (replaces usp_attn_forward's packing,
+ *      videox_fun/dist/wan_xfuser.py:68-111, and yunchang's SeqAllToAll4D; the collective itself is an RCCL
+ *      all_to_all_single with equal splits issued by the host, videocof_amd/dist.py).  One rank holds T tokens of B samples;
+ *      P ranks; Cl = dim / P channels (H / P heads) per rank after the exchange.
+ *        token-major wire   [P][T][B][Cl]  (q, k, and the attention output)
+ *        channel-major wire [P][Cl][B][T]  (V^T: exactly what wan_gemm_bf16(WAN_EPI_BF16_T, ldo = B*T) writes per sample)
+ *      After the exchange a token-major wire buffer reads as [P*T][B][Cl] -- all tokens, this rank's heads, row stride B*Cl,
+ *      sample stride Cl -- which wan_attention_fwd consumes and produces in place (no unpacking of q, k or o).
+ *      wan_rmsnorm_rope_sp: wan_rmsnorm_rope that reads x0 / x1 (not modified) and writes the results straight into
+ *                           token-major wire buffers (slabs = P, batch = B; rows = B * rp->rows_per_batch): the fused form
+ *                           of "norm, rotate, then pack for the all-to-all".
+ *      wan_sp_pack_heads / wan_sp_unpack_heads: [B][T][ldx >= P*Cl] <-> token-major wire (the o projection's input).
+ *      wan_sp_unpack_vt: arrived channel-major wire -> vt [B][Cl][ldvt], column s*T + t (ldvt >= P*T; pad columns untouched).
+ *      Cl % 8 == 0, T % 8 == 0.
+ * ------------------------------------------------------------------------- */
+wan_status_t wan_rmsnorm_rope_sp(const void* x0_bf16, const float* w0, const void* x1_bf16, const float* w1,
+                                 int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                 const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                 float x0_scale, void* wire0, void* wire1, int slabs, int batch, void* stream);
+wan_status_t wan_sp_pack_heads(const void* x_bf16, int64_t ldx, void* wire, int P, int T, int B, int Cl, void* stream);
+wan_status_t wan_sp_unpack_heads(const void* wire, void* x_bf16, int64_t ldx, int P, int T, int B, int Cl, void* stream);
+wan_status_t wan_sp_unpack_vt(const void* wire, void* vt_bf16, int64_t ldvt, int P, int B, int Cl, int T, void* stream);
+
+/* ---------------------------------------------------------------------------
  * a11  One WanAttentionBlock as a single call (WanAttentionBlock.forward, wan_transformer3d.py:464-515) -- the
  *      composite a non-Python host drives: LN-modulate -> q|k GEMM -> RMSNorm+RoPE (q pre-scaled) -> V^T GEMM ->
  *      self-attention -> o GEMM (+gate, +residual) -> LN-affine -> q GEMM -> RMSNorm -> cross-attention over the text

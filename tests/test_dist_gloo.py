@@ -62,6 +62,36 @@ def _worker(rank, world, port, L, H, q_out):
         o_ref = torch.stack([O.attention(q[b].view(Lp, H, D), k[b].view(Lp, H, D), v[b].view(Lp, H, D),
                                          k_len=L).reshape(Lp, C) for b in range(B)])[:, sl]
         err = float((o_local - o_ref).abs().max())
+        # --- the wire layouts the DiT uses (include/wan_hip.h a21): ONE flat all-to-all per tensor, no re-layout of q / k / o
+        Cl, Lt = C // world, Lp
+        for name, full in (("q", q), ("k", k)):
+            send = sp.pack_heads_ref(full[:, sl])                               # [P, Ll, B, Cl] (what wan_rmsnorm_rope_sp writes)
+            recv = torch.empty_like(send)
+            wait = sp.exchange(recv, send, async_op=True)
+            wait()
+            # arrived buffer == [P*Ll][B][Cl]: all tokens, my heads, uniform strides
+            got = recv.view(Lt, B, Cl).permute(1, 0, 2)
+            assert torch.equal(got, full[:, :, rank * Cl:(rank + 1) * Cl]), name
+        vsend = sp.pack_vt_ref(vt_local)                                        # [P, Cl, B, Ll] == [C, B, Ll]: GEMM out with ldo = B*Ll
+        assert torch.equal(vsend.view(C, B, Ll)[:, 1], vt_local[1])
+        vrecv = torch.empty_like(vsend)
+        sp.exchange(vrecv, vsend)
+        vt_full = sp.unpack_vt_ref(vrecv, Lp + 24)
+        assert torch.equal(vt_full, vth)
+        # attention on the arrived buffers, output written in wire form, inverse exchange, unpack
+        qa = sp.pack_heads_ref(q[:, sl]); ka = sp.pack_heads_ref(k[:, sl])
+        qr, kr = torch.empty_like(qa), torch.empty_like(ka)
+        sp.exchange(qr, qa); sp.exchange(kr, ka)
+        osend = torch.empty(Lt, B, Cl)
+        for b in range(B):
+            osend[:, b] = O.attention(qr.view(Lt, B, Cl)[:, b].reshape(Lt, Hs, D), kr.view(Lt, B, Cl)[:, b].reshape(Lt, Hs, D),
+                                      vt_full[b, :, :Lp].t().reshape(Lt, Hs, D), k_len=L).reshape(Lt, Cl)
+        orecv = torch.empty_like(osend)
+        sp.exchange(orecv, osend)                                               # slab r of [P*Ll][B][Cl] = rank r's token rows
+        o_wire = sp.unpack_heads_ref(orecv.view(world, Ll, B, Cl))
+        err = max(err, float((o_wire - o_ref).abs().max()))
+        with pytest.raises(ValueError):
+            sp.exchange(torch.empty(7), torch.empty(7))
         # --- final token all-gather
         y = torch.randn(B, Lp, 64)
         full = sp.all_gather_tokens(y[:, sl])

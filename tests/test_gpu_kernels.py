@@ -574,3 +574,39 @@ def test_gemm_256_tile_kernels_all_epilogues(M, N, K, w4):
     assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
     assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc) < 4e-3
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
+
+
+@pytest.mark.parametrize("P,T,B,Cl", [(2, 24, 2, 128), (8, 56, 1, 640), (4, 8, 3, 8)])
+def test_sp_wire_layout_kernels(rope_dev, P, T, B, Cl):
+    """wan_sp_pack_heads / wan_sp_unpack_heads / wan_sp_unpack_vt move bytes exactly like the torch statements of the
+    layouts in videocof_amd.dist, and wan_rmsnorm_rope_sp == wan_rmsnorm_rope followed by the pack."""
+    import types
+    from videocof_amd.dist import SequenceParallelGroup
+    sp = types.SimpleNamespace(world_size=P)
+    ref = lambda name, *a: getattr(SequenceParallelGroup, name)(sp, *a)
+    g = torch.Generator().manual_seed(P + T)
+    C = P * Cl
+    x = bf(torch.randn(B * T, C + 16, generator=g)).to(DEV)[:, :C]              # strided rows (ldx = C + 16)
+    wire = torch.empty(B * T * C, device=DEV, dtype=torch.bfloat16)
+    ops.sp_pack_heads(x, wire, P, T, B)
+    want = ref("pack_heads_ref", x.view(B, T, C))
+    assert torch.equal(wire.view(P, T, B, Cl), want)
+    back = torch.zeros(B * T, C, device=DEV, dtype=torch.bfloat16)
+    ops.sp_unpack_heads(wire, back, P, T, B)
+    assert torch.equal(back, ref("unpack_heads_ref", wire.view(P, T, B, Cl)).reshape(B * T, C))
+    vwire = bf(torch.randn(P, Cl, B, T, generator=g)).to(DEV)
+    ld = P * T + 40
+    vt = torch.zeros(B, Cl, ld, device=DEV, dtype=torch.bfloat16)
+    ops.sp_unpack_vt(vwire.view(-1), vt, P, T)
+    assert torch.equal(vt, ref("unpack_vt_ref", vwire, ld))
+    if Cl % 128 == 0:                                                          # head_dim 128 rows
+        w = (torch.rand(C, generator=g) + 0.5).to(DEV)
+        rp = RopeParams(T // 4 if T % 4 == 0 else 1, 2, 2, 2, 1, 2, 16, T, 1024)
+        xin = x.contiguous()
+        inplace = xin.clone()
+        ops.rmsnorm_rope_(inplace, w, None, None, 128, 1e-6, rope_dev, rp, x0_scale=0.37)
+        w2 = torch.empty(B * T * C, device=DEV, dtype=torch.bfloat16)
+        keep = xin.clone()
+        ops.rmsnorm_rope_sp(xin, w, None, None, 128, 1e-6, rope_dev, rp, w2, None, P, B, x0_scale=0.37)
+        assert torch.equal(xin, keep)                                           # the input is not modified
+        assert torch.equal(w2.view(P, T, B, Cl), ref("pack_heads_ref", inplace.view(B, T, C)))

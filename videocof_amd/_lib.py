@@ -62,6 +62,12 @@ SIGNATURES = {
                                  c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_void_p]),
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                               c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_rmsnorm_rope_sp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                    c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_void_p, c_void_p, c_int, c_int,
+                                    c_void_p]),
+    "wan_sp_pack_heads": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_sp_unpack_heads": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_sp_unpack_vt": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_dit_block_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockWeights), POINTER(BlockWorkspace),
                                       c_void_p, c_void_p, POINTER(RopeParams), c_int, c_int64, c_int64, c_void_p]),
     "wan_dit_block_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64)]),

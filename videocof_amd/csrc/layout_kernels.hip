@@ -1,5 +1,7 @@
 // Layout glue at the two ends of the DiT: patchify (im2col of the (1,2,2) Conv3d) and unpatchify.
 // Pure data movement (HBM-bound, a few MB per forward).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace {
@@ -127,5 +129,93 @@ extern "C" wan_status_t wan_lincomb(void* out, int dtype, const void* x0, const 
         hipLaunchKernelGGL(lincomb_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)x0,
                            (const bf16_t*)x1, (const bf16_t*)x2, (const bf16_t*)x3, c0, c1, c2, c3, n);
     WAN_CHECK_LAUNCH("wan_lincomb");
+    return WAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ulysses (sequence-parallel) wire layouts, replacing videox_fun/dist/wan_xfuser.py:68-111 + yunchang's all-to-all packing.
+// One rank holds T local tokens of B samples; P ranks; Cl = C / P channels (= H / P heads) per rank after the exchange.
+//   token-major wire   [P][T][B][Cl]:  q / k on the way out (slab d goes to rank d; written directly by wan_rmsnorm_rope's
+//                      `out` arguments, or by wan_sp_pack_heads) -- on arrival slab s holds the tokens of rank s, i.e. the
+//                      buffer reads as [P*T][B][Cl] = all tokens, my heads, with UNIFORM strides (row B*Cl, sample Cl), so
+//                      wan_attention_fwd consumes it in place; the attention output is written in the same form and is
+//                      the send buffer of the inverse exchange as it stands.
+//   channel-major wire [P][Cl][B][T]:  V^T on the way out = what the V-projection's transposed epilogue writes with
+//                      ldo = B*T (no packing); on arrival wan_sp_unpack_vt lays it out as [B][Cl][ldvt] (column s*T + t).
+// The collective itself stays an RCCL all_to_all_single issued by the host (videocof_amd/dist.py).
+// All three kernels move 16-byte chunks: Cl % 8 == 0 and T % 8 == 0.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sp_pack_heads_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out,
+                                                            int P, int T, int B, int Cl, bool unpack) {
+    // one 16-byte chunk per thread; grid-stride over B*T*P*Cl/8 chunks, local layout index fastest along channels
+    const int cpr = Cl >> 3;                                  // chunks per (token, slab)
+    const int64_t total = (int64_t)B * T * P * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int c8 = (int)(r % cpr); r /= cpr;
+        const int p = (int)(r % P); r /= P;
+        const int t = (int)(r % T);
+        const int b = (int)(r / T);
+        const u32x4* loc = reinterpret_cast<const u32x4*>(x + ((int64_t)b * T + t) * ldx + (int64_t)p * Cl) + c8;
+        u32x4* wire = reinterpret_cast<u32x4*>(out + (((int64_t)p * T + t) * B + b) * Cl) + c8;
+        if (unpack) *const_cast<u32x4*>(loc) = *wire;        // `x` is the destination [B][T][ldx], `out` the wire buffer
+        else *wire = *loc;
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_unpack_vt_kernel(const bf16_t* __restrict__ wire, bf16_t* __restrict__ vt, int64_t ldvt,
+                                                           int P, int B, int Cl, int T) {
+    const int tpr = T >> 3;                                   // chunks per (source, channel, sample)
+    const int64_t total = (int64_t)P * Cl * B * tpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int t8 = (int)(r % tpr); r /= tpr;
+        const int b = (int)(r % B); r /= B;
+        const int c = (int)(r % Cl);
+        const int s = (int)(r / Cl);
+        const u32x4 v = reinterpret_cast<const u32x4*>(wire + (((int64_t)s * Cl + c) * B + b) * T)[t8];
+        reinterpret_cast<u32x4*>(vt + ((int64_t)b * Cl + c) * ldvt + (int64_t)s * T)[t8] = v;
+    }
+}
+}  // namespace
+
+static wan_status_t sp_check(const char* what, int P, int T, int B, int Cl) {
+    WAN_REQUIRE(P > 0 && T > 0 && B > 0 && Cl > 0 && Cl % 8 == 0, WAN_ERR_INVALID, "%s: P=%d T=%d B=%d Cl=%d (Cl must be a multiple of 8)",
+                what, P, T, B, Cl);
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_sp_pack_heads(const void* x, int64_t ldx, void* wire, int P, int T, int B, int Cl, void* stream) {
+    WAN_REQUIRE(x && wire, WAN_ERR_INVALID, "wan_sp_pack_heads: null tensor");
+    if (wan_status_t st = sp_check("wan_sp_pack_heads", P, T, B, Cl)) return st;
+    WAN_REQUIRE(ldx >= (int64_t)P * Cl && ldx % 8 == 0, WAN_ERR_INVALID, "wan_sp_pack_heads: ldx=%lld", (long long)ldx);
+    const int64_t total = (int64_t)B * T * P * (Cl >> 3);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(sp_pack_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)wire, P, T, B, Cl, false);
+    WAN_CHECK_LAUNCH("wan_sp_pack_heads");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_sp_unpack_heads(const void* wire, void* x, int64_t ldx, int P, int T, int B, int Cl, void* stream) {
+    WAN_REQUIRE(x && wire, WAN_ERR_INVALID, "wan_sp_unpack_heads: null tensor");
+    if (wan_status_t st = sp_check("wan_sp_unpack_heads", P, T, B, Cl)) return st;
+    WAN_REQUIRE(ldx >= (int64_t)P * Cl && ldx % 8 == 0, WAN_ERR_INVALID, "wan_sp_unpack_heads: ldx=%lld", (long long)ldx);
+    const int64_t total = (int64_t)B * T * P * (Cl >> 3);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(sp_pack_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)wire, P, T, B, Cl, true);
+    WAN_CHECK_LAUNCH("wan_sp_unpack_heads");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_sp_unpack_vt(const void* wire, void* vt, int64_t ldvt, int P, int B, int Cl, int T, void* stream) {
+    WAN_REQUIRE(vt && wire, WAN_ERR_INVALID, "wan_sp_unpack_vt: null tensor");
+    if (wan_status_t st = sp_check("wan_sp_unpack_vt", P, T, B, Cl)) return st;
+    WAN_REQUIRE(T % 8 == 0 && ldvt >= (int64_t)P * T && ldvt % 8 == 0, WAN_ERR_INVALID, "wan_sp_unpack_vt: T=%d ldvt=%lld (T %% 8 == 0, ldvt >= P*T)",
+                T, (long long)ldvt);
+    const int64_t total = (int64_t)P * Cl * B * (T >> 3);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(sp_unpack_vt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)wire, (bf16_t*)vt, ldvt, P, B, Cl, T);
+    WAN_CHECK_LAUNCH("wan_sp_unpack_vt");
     return WAN_OK;
 }

@@ -97,11 +97,13 @@ template <int NV>   // 16-byte chunks (8 bf16) per thread
 __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ x0, const float* __restrict__ w0, bf16_t* __restrict__ x1,
     const float* __restrict__ w1, int64_t ld, int dim, int head_dim, float eps,
-    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp, float x0_scale) {
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp, float x0_scale,
+    bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, int out_slabs, int out_batch) {
     __shared__ float red[kWaves];
     __shared__ __attribute__((aligned(16))) float2 cs[128];   // (cos, sin) of this token's head_dim/2 pairs
     const int64_t row = blockIdx.x;
     bf16_t* xb = blockIdx.y == 0 ? x0 : x1;
+    bf16_t* ob = blockIdx.y == 0 ? out0 : out1;               // nullptr: in place
     const float* w = blockIdx.y == 0 ? w0 : w1;
     u32x4* xr = reinterpret_cast<u32x4*>(xb + row * ld);
     const int nchunk = dim >> 3;
@@ -164,7 +166,16 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
                 }
                 o[j] = pack_bf16x2(a, b);
             }
-            xr[idx] = o;
+            if (ob == nullptr) {
+                xr[idx] = o;
+            } else {
+                // Ulysses send layout [slab][t][b][Cl] (layout_kernels.hip): the row's channels are split into `out_slabs` head
+                // groups, one per destination rank, so the all-to-all sends this buffer as it stands
+                const int Cl = dim / out_slabs, c = idx << 3;
+                const int slab = c / Cl, cl = c - slab * Cl;
+                const int64_t bi = row / rp.rows_per_batch, t = row - bi * rp.rows_per_batch;
+                *reinterpret_cast<u32x4*>(ob + (((int64_t)slab * rp.rows_per_batch + t) * out_batch + bi) * Cl + cl) = o;
+            }
         }
     }
 }
@@ -252,11 +263,20 @@ extern "C" wan_status_t wan_quantize_rows_fp8(const void* x_bf16, int64_t ldx, v
     return WAN_OK;
 }
 
-extern "C" wan_status_t wan_rmsnorm_rope(void* x0, const float* w0, void* x1, const float* w1,
-                                         int64_t ld, int64_t rows, int dim, int head_dim, float eps,
-                                         const float* rope_cos, const float* rope_sin,
-                                         const wan_rope_params* rp, float x0_scale, void* stream) {
+static wan_status_t rmsnorm_rope_impl(void* x0, const float* w0, void* x1, const float* w1,
+                                      int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                      const float* rope_cos, const float* rope_sin,
+                                      const wan_rope_params* rp, float x0_scale, void* out0, void* out1, int out_slabs,
+                                      int out_batch, void* stream) {
     WAN_REQUIRE(x0 && w0, WAN_ERR_INVALID, "wan_rmsnorm_rope: null tensor");
+    if (out0 || out1) {
+        WAN_REQUIRE(rp != nullptr && rope_cos != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: needs rope tables and parameters");
+        WAN_REQUIRE(out0 != nullptr && (out1 != nullptr) == (x1 != nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: one output per input tensor");
+        WAN_REQUIRE(out_slabs > 0 && out_batch > 0 && dim % out_slabs == 0 && (dim / out_slabs) % 8 == 0 &&
+                        rows == (int64_t)out_batch * rp->rows_per_batch, WAN_ERR_INVALID,
+                    "wan_rmsnorm_rope_sp: slabs=%d batch=%d rows=%lld rows_per_batch=%lld dim=%d", out_slabs, out_batch,
+                    (long long)rows, (long long)rp->rows_per_batch, dim);
+    }
     WAN_REQUIRE(x0_scale == x0_scale && x0_scale != 0.f, WAN_ERR_INVALID, "wan_rmsnorm_rope: x0_scale must be a non-zero number (1 = none)");
     WAN_REQUIRE((x1 == nullptr) == (w1 == nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope: x1/w1 must both be set or both NULL");
     WAN_REQUIRE(dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= dim, WAN_ERR_INVALID,
@@ -282,9 +302,25 @@ extern "C" wan_status_t wan_rmsnorm_rope(void* x0, const float* w0, void* x1, co
     hipStream_t s = (hipStream_t)stream;
     const int nv = (dim / 8 + kThreads - 1) / kThreads;
     dim3 grid((unsigned)rows, x1 ? 2 : 1), block(kThreads);
-#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale); break;
+#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch); break;
     switch (nv) { RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) }
 #undef RR_CASE
     WAN_CHECK_LAUNCH("wan_rmsnorm_rope");
     return WAN_OK;
+}
+
+extern "C" wan_status_t wan_rmsnorm_rope(void* x0, const float* w0, void* x1, const float* w1,
+                                         int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                         const float* rope_cos, const float* rope_sin,
+                                         const wan_rope_params* rp, float x0_scale, void* stream) {
+    return rmsnorm_rope_impl(x0, w0, x1, w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp, x0_scale, nullptr, nullptr, 1, 1, stream);
+}
+
+extern "C" wan_status_t wan_rmsnorm_rope_sp(const void* x0, const float* w0, const void* x1, const float* w1,
+                                            int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                            const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                            float x0_scale, void* wire0, void* wire1, int slabs, int batch, void* stream) {
+    WAN_REQUIRE(wire0 != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: null wire buffer");
+    return rmsnorm_rope_impl(const_cast<void*>(x0), w0, const_cast<void*>(x1), w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp,
+                             x0_scale, wire0, wire1, slabs, batch, stream);
 }

@@ -56,6 +56,43 @@ class SequenceParallelGroup:
             return None
         return dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
 
+    # ------------------------------------------------------------------ wire-layout exchange (the DiT's per-layer path)
+    # The model writes q / k / V^T straight into the send layouts of include/wan_hip.h (a21) from its kernels' epilogues
+    # and reads the arrived buffers in place, so per layer the exchange layer adds nothing but the collective:
+    # `exchange` is ONE all_to_all_single with equal splits between two persistent flat buffers.
+    def exchange(self, recv: torch.Tensor, send: torch.Tensor, async_op: bool = False):
+        """recv[s-th slab] <- send[my slab] of rank s (flat contiguous buffers of equal size, a multiple of P).
+        Returns a callable that waits for completion (async_op) or None."""
+        if send.numel() != recv.numel() or send.numel() % self.world_size or not (send.is_contiguous() and recv.is_contiguous()):
+            raise ValueError("exchange: send / recv must be contiguous, of equal size, divisible by the group size")
+        work = self._a2a(recv.view(-1), send.view(-1), async_op)
+        if not async_op:
+            return None
+        return (lambda: work.wait()) if work is not None else (lambda: None)
+
+    # torch statements of the wire layouts (CPU tests and documentation; the GPU path uses wan_sp_* / wan_rmsnorm_rope_sp)
+    def pack_heads_ref(self, x: torch.Tensor) -> torch.Tensor:
+        """[B, T, C] -> token-major wire [P, T, B, C/P]."""
+        B, T, C = x.shape
+        return x.reshape(B, T, self.world_size, C // self.world_size).permute(2, 1, 0, 3).contiguous()
+
+    def unpack_heads_ref(self, wire: torch.Tensor) -> torch.Tensor:
+        """arrived token-major wire [P, T, B, Cl] -> [B, T, P*Cl] (column s * Cl + c: the o projection's input)."""
+        P, T, B, Cl = wire.shape
+        return wire.permute(2, 1, 0, 3).reshape(B, T, P * Cl)
+
+    def pack_vt_ref(self, vt: torch.Tensor) -> torch.Tensor:
+        """[B, C, T] -> channel-major wire [P, C/P, B, T] (what the V projection writes per sample with ldo = B*T)."""
+        B, C, T = vt.shape
+        return vt.reshape(B, self.world_size, C // self.world_size, T).permute(1, 2, 0, 3).contiguous()
+
+    def unpack_vt_ref(self, wire: torch.Tensor, ld: int) -> torch.Tensor:
+        """arrived channel-major wire [P, Cl, B, T] -> [B, Cl, ld] with column s * T + t (pad columns zero)."""
+        P, Cl, B, T = wire.shape
+        out = torch.zeros(B, Cl, ld, dtype=wire.dtype, device=wire.device)
+        out[:, :, :P * T].view(B, Cl, P, T).copy_(wire.permute(2, 1, 0, 3))
+        return out
+
     # token-sharded [B, Ll, C] -> head-sharded [B, P*Ll, C/P]; `x` may be a strided view
     def scatter_heads(self, x: torch.Tensor, async_op: bool = False):
         P = self.world_size

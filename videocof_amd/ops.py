@@ -122,6 +122,72 @@ def rmsnorm_rope_(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor]
                                     float(x0_scale), _stream()), "wan_rmsnorm_rope")
 
 
+@_on_tensor_device
+def rmsnorm_rope_sp(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor], w1: Optional[torch.Tensor], head_dim: int,
+                    eps: float, rope: Tuple[torch.Tensor, torch.Tensor], rope_params: RopeParams, wire0: torch.Tensor,
+                    wire1: Optional[torch.Tensor], slabs: int, batch: int, x0_scale: float = 1.0) -> None:
+    """``rmsnorm_rope_`` that leaves x0 / x1 untouched and writes the results into Ulysses token-major wire buffers
+    ``[slabs][rows_per_batch][batch][dim / slabs]`` (include/wan_hip.h, a21)."""
+    _need(x0, torch.bfloat16, "rmsnorm_rope_sp.x0")
+    _need(w0, torch.float32, "rmsnorm_rope_sp.w0")
+    rows, dim = x0.shape
+    ld = x0.stride(0)
+    for nm, t in (("wire0", wire0), ("wire1", wire1)):
+        if t is not None:
+            _need(t, torch.bfloat16, "rmsnorm_rope_sp." + nm)
+            if not t.is_contiguous() or t.numel() < rows * dim:
+                raise ValueError(f"rmsnorm_rope_sp.{nm} must be contiguous with >= rows * dim elements")
+    if x1 is not None:
+        _need(x1, torch.bfloat16, "rmsnorm_rope_sp.x1")
+        _need(w1, torch.float32, "rmsnorm_rope_sp.w1")
+        if x1.shape != x0.shape or x1.stride(0) != ld or wire1 is None:
+            raise ValueError("rmsnorm_rope_sp: x0 / x1 must share shape and row stride, and x1 needs wire1")
+    cos, sin = rope
+    lib = _lib.load()
+    _lib.check(lib.wan_rmsnorm_rope_sp(_p(x0), _p(w0), _p(x1), _p(w1), ld, rows, dim, head_dim, float(eps), _p(cos), _p(sin),
+                                       ctypes.byref(rope_params), float(x0_scale), _p(wire0), _p(wire1), int(slabs), int(batch),
+                                       _stream()), "wan_rmsnorm_rope_sp")
+
+
+@_on_tensor_device
+def sp_pack_heads(x: torch.Tensor, wire: torch.Tensor, P: int, T: int, B: int) -> torch.Tensor:
+    """x bf16 [B*T, ldx >= C] (C = P * Cl) -> token-major wire [P][T][B][Cl]."""
+    _need(x, torch.bfloat16, "sp_pack_heads.x")
+    _need(wire, torch.bfloat16, "sp_pack_heads.wire")
+    C = x.shape[1]
+    if x.shape[0] != B * T or C % P or not wire.is_contiguous() or wire.numel() < B * T * C:
+        raise ValueError("sp_pack_heads: shapes disagree")
+    lib = _lib.load()
+    _lib.check(lib.wan_sp_pack_heads(_p(x), x.stride(0), _p(wire), P, T, B, C // P, _stream()), "wan_sp_pack_heads")
+    return wire
+
+
+@_on_tensor_device
+def sp_unpack_heads(wire: torch.Tensor, x: torch.Tensor, P: int, T: int, B: int) -> torch.Tensor:
+    """token-major wire [P][T][B][Cl] -> x bf16 [B*T, ldx >= P*Cl] (column s * Cl + c)."""
+    _need(x, torch.bfloat16, "sp_unpack_heads.x")
+    _need(wire, torch.bfloat16, "sp_unpack_heads.wire")
+    C = x.shape[1]
+    if x.shape[0] != B * T or C % P or not wire.is_contiguous() or wire.numel() < B * T * C:
+        raise ValueError("sp_unpack_heads: shapes disagree")
+    lib = _lib.load()
+    _lib.check(lib.wan_sp_unpack_heads(_p(wire), _p(x), x.stride(0), P, T, B, C // P, _stream()), "wan_sp_unpack_heads")
+    return x
+
+
+@_on_tensor_device
+def sp_unpack_vt(wire: torch.Tensor, vt: torch.Tensor, P: int, T: int) -> torch.Tensor:
+    """arrived channel-major wire [P][Cl][B][T] -> vt bf16 [B, Cl, ldvt >= P*T], column s * T + t."""
+    _need(vt, torch.bfloat16, "sp_unpack_vt.vt")
+    _need(wire, torch.bfloat16, "sp_unpack_vt.wire")
+    B, Cl, ldvt = vt.shape
+    if not wire.is_contiguous() or wire.numel() < P * Cl * B * T or not vt.is_contiguous():
+        raise ValueError("sp_unpack_vt: shapes disagree")
+    lib = _lib.load()
+    _lib.check(lib.wan_sp_unpack_vt(_p(wire), _p(vt), ldvt, P, B, Cl, T, _stream()), "wan_sp_unpack_vt")
+    return vt
+
+
 def q_prescale(head_dim: int, softmax_scale: Optional[float] = None) -> float:
     """The factor q must carry for ``attention_fwd(q_prescaled=True)``: softmax_scale * log2(e)."""
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(head_dim)

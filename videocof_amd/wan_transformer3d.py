@@ -482,8 +482,17 @@ class WanTransformer3DModel(nn.Module):
         b.att = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         b.cq = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         b.ff = torch.empty(M, self.ffn_dim, device=dev, dtype=torch.bfloat16)
-        # V^T pad columns [L, roundup(L, 64)) are never written and must stay finite: zero them once
-        b.vt = torch.zeros(B, C, ops.round_up(L, 64) if self.sp_world_size == 1 else Ll, device=dev, dtype=torch.bfloat16)
+        P = self.sp_world_size
+        if P == 1:
+            # V^T pad columns [L, roundup(L, 64)) are never written and must stay finite: zero them once
+            b.vt = torch.zeros(B, C, ops.round_up(L, 64), device=dev, dtype=torch.bfloat16)
+        else:
+            # Ulysses wire buffers (include/wan_hip.h a21), persistent: send / receive pairs for k, q, V^T and o, and the
+            # head-sharded V^T the attention kernel reads (pad columns [P*Ll, ld) zeroed once, never written again)
+            b.vt = None
+            for name in ("kw_s", "kw_r", "qw_s", "qw_r", "vw_s", "vw_r", "ow_s", "ow_r"):
+                setattr(b, name, torch.empty(M * C, device=dev, dtype=torch.bfloat16))
+            b.vt_full = torch.zeros(B, C // P, ops.round_up(seq_len, 64), device=dev, dtype=torch.bfloat16)
         b.qk3 = b.qk.view(B, Ll, 2 * C)
         if self._fp8:
             b.hq = torch.empty(M, C, device=dev, dtype=ops.FP8)
@@ -532,24 +541,36 @@ class WanTransformer3DModel(nn.Module):
             self._event_done(ev, B * Ll)
             o_in = att
         else:
-            # Ulysses: each projection is followed at once by its own head exchange (async, on RCCL's stream), so
-            # the k exchange runs under the V projection and the V^T exchange under the q projection; only the q
-            # exchange is left exposed before the attention launch.
-            sp = self._sp
+            # Ulysses.  Every projection writes its result straight into the send layout of its own exchange (k, q: the
+            # RMSNorm+RoPE kernel's wire output; V^T: the transposed GEMM epilogue with ldo = B * Ll) and is followed at once
+            # by that exchange (async, on RCCL's stream): the k exchange runs under the V projection, the V^T exchange under
+            # the q projection, only the q exchange is exposed.  The arrived q / k buffers ARE the attention operands
+            # ([P*Ll][B][C/P], uniform strides), the attention output IS the send buffer of the inverse exchange; the only
+            # re-layout passes per layer are wan_sp_unpack_vt and wan_sp_unpack_heads (2 x M*C bf16 each way).
+            sp, Cl, Lt = self._sp, C // P, P * Ll
             ops.gemm(h, blk.w_qk[C:], blk.b_qk[C:], ops.EPI_BF16, out=qk[:, C:])
-            ops.rmsnorm_rope_(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp)
-            fk = sp.scatter_heads(qk3[:, :, C:], async_op=True)
+            ops.rmsnorm_rope_sp(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp, bufs.kw_s, None, P, B)
+            wait_k = sp.exchange(bufs.kw_r, bufs.kw_s, async_op=True)
+            vsend = bufs.vw_s.view(C, B, Ll)
             for b in range(B):
-                ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
-            fv = sp.scatter_heads_t(vt, ld=ops.round_up(seq_len, 64), async_op=True)
+                ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vsend[:, b])
+            wait_v = sp.exchange(bufs.vw_r, bufs.vw_s, async_op=True)
             ops.gemm(h, blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[:, :C])
-            ops.rmsnorm_rope_(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
-            fq = sp.scatter_heads(qk3[:, :, :C], async_op=True)
-            q_full, k_full, vt_full = fq().contiguous(), fk().contiguous(), fv()
+            ops.rmsnorm_rope_sp(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, bufs.qw_s, None, P, B,
+                                x0_scale=self._qs)
+            wait_q = sp.exchange(bufs.qw_r, bufs.qw_s, async_op=True)
+            wait_k()
+            wait_v()
+            ops.sp_unpack_vt(bufs.vw_r, bufs.vt_full, P, Ll)
+            wait_q()
+            as_bld = lambda w: w.view(Lt, B, Cl).permute(1, 0, 2)          # [B, P*Ll, Cl] view: row stride B*Cl, sample stride Cl
             ev = self._event_pair()
-            o_full = ops.attention_fwd(q_full, k_full, vt_full, H // P, k_len=L, q_prescaled=True, workspace=self._ws_self)
+            ops.attention_fwd(as_bld(bufs.qw_r), as_bld(bufs.kw_r), bufs.vt_full, H // P, k_len=L, out=as_bld(bufs.ow_s),
+                              q_prescaled=True, workspace=self._ws_self)
             self._event_done(ev, B * seq_len)
-            o_in = sp.gather_heads(o_full).reshape(M, C)
+            sp.exchange(bufs.ow_r, bufs.ow_s)
+            ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B)
+            o_in = att
         ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
         # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
         ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
