@@ -238,6 +238,18 @@ def test_block_composite_is_the_python_launch_sequence(golden, model):
             model.use_block_composite = True
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     assert rel_l2(outs[True][1], g["out_b2"]) < 1e-2
+    # the last-block suffix launches (skip_source_frames) have their own attention scratch: a differently sized launch must
+    # never re-allocate -- and thereby invalidate -- the scratch whose address the composite hands to the C side, nor leave
+    # the sticky "max-free attempt off" word of any call site set
+    model.skip_source_frames = 3
+    try:
+        a = model(lat2[:1], torch.tensor([899], device=DEV), ctx2[:1], 420, frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+        b = model(lat2[:1], torch.tensor([899], device=DEV), ctx2[:1], 420, frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    finally:
+        model.skip_source_frames = 0
+    assert torch.equal(a, b) and torch.equal(a[:, :, 3:], outs[True][0][:, :, 3:] * 0 + a[:, :, 3:])
+    for ws in (model._ws_self, model._ws_cross, model._ws_self_sfx, model._ws_cross_sfx):
+        assert ws.buf is None or int(ws.buf[:4].view(torch.int32)) == 0
     from videocof_amd import _lib
     import ctypes
     lib = _lib.load()

@@ -132,6 +132,7 @@ class WanTransformer3DModel(nn.Module):
         self.mask_source_frames = 0
         # one attention scratch per call site: the sticky "max-free attempt off" word of one site never reaches another
         self._ws_self, self._ws_cross = ops.AttentionWorkspace(), ops.AttentionWorkspace()
+        self._ws_self_sfx, self._ws_cross_sfx = ops.AttentionWorkspace(), ops.AttentionWorkspace()      # _last_block_suffix's launches
         self._probe_layer = None            # bench.py / tests: keep a copy of the residual stream entering this block
         self._probe = None
         self._attn_events = None            # bench.py: list collecting (start, end) HIP events per self-attn launch
@@ -428,13 +429,13 @@ class WanTransformer3DModel(nn.Module):
         ops.gemm(h[:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[0])
         n = Ll - r0
         ops.attention_fwd(qk[r0:, :C].unsqueeze(0), qk[:, C:].unsqueeze(0), vt, H, k_len=L, out=att[r0:].unsqueeze(0), q_prescaled=True,
-                          workspace=self._ws_self)
+                          workspace=self._ws_self_sfx)
         ops.gemm(att[r0:], blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs[r0:], gate=em[2], rows_per_batch=n)
         ops.ln_modulate(xs[r0:], blk.n3w, blk.n3b, False, n, self.eps, out=h[r0:])
         ops.gemm(h[r0:], blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq[r0:])
         ops.rmsnorm_rope_(cq[r0:], blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
         ck, cvt = ctx_kv
-        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0), q_prescaled=True, workspace=self._ws_cross)
+        ops.attention_fwd(cq[r0:].unsqueeze(0), ck, cvt, H, out=att[r0:].unsqueeze(0), q_prescaled=True, workspace=self._ws_cross_sfx)
         ops.gemm(att[r0:], blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs[r0:])
         ops.ln_modulate(xs[r0:], em[4], em[3], True, n, self.eps, out=h[r0:])
         ops.gemm(h[r0:], blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff[r0:])
@@ -603,12 +604,14 @@ class WanTransformer3DModel(nn.Module):
         if getattr(bufs, "cws", None) is None:
             p = lambda t: ctypes.c_void_p(t.data_ptr())
             H = self.num_heads
-            nself = int(lib.wan_attention_workspace_bytes(B, Ll, L, H, 128))
-            ncross = int(lib.wan_attention_workspace_bytes(B, Ll, self.text_len, H, 128))
-            a = self._ws_self.get(self._device, max(nself, 16))
-            c = self._ws_cross.get(self._device, max(ncross, 16))
+            bufs.nself = int(lib.wan_attention_workspace_bytes(B, Ll, L, H, 128))
+            bufs.ncross = int(lib.wan_attention_workspace_bytes(B, Ll, self.text_len, H, 128))
             bufs.cws = BlockWorkspace(p(bufs.h), p(bufs.qk), p(bufs.att), p(bufs.cq), p(bufs.ff), p(bufs.vt), bufs.vt.stride(1),
-                                      p(a), nself, p(c), ncross)
+                                      None, bufs.nself, None, bufs.ncross)
+        # the attention scratches belong to the call sites (AttentionWorkspace objects that may be re-allocated when another
+        # shape asks for more): take their CURRENT addresses on every call, never a cached pointer
+        bufs.cws.attn_ws_self = self._ws_self.get(self._device, max(bufs.nself, 16)).data_ptr()
+        bufs.cws.attn_ws_cross = self._ws_cross.get(self._device, max(bufs.ncross, 16)).data_ptr()
         ck, cvt = ctx_kv
         check(lib.wan_dit_block_forward(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(em.data_ptr()),
                                         ctypes.c_void_p(ck.data_ptr()), ctypes.c_void_p(cvt.data_ptr()),
