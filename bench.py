@@ -379,8 +379,9 @@ def main():
         flop = 4.0 * Lq * Lk * heads_local * 128
         ach = flop / (avg_ms * 1e-3) / 1e12
         traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1)
-        roof = {"kernel": "attn_fwd_v2_kernel<0, true, false, 1> = self-attention, pre-scaled q, max-free MODE 1 (per wan_attention_fwd call: "
-                          "this main launch + its MODE 2 fix-up launch + the split-KV tail round <0, true, true, 0> + merge)", "bound": "mfma", "achieved": round(ach, 1),
+        roof = {"kernel": "attn_fwd_w4_kernel<0> = self-attention, pre-scaled q, max-free 4-wave kernel (per wan_attention_fwd call: this "
+                          "main launch + the MODE 2 fix-up launch attn_fwd_v2_kernel<0, true, false, 2> + the split-KV tail round "
+                          "attn_fwd_v2_kernel<0, true, true, 0> + merge)", "bound": "mfma", "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
