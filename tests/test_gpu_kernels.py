@@ -610,3 +610,24 @@ def test_sp_wire_layout_kernels(rope_dev, P, T, B, Cl):
         ops.rmsnorm_rope_sp(xin, w, None, None, 128, 1e-6, rope_dev, rp, w2, None, P, B, x0_scale=0.37)
         assert torch.equal(xin, keep)                                           # the input is not modified
         assert torch.equal(w2.view(P, T, B, Cl), ref("pack_heads_ref", inplace.view(B, T, C)))
+
+
+def test_attention_debug_check_catches_non_finite_vt_padding():
+    """The one caller contract the kernels cannot enforce -- V^T pad columns [Lk, roundup(Lk, 64)) finite -- is checked
+    (synchronising) when the `debug_checks` switch is on, and costs nothing when it is off."""
+    Lq, Lk, H = 256, 100, 1
+    g = torch.Generator(device=DEV).manual_seed(3)
+    q = torch.randn(1, Lq, 128, device=DEV, generator=g).bfloat16()
+    k = torch.randn(1, Lk, 128, device=DEV, generator=g).bfloat16()
+    vt = torch.zeros(1, 128, 128, device=DEV, dtype=torch.bfloat16)
+    vt[:, :, :Lk] = torch.randn(1, 128, Lk, device=DEV, generator=g).bfloat16()
+    good = ops.attention_fwd(q, k, vt, H, k_len=Lk)
+    vt[0, 5, Lk + 3] = float("nan")
+    ops.set_tuning("debug_checks", 1)
+    try:
+        with pytest.raises(ValueError, match="pad columns"):
+            ops.attention_fwd(q, k, vt, H, k_len=Lk)
+        vt[0, 5, Lk + 3] = 0
+        assert torch.equal(ops.attention_fwd(q, k, vt, H, k_len=Lk), good)
+    finally:
+        ops.set_tuning("debug_checks", 0)
