@@ -259,6 +259,38 @@ wan_status_t wan_dit_block_forward(float* x, const float* emod, const void* ctx_
 wan_status_t wan_dit_block_workspace_bytes(int dim, int ffn_dim, int batch, int64_t rows_per_batch, int64_t valid_tokens,
                                            int64_t* bytes /* [6]: h, qk, att, cq, ff, vt */, int64_t* ldvt);
 
+/* ---------------------------------------------------------------------------
+ * a11' The token path of WanTransformer3DModel.forward (wan_transformer3d.py:870-879, 1034-1083, 535-548, 1108-1131) as one
+ *      call: patchify -> patch-embedding GEMM -> num_layers x wan_dit_block_forward -> head LN-modulate -> head GEMM ->
+ *      unpatchify.  The embedding MLPs stay with the host and arrive as inputs:
+ *      latent  [batch][in_dim][F][H][W] (latent_dtype 0 fp32 | 1 bf16); out the same shape with out_dim channels
+ *      emod    fp32 [num_layers][6][batch][dim]   `modulation + time_projection(e)` of every block (:494, :899-901)
+ *      ehead   fp32 [2][batch][dim]               `head.modulation + e` (shift, scale; :545)
+ *      ctx_k / ctx_vt  host arrays of num_layers device pointers: the text K and V^T of each block (wan_dit_block_forward)
+ *      rp      grid = (F/pt, H/ph, W/pw); rows_per_batch >= tokens (pad rows are zero on entry to the first block)
+ *      zero_frames as wan_unpatchify.  Workspace: the block workspace plus x fp32 [batch*rows_per_batch, dim],
+ *      tokens bf16 [tokens, in_dim*pt*ph*pw], head_out fp32 [batch*rows_per_batch, pt*ph*pw*out_dim].
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int num_layers, in_dim, out_dim, pt, ph, pw;
+    const wan_block_weights* blocks;                /* [num_layers] */
+    const void* pe_w; const float* pe_b;            /* patch_embedding as a GEMM: bf16 [dim, in_dim*pt*ph*pw] */
+    const void* head_w; const float* head_b;        /* head.head: bf16 [pt*ph*pw*out_dim, dim] */
+} wan_dit_weights;
+
+typedef struct {
+    wan_block_workspace block;
+    float* x;
+    void* tokens;
+    float* head_out;
+} wan_dit_workspace;
+
+wan_status_t wan_dit_forward(const void* latent, int latent_dtype, void* out, int out_dtype, const float* emod,
+                             const float* ehead, const void* const* ctx_k, const void* const* ctx_vt,
+                             const wan_dit_weights* w, const wan_dit_workspace* ws, const float* rope_cos,
+                             const float* rope_sin, const wan_rope_params* rp, int batch, int F, int H, int W,
+                             int64_t rows_per_batch, int zero_frames, void* stream);
+
 /* a17  UniPC updates as one fused pass: out[i] = c0*x0[i] + c1*x1[i] + c2*x2[i] + c3*x3[i] (x1..x3 may be
  *      NULL), fp32 accumulate, all tensors of one dtype (0 fp32, 1 bf16).
  *      replaces: the elementwise chains of convert_model_output / multistep_uni_p_bh_update /

@@ -261,6 +261,43 @@ def test_block_composite_is_the_python_launch_sequence(golden, model):
     assert st == _lib.WAN_ERR_INVALID
 
 
+def test_forward_composite_is_the_python_launch_sequence(golden, model):
+    """wan_dit_forward (the whole token path as one C call) against the per-block composite and the per-op Python sequence:
+    bit-identical for fp32 and bf16 latents, B = 1 padded and B = 2, with the CoF mask folded into the unpatchify; the raw
+    entry rejects null arguments."""
+    g = golden("dit_g6_forward")
+    lat2 = torch.from_numpy(g["lat2"]).to(DEV)
+    ctx2 = [torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx2"]).to(DEV)]
+    t1, t2 = torch.tensor([899], device=DEV), torch.tensor([749, 749], device=DEV)
+    kw1 = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    kw2 = dict(frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
+    outs = {}
+    for name, fwd, blk in (("forward", True, True), ("block", False, True), ("ops", False, False)):
+        model.use_forward_composite, model.use_block_composite = fwd, blk
+        try:
+            model.mask_source_frames = 0
+            a = model(lat2[:1], t1, ctx2[:1], 448, **kw1)
+            b = model(lat2, t2, ctx2, 420, **kw2)
+            c = model(lat2.bfloat16(), t2, ctx2, 420, **kw2)
+            model.mask_source_frames = 3
+            d = model(lat2[:1], t1, ctx2[:1], 420, **kw1)
+            outs[name] = (a, b, c, d)
+        finally:
+            model.use_forward_composite = model.use_block_composite = True
+            model.mask_source_frames = 0
+    for name in ("block", "ops"):
+        for u, v in zip(outs["forward"], outs[name]):
+            assert u.dtype == v.dtype and torch.equal(u, v), name
+    assert rel_l2(outs["forward"][1], g["out_b2"]) < 1e-2
+    assert outs["forward"][2].dtype == torch.bfloat16
+    d = outs["forward"][3]
+    assert float(d[:, :, :3].abs().max()) == 0 and float(d[:, :, 3:].abs().max()) > 0
+    from videocof_amd import _lib
+    lib = _lib.load()
+    st = lib.wan_dit_forward(None, 0, None, 0, None, None, None, None, None, None, None, None, None, 1, 7, 12, 20, 420, 0, None)
+    assert st == _lib.WAN_ERR_INVALID
+
+
 def test_g7_sched50_on_device(golden):
     g50 = golden("dit_g7_sched50")
     s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)

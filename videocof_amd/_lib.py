@@ -50,6 +50,17 @@ class BlockWorkspace(Structure):
                  ("attn_ws_cross", c_void_p), ("attn_ws_cross_bytes", c_int64)])
 
 
+class DitWeights(Structure):
+    """``wan_dit_weights`` of include/wan_hip.h."""
+    _fields_ = ([(n, c_int) for n in ("num_layers", "in_dim", "out_dim", "pt", "ph", "pw")] +
+                [("blocks", POINTER(BlockWeights))] + [(n, c_void_p) for n in ("pe_w", "pe_b", "head_w", "head_b")])
+
+
+class DitWorkspace(Structure):
+    """``wan_dit_workspace`` of include/wan_hip.h."""
+    _fields_ = [("block", BlockWorkspace), ("x", c_void_p), ("tokens", c_void_p), ("head_out", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "wan_abi_version": (c_int, []),
@@ -70,6 +81,9 @@ SIGNATURES = {
     "wan_sp_unpack_vt": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_dit_block_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockWeights), POINTER(BlockWorkspace),
                                       c_void_p, c_void_p, POINTER(RopeParams), c_int, c_int64, c_int64, c_void_p]),
+    "wan_dit_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                POINTER(DitWeights), POINTER(DitWorkspace), c_void_p, c_void_p, POINTER(RopeParams),
+                                c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "wan_dit_block_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64)]),
     "wan_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                              c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),

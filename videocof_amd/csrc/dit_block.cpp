@@ -79,3 +79,57 @@ extern "C" wan_status_t wan_dit_block_workspace_bytes(int dim, int ffn_dim, int 
     bytes[4] = M * ffn_dim * 2; bytes[5] = (int64_t)batch * dim * *ldvt * 2;
     return WAN_OK;
 }
+
+// The token path of WanTransformer3DModel.forward (videox_fun/models/wan_transformer3d.py:870-879 patch embedding,
+// :1034-1083 the block loop, :535-548 head, :1108-1131 unpatchify) as ONE C call: patchify -> patch-embedding GEMM into the
+// fp32 residual stream -> num_layers x wan_dit_block_forward -> head LN-modulate -> head GEMM -> unpatchify (with the CoF
+// mask).  The two embedding MLPs that feed it (time: :891-901, text: :915-919 -- a few GFLOP per call, fp32 / bf16 GEMMs of
+// this library or the host's) stay with the host: their results arrive as `emod`, `ehead`, `ctx_k`, `ctx_vt`.
+extern "C" wan_status_t wan_dit_forward(const void* latent, int latent_dtype, void* out, int out_dtype, const float* emod,
+                                        const float* ehead, const void* const* ctx_k, const void* const* ctx_vt,
+                                        const wan_dit_weights* w, const wan_dit_workspace* ws, const float* rope_cos,
+                                        const float* rope_sin, const wan_rope_params* rp, int batch, int F, int H, int W,
+                                        int64_t rows_per_batch, int zero_frames, void* stream) {
+    WAN_REQUIRE(latent && out && emod && ehead && ctx_k && ctx_vt && w && ws && rp, WAN_ERR_INVALID, "wan_dit_forward: null argument");
+    WAN_REQUIRE(w->num_layers > 0 && w->blocks && w->pe_w && w->pe_b && w->head_w && w->head_b, WAN_ERR_INVALID,
+                "wan_dit_forward: incomplete weights");
+    WAN_REQUIRE(ws->x && ws->tokens && ws->head_out, WAN_ERR_INVALID, "wan_dit_forward: null workspace");
+    const int pt = w->pt, ph = w->ph, pw = w->pw;
+    WAN_REQUIRE(pt > 0 && ph > 0 && pw > 0 && F > 0 && H > 0 && W > 0 && F % pt == 0 && H % ph == 0 && W % pw == 0, WAN_ERR_INVALID,
+                "wan_dit_forward: latent (%d,%d,%d) is not a multiple of the patch (%d,%d,%d)", F, H, W, pt, ph, pw);
+    const int gf = F / pt, gh = H / ph, gw = W / pw;
+    const int64_t L = (int64_t)gf * gh * gw, Ll = rows_per_batch;
+    WAN_REQUIRE(batch > 0 && L <= Ll && (int64_t)batch * Ll <= 0x7fffffff, WAN_ERR_INVALID,
+                "wan_dit_forward: batch=%d tokens=%lld rows_per_batch=%lld", batch, (long long)L, (long long)Ll);
+    WAN_REQUIRE(rp->F == gf && rp->Hp == gh && rp->Wp == gw, WAN_ERR_INVALID, "wan_dit_forward: rope grid (%d,%d,%d) != latent grid (%d,%d,%d)",
+                rp->F, rp->Hp, rp->Wp, gf, gh, gw);
+    const int C = w->blocks[0].dim;
+    const int pv = pt * ph * pw, Kpe = w->in_dim * pv, Nh = w->out_dim * pv;
+    const int64_t M = (int64_t)batch * Ll;
+    const int64_t lat_el = latent_dtype == 0 ? 4 : 2, out_el = out_dtype == 0 ? 4 : 2;
+    WAN_REQUIRE((latent_dtype == 0 || latent_dtype == 1) && (out_dtype == 0 || out_dtype == 1), WAN_ERR_INVALID,
+                "wan_dit_forward: dtypes must be 0 (fp32) or 1 (bf16)");
+
+    // pad rows (token >= L) enter the stream as zeros, exactly as torch.cat([u, u.new_zeros(...)]) leaves them (:907-909)
+    WAN_REQUIRE(hipMemsetAsync(ws->x, 0, (size_t)M * C * 4, (hipStream_t)stream) == hipSuccess, WAN_ERR_LAUNCH,
+                "wan_dit_forward: hipMemsetAsync failed");
+    for (int b = 0; b < batch; ++b) {
+        WAN_TRY(wan_patchify(at(latent, (int64_t)b * w->in_dim * F * H * W * lat_el), latent_dtype, ws->tokens, Kpe, w->in_dim, F, H, W,
+                             pt, ph, pw, stream));
+        WAN_TRY(wan_gemm_bf16(ws->tokens, Kpe, w->pe_w, Kpe, w->pe_b, ws->x + (int64_t)b * Ll * C, C, (int)L, C, Kpe, WAN_EPI_F32,
+                              nullptr, 0, stream));
+    }
+    const int64_t emod_layer = 6 * (int64_t)batch * C;
+    for (int l = 0; l < w->num_layers; ++l) {
+        WAN_REQUIRE(w->blocks[l].dim == C, WAN_ERR_INVALID, "wan_dit_forward: block %d has dim %d != %d", l, w->blocks[l].dim, C);
+        WAN_TRY(wan_dit_block_forward(ws->x, emod + l * emod_layer, ctx_k[l], ctx_vt[l], &w->blocks[l], &ws->block, rope_cos, rope_sin, rp,
+                                      batch, Ll, L, stream));
+    }
+    const int64_t bC = (int64_t)batch * C;                    // ehead = [shift][scale], each [batch][C] (Head.forward :545-547)
+    WAN_TRY(wan_ln_modulate(ws->x, ehead + bC, ehead, 1, ws->block.h, M, C, Ll, w->blocks[0].eps, stream));
+    WAN_TRY(wan_gemm_bf16(ws->block.h, C, w->head_w, C, w->head_b, ws->head_out, Nh, (int)M, Nh, C, WAN_EPI_F32, nullptr, 0, stream));
+    for (int b = 0; b < batch; ++b)
+        WAN_TRY(wan_unpatchify(ws->head_out + (int64_t)b * Ll * Nh, Nh, at(out, (int64_t)b * w->out_dim * F * H * W * out_el), out_dtype,
+                               w->out_dim, gf, gh, gw, pt, ph, pw, zero_frames, stream));
+    return WAN_OK;
+}

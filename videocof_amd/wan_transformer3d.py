@@ -120,6 +120,8 @@ class WanTransformer3DModel(nn.Module):
         self._ctx_cache = None
         self._fp8 = ()                      # enable_fp8_linear: which projections run in e4m3 (lossy, opt-in)
         self.use_block_composite = True     # single-device blocks through wan_dit_block_forward (one C call per block)
+        self.use_forward_composite = True   # ... and, when nothing hooks into the block loop, the whole token path through wan_dit_forward
+        self._cdw = None                    # ctypes wan_dit_weights of the loaded blocks (built on first use)
         self._bufs = None                   # cached activation workspaces of the last call shape (_workspaces)
         # Number of leading latent frames whose prediction the caller discards (WanPipeline zeroes
         # noise_pred[:, :, :condition_count], pipeline_wan.py:736).  When set (B = 1, no SP) the LAST block and
@@ -218,6 +220,7 @@ class WanTransformer3DModel(nn.Module):
             b._cw = None
             self.blocks.append(b)
         w["mod_all"] = torch.stack([b.modulation for b in self.blocks])        # [layers, 6, C]
+        self._cdw = None
         extra = [k for k in sd.keys() if k not in used]
         if strict and extra:
             raise KeyError(f"unexpected keys in state_dict: {extra[:5]}{'...' if len(extra) > 5 else ''}")
@@ -591,8 +594,9 @@ class WanTransformer3DModel(nn.Module):
             ops.gemm(h, blk.w1, blk.b1, ops.EPI_GELU_BF16, out=ff)
             ops.gemm(ff, blk.w2, blk.b2, ops.EPI_RESID_F32, out=xs, gate=em[5], rows_per_batch=Ll)
 
-    def _block_composite(self, blk: _Block, em, xs, bufs, ctx_kv, rp, B, Ll, L):
-        from ._lib import BlockWeights, BlockWorkspace, check, load
+    def _block_cw(self, blk: _Block):
+        """The block's weights as a ``wan_block_weights`` (built once; the tensors it points at live as long as the block)."""
+        from ._lib import BlockWeights
         import ctypes
         if getattr(blk, "_cw", None) is None:
             p = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -600,18 +604,61 @@ class WanTransformer3DModel(nn.Module):
                                    p(blk.w_qk), p(blk.w_v), p(blk.w_o), p(blk.w_cq), p(blk.w_co), p(blk.w1), p(blk.w2),
                                    p(blk.b_qk), p(blk.b_v), p(blk.b_o), p(blk.b_cq), p(blk.b_co), p(blk.b1), p(blk.b2),
                                    p(blk.nq), p(blk.nk), p(blk.ncq), p(blk.n3w), p(blk.n3b))
-        lib = load()
-        if getattr(bufs, "cws", None) is None:
+        return blk._cw
+
+    def _block_cws(self, bufs, holder, B, Ll, L):
+        """``wan_block_workspace`` over the cached activation buffers, kept on `holder.cws`."""
+        from ._lib import BlockWorkspace, load
+        import ctypes
+        if getattr(holder, "cws", None) is None:
+            lib = load()
             p = lambda t: ctypes.c_void_p(t.data_ptr())
             H = self.num_heads
             bufs.nself = int(lib.wan_attention_workspace_bytes(B, Ll, L, H, 128))
             bufs.ncross = int(lib.wan_attention_workspace_bytes(B, Ll, self.text_len, H, 128))
-            bufs.cws = BlockWorkspace(p(bufs.h), p(bufs.qk), p(bufs.att), p(bufs.cq), p(bufs.ff), p(bufs.vt), bufs.vt.stride(1),
-                                      None, bufs.nself, None, bufs.ncross)
+            holder.cws = BlockWorkspace(p(bufs.h), p(bufs.qk), p(bufs.att), p(bufs.cq), p(bufs.ff), p(bufs.vt), bufs.vt.stride(1),
+                                        None, bufs.nself, None, bufs.ncross)
         # the attention scratches belong to the call sites (AttentionWorkspace objects that may be re-allocated when another
         # shape asks for more): take their CURRENT addresses on every call, never a cached pointer
-        bufs.cws.attn_ws_self = self._ws_self.get(self._device, max(bufs.nself, 16)).data_ptr()
-        bufs.cws.attn_ws_cross = self._ws_cross.get(self._device, max(bufs.ncross, 16)).data_ptr()
+        holder.cws.attn_ws_self = self._ws_self.get(self._device, max(bufs.nself, 16)).data_ptr()
+        holder.cws.attn_ws_cross = self._ws_cross.get(self._device, max(bufs.ncross, 16)).data_ptr()
+        return holder.cws
+
+    def _forward_composite(self, x, emod, ehead, kvs, rp, bufs, B, Ll, L, out_dtype):
+        """The token path of forward as ONE C call (wan_dit_forward, include/wan_hip.h a11'): used when nothing hooks into
+        the block loop (no TeaCache, probes, fp8 projections, suffix-only last block, kernel events) on a single device."""
+        from ._lib import BlockWeights, DitWeights, DitWorkspace, check, load
+        import ctypes
+        lib, w, n = load(), self._w, self.num_layers
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        pt, ph, pw = self.patch_size
+        _, Cin, F, Hh, Ww = x.shape
+        if self._cdw is None:
+            arr = (BlockWeights * n)(*[self._block_cw(b) for b in self.blocks])
+            self._cdw = (DitWeights(n, self.in_dim, self.out_dim, pt, ph, pw, arr, p(w["pe_w"]), p(w["pe_b"]), p(w["head_w"]), p(w["head_b"])), arr)
+        if getattr(bufs, "dws", None) is None:
+            M, dev = B * Ll, self._device
+            bufs.xs = torch.empty(M, self.dim, device=dev, dtype=torch.float32)
+            bufs.tok = torch.empty(L, Cin * pt * ph * pw, device=dev, dtype=torch.bfloat16)
+            bufs.yt = torch.empty(M, w["head_w"].shape[0], device=dev, dtype=torch.float32)
+            bufs.dws = DitWorkspace()
+            bufs.dws.x, bufs.dws.tokens, bufs.dws.head_out = bufs.xs.data_ptr(), bufs.tok.data_ptr(), bufs.yt.data_ptr()
+        bufs.dws.block = self._block_cws(bufs, bufs, B, Ll, L)
+        ck = (ctypes.c_void_p * n)(*[kv[0].data_ptr() for kv in kvs])
+        cvt = (ctypes.c_void_p * n)(*[kv[1].data_ptr() for kv in kvs])
+        out = torch.empty(B, self.out_dim, F, Hh, Ww, device=self._device, dtype=out_dtype)
+        check(lib.wan_dit_forward(p(x), 0 if x.dtype == torch.float32 else 1, p(out), 0 if out_dtype == torch.float32 else 1,
+                                  p(emod), p(ehead), ck, cvt, ctypes.byref(self._cdw[0]), ctypes.byref(bufs.dws),
+                                  p(self._rope_dev[0]), p(self._rope_dev[1]), ctypes.byref(rp), B, F, Hh, Ww, Ll,
+                                  min(int(self.mask_source_frames), F // pt) * pt, ops._stream()), "wan_dit_forward")
+        return out
+
+    def _block_composite(self, blk: _Block, em, xs, bufs, ctx_kv, rp, B, Ll, L):
+        from ._lib import check, load
+        import ctypes
+        lib = load()
+        self._block_cw(blk)
+        self._block_cws(bufs, bufs, B, Ll, L)
         ck, cvt = ctx_kv
         check(lib.wan_dit_block_forward(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(em.data_ptr()),
                                         ctypes.c_void_p(ck.data_ptr()), ctypes.c_void_p(cvt.data_ptr()),
@@ -701,6 +748,16 @@ class WanTransformer3DModel(nn.Module):
             ctx = self._text_embed(context)
             ctx_kv = [None] * self.num_layers
 
+        r0 = 0          # rows whose output is needed after the last block start here (non-zero only with skip_source_frames)
+        if self.skip_source_frames and B == 1 and P == 1:
+            r0 = min(int(self.skip_source_frames), grid[0]) * grid[1] * grid[2]
+        if (P == 1 and self.use_block_composite and self.use_forward_composite and not self._fp8 and self.teacache is None
+                and self._probe_layer is None and self._attn_events is None and r0 == 0
+                and dtype in (torch.float32, torch.bfloat16)):
+            kvs = ctx_kv if ctx_kv[0] is not None else [self._context_kv(blk, ctx, B) for blk in self.blocks]
+            rp = self._rope_map(grid, frame_split_indices, ground_frame_indices, 0, Ll)
+            return self._forward_composite(x.contiguous(), emod, ehead, kvs, rp, self._workspaces(B, Ll, L, seq_len), B, Ll, L, dtype)
+
         # -- patch embedding into the fp32 residual stream (this rank's token rows only) --------
         xs = torch.zeros(M, C, device=dev, dtype=torch.float32)
         lo, hi = rank * Ll, min((rank + 1) * Ll, L)
@@ -716,10 +773,6 @@ class WanTransformer3DModel(nn.Module):
         bufs = self._workspaces(B, Ll, L, seq_len)
         h = bufs.h
 
-        # rows whose output is needed after the last block (all of them unless skip_source_frames is set)
-        r0 = 0
-        if self.skip_source_frames and B == 1 and P == 1:
-            r0 = min(int(self.skip_source_frames), grid[0]) * grid[1] * grid[2]
         # TeaCache (:956-1031): skip the blocks and re-apply the residual they produced the last time they ran
         run_blocks, ori_x = True, None
         if self.teacache is not None:
