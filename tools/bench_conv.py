@@ -25,7 +25,7 @@ SHAPES = [  # Cin, Cout, T, H, W, what
 
 def main():
     g = torch.Generator(device=DEV).manual_seed(0)
-    print("WAN_CONV_XCD =", os.environ.get("WAN_CONV_XCD", "1 (default)"))
+    print("tuning:", {k: ops.get_tuning(k) for k in ("conv_xcd", "conv_fast")})
     for cin, cout, T, H, W, what in SHAPES:
         co = max(cout, 8)
         K = 27 * cin
@@ -39,7 +39,7 @@ def main():
         f()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 5
+        n = 20
         for _ in range(n):
             f()
         torch.cuda.synchronize()

@@ -54,6 +54,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"conv_xcd", "WAN_CONV_XCD", 1},            // XCD slab rasterisation of wan_conv_cl
     {"attn_w4", "WAN_ATTN_W4", 1},              // max-free main launch on the 4-wave / 64-rows-per-wave kernel (0 = 8-wave)
     {"gemm_w4", "WAN_GEMM_W4", 2},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 when K % 128 == 0, 2 deep K only
+    {"conv_fast", "WAN_CONV_FAST", 1},          // wan_conv_cl gather addresses on the branch-free 24-bit multiply path (0 = general 64-bit path)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

@@ -41,12 +41,28 @@ struct ConvArgs {
     int ups, interleave, hist_frames, silu;
     int M, ntaps, nk, tiles_m, tiles_n;
     unsigned cin_magic;          // ceil(2^32 / Cin)
+    unsigned div_w_mul, div_w_sh, div_h_mul, div_h_sh;   // q = (a * mul) >> sh divides by KW / KH (171, 9 for 3; 1, 0 for 1)
     int xcd_slabs;               // 1: XCD-contiguous tile slabs (default), 0: plain order (A/B switch WAN_CONV_XCD=0)
 };
 
 __device__ __forceinline__ int div3(int a) { return (a * 171) >> 9; }   // exact for 0 <= a < 256
 
-template <int NT>
+// a * b + c on the full-rate 24-bit multiplier (a, b < 2^24; b wave-uniform); v_mul_lo_u32 / v_mad_u64_u32 are quarter rate
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b), "v"(a));
+    return r;
+}
+
+// FAST: the gather address of a chunk without a branch and without 64-bit / quarter-rate multiplies -- the host takes this
+// path when every pixel index fits 24 bits and every element offset 32 bits (true for every chunked VAE call up to 720p);
+// the general path measured 329 VALU instructions per K tile against 24 MFMAs (VALU-bound at 22 % of the matrix peak).
+template <int NT, bool FAST>
 __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(ConvArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 32 * NT;
@@ -90,6 +106,29 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
     const int cl[2] = {spc ^ ((srow >> 1) & 7), spc ^ ((4 + (srow >> 1)) & 7)};
     const int Hlim = g.H_in << g.ups, Wlim = g.W_in << g.ups;
     const int64_t frame_elems = (int64_t)g.H_in * g.W_in * g.Cin;
+    // FAST: frames are counted from the first history frame (tsel = ti + hist_frames >= 0 for every valid tap), addresses are
+    // xbase + 2 * element(tsel, hi, wi, ci) with the (wave-uniform) distance to the history buffer added for tsel < hist_frames
+    int hi0[4], wi0[4];
+    unsigned tb0[4];
+    uint64_t xbase = 0, hdelta = 0, zpage = 0;
+    if constexpr (FAST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi0[j] = (hw0[j] >> 16) - 4096;
+            wi0[j] = (hw0[j] & 0xffff) - 4096;
+            tb0[j] = (unsigned)(ti0[j] + g.hist_frames);
+        }
+        xbase = (uint64_t)g.x - (uint64_t)g.hist_frames * (uint64_t)frame_elems * 2;
+        hdelta = g.hist_frames ? (uint64_t)g.hist - xbase : 0;
+        zpage = (uint64_t)wan_zero_page;
+    }
+    // the three candidate bases as VGPR pairs, materialised once (as SGPR values the selects cost two v_mov each per chunk, and
+    // the zero page's address is re-read through the GOT every K tile)
+    unsigned xb_lo = (unsigned)xbase, xb_hi = (unsigned)(xbase >> 32);
+    unsigned hb_lo = (unsigned)(xbase + hdelta), hb_hi = (unsigned)((xbase + hdelta) >> 32);
+    unsigned zp_lo = (unsigned)zpage, zp_hi = (unsigned)(zpage >> 32);
+    if constexpr (FAST) asm volatile("" : "+v"(xb_lo), "+v"(xb_hi), "+v"(hb_lo), "+v"(hb_hi), "+v"(zp_lo), "+v"(zp_hi));
+    const unsigned Tlim = (unsigned)(g.T_in + g.hist_frames);
 
     const bf16_t* w_src[WP];
 #pragma unroll
@@ -101,40 +140,73 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
     }
 
     auto stage = [&](int buf, int kstep) {
-        char* base = smem + buf * kStage;
-        // decode (tap, ci) once per swizzle parity
-        int dt[2], dh[2], dw[2], ci[2];
-        bool tapok[2];
+        char* sbase = smem + buf * kStage;
+        if constexpr (FAST) {
+            unsigned dt[2], ci[2];
+            int dh[2], dw[2];
+            bool tapok[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned k = (unsigned)(kstep * BK + cl[p] * 8);
-            const int tap = (int)__umulhi(k, g.cin_magic);
-            ci[p] = (int)k - tap * g.Cin;
-            tapok[p] = tap < g.ntaps;
-            int rest = tap;
-            int kw = 0, kh = 0;
-            if (g.KW == 3) { const int q = div3(rest); kw = rest - 3 * q; rest = q; }
-            if (g.KH == 3) { const int q = div3(rest); kh = rest - 3 * q; rest = q; }
-            dt[p] = rest; dh[p] = kh; dw[p] = kw;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = j & 1;
-            const int ti = ti0[j] + dt[p];
-            const int hi = (hw0[j] >> 16) - 4096 + dh[p];
-            const int wi = (hw0[j] & 0xffff) - 4096 + dw[p];
-            const bool ok = tapok[p] && (unsigned)hi < (unsigned)Hlim && (unsigned)wi < (unsigned)Wlim &&
-                            ti < g.T_in && ti >= -g.hist_frames;
-            const bf16_t* src = reinterpret_cast<const bf16_t*>(wan_zero_page);
-            if (ok) {
-                const int64_t pix = ((int64_t)(hi >> g.ups) * g.W_in + (wi >> g.ups)) * g.Cin + ci[p];
-                src = ti >= 0 ? g.x + ti * frame_elems + pix : g.hist + (ti + g.hist_frames) * frame_elems + pix;
+            for (int p = 0; p < 2; ++p) {
+                const unsigned k = (unsigned)(kstep * BK + cl[p] * 8);
+                const unsigned tap = __umulhi(k, g.cin_magic);
+                ci[p] = k - mul24(tap, (unsigned)g.Cin);
+                tapok[p] = tap < (unsigned)g.ntaps;
+                const unsigned q1 = mul24(tap, g.div_w_mul) >> g.div_w_sh;
+                dw[p] = (int)(tap - mul24(q1, (unsigned)g.KW));
+                const unsigned q2 = mul24(q1, g.div_h_mul) >> g.div_h_sh;
+                dh[p] = (int)(q1 - mul24(q2, (unsigned)g.KH));
+                dt[p] = q2;
             }
-            glds16(src, base + (wid * 4 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = j & 1;
+                const unsigned tsel = tb0[j] + dt[p];
+                const int hi = hi0[j] + dh[p], wi = wi0[j] + dw[p];
+                const bool ok = tapok[p] & ((unsigned)hi < (unsigned)Hlim) & ((unsigned)wi < (unsigned)Wlim) & (tsel < Tlim);
+                const unsigned row = mad24(tsel, (unsigned)g.H_in, (unsigned)(hi >> g.ups));
+                const unsigned pix = mad24(row, (unsigned)g.W_in, (unsigned)(wi >> g.ups));
+                const unsigned el = mad24(pix, (unsigned)g.Cin, ci[p]);
+                const bool hist = tsel < (unsigned)g.hist_frames;
+                const uint64_t b = ((uint64_t)(hist ? hb_hi : xb_hi) << 32) | (hist ? hb_lo : xb_lo);
+                const uint64_t a = b + ((uint64_t)el << 1);
+                const uint64_t src = ((uint64_t)(ok ? (unsigned)(a >> 32) : zp_hi) << 32) | (ok ? (unsigned)a : zp_lo);
+                glds16(reinterpret_cast<const void*>(src), sbase + (wid * 4 + j) * 1024);
+            }
+        } else {
+            // decode (tap, ci) once per swizzle parity
+            int dt[2], dh[2], dw[2], ci[2];
+            bool tapok[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned k = (unsigned)(kstep * BK + cl[p] * 8);
+                const int tap = (int)__umulhi(k, g.cin_magic);
+                ci[p] = (int)k - tap * g.Cin;
+                tapok[p] = tap < g.ntaps;
+                int rest = tap;
+                int kw = 0, kh = 0;
+                if (g.KW == 3) { const int q = div3(rest); kw = rest - 3 * q; rest = q; }
+                if (g.KH == 3) { const int q = div3(rest); kh = rest - 3 * q; rest = q; }
+                dt[p] = rest; dh[p] = kh; dw[p] = kw;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = j & 1;
+                const int ti = ti0[j] + dt[p];
+                const int hi = (hw0[j] >> 16) - 4096 + dh[p];
+                const int wi = (hw0[j] & 0xffff) - 4096 + dw[p];
+                const bool ok = tapok[p] && (unsigned)hi < (unsigned)Hlim && (unsigned)wi < (unsigned)Wlim &&
+                                ti < g.T_in && ti >= -g.hist_frames;
+                const bf16_t* src = reinterpret_cast<const bf16_t*>(wan_zero_page);
+                if (ok) {
+                    const int64_t pix = ((int64_t)(hi >> g.ups) * g.W_in + (wi >> g.ups)) * g.Cin + ci[p];
+                    src = ti >= 0 ? g.x + ti * frame_elems + pix : g.hist + (ti + g.hist_frames) * frame_elems + pix;
+                }
+                glds16(src, sbase + (wid * 4 + j) * 1024);
+            }
         }
         const int koff = kstep * BK;
 #pragma unroll
-        for (int j = 0; j < WP; ++j) glds16(w_src[j] + koff, base + kATile + (wid * WP + j) * 1024);
+        for (int j = 0; j < WP; ++j) glds16(w_src[j] + koff, sbase + kATile + (wid * WP + j) * 1024);
     };
 
     // ---- fragment read offsets (identical to gemm_bf16.hip)
@@ -215,12 +287,12 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
     }
 }
 
-template <int NT>
-wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
+template <int NT, bool FAST>
+wan_status_t launch_conv_t(const ConvArgs& g, hipStream_t s) {
     constexpr int lds = 2 * (kATile + 32 * NT * BK * 2);
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cl_kernel<NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cl_kernel<NT, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             wan_set_error("wan_conv_cl: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
@@ -229,9 +301,17 @@ wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
         return WAN_OK;
     });
     if (st != WAN_OK) return st;
-    hipLaunchKernelGGL(conv_cl_kernel<NT>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), lds, s, g);
+    hipLaunchKernelGGL((conv_cl_kernel<NT, FAST>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), lds, s, g);
     WAN_CHECK_LAUNCH("wan_conv_cl");
     return WAN_OK;
+}
+
+template <int NT>
+wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
+    // FAST needs: pixel indices < 2^24 and element offsets < 2^32 (24-bit multiplies, 32-bit element index)
+    const int64_t px = (int64_t)(g.T_in + g.hist_frames) * g.H_in * g.W_in;       // frames counted from the first history frame
+    const bool fits = px < (1 << 24) && px * g.Cin < (1LL << 32) && g.Cin < (1 << 24) && g.H_in < (1 << 24) && g.W_in < (1 << 24);
+    return fits && wan_tune(WAN_TUNE_CONV_FAST) ? launch_conv_t<NT, true>(g, s) : launch_conv_t<NT, false>(g, s);
 }
 
 // ------------------------------------------------------------------ per-pixel RMS_norm (+SiLU)
@@ -362,6 +442,8 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
     g.ups = p->upsample2x ? 1 : 0; g.interleave = p->time_interleave ? 1 : 0; g.hist_frames = hist_frames; g.silu = 0;
     g.M = (int)M; g.ntaps = ntaps; g.nk = Kpad / BK;
     g.cin_magic = (unsigned)((0x100000000ULL + p->Cin - 1) / p->Cin);
+    g.div_w_mul = p->KW == 3 ? 171 : 1; g.div_w_sh = p->KW == 3 ? 9 : 0;
+    g.div_h_mul = p->KH == 3 ? 171 : 1; g.div_h_sh = p->KH == 3 ? 9 : 0;
     g.xcd_slabs = wan_tune(WAN_TUNE_CONV_XCD) != 0;      // developer A/B switch (wan_set_tuning)
     g.tiles_m = (g.M + BM - 1) / BM;
     hipStream_t s = (hipStream_t)stream;
