@@ -216,3 +216,40 @@ def test_full_resolution_resample_convs_vs_torch_fp32(vae, vae_sd):
     xp = torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1))
     ref = torch.nn.functional.conv2d(xp, w[:, :, 0], b, stride=2).permute(0, 2, 3, 1)
     assert out.shape[:3] == ref.shape[:3] and rel_l2_dev(out[..., :96].float(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,nh,resid", [
+    (32, 96, 1, 8, 32, 0, False),        # one exact tile, no history (zero causal padding)
+    (96, 96, 3, 13, 37, 1, True),        # ragged tiles along H and W, one history frame, fused residual add
+    (64, 192, 2, 21, 70, 2, False),      # two output-channel slices
+    (96, 384, 1, 9, 33, 2, True),
+])
+def test_lds_patch_conv_vs_torch_and_vs_gather_kernel(cin, cout, T, H, W, nh, resid):
+    """The LDS-patch kernel of the causal 3x3x3 / stride-1 convolution (conv3_patch_kernel), forced on shapes smaller than
+    its dispatch threshold: against torch's fp32 conv3d on the same bf16 inputs (<= 4e-3, bf16 output rounding) and against the
+    implicit-GEMM gather kernel (same arithmetic, another summation order)."""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + H)
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).bfloat16()
+    hist = torch.randn(nh, H, W, cin, device=DEV, generator=g).bfloat16() if nh else None
+    K = 27 * cin
+    wt = (torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) * (1.0 / K ** 0.5)).bfloat16()
+    w = torch.zeros(cout, ops.round_up(K, 64), device=DEV, dtype=torch.bfloat16)
+    w[:, :K] = wt.permute(0, 2, 3, 4, 1).reshape(cout, K)
+    b = torch.randn(cout, device=DEV, generator=g)
+    r = torch.randn(T, H, W, cout, device=DEV, generator=g).bfloat16() if resid else None
+    run = lambda: ops.conv_cl(x, w, b, cout, (3, 3, 3), pad=(2, 1, 1), out_thw=(T, H, W), hist=hist, resid=r)
+    old = ops.get_tuning("conv_patch")
+    try:
+        ops.set_tuning("conv_patch", 2)
+        got = run()
+        ops.set_tuning("conv_patch", 0)
+        gather = run()
+    finally:
+        ops.set_tuning("conv_patch", old)
+    frames = torch.cat([torch.zeros(2 - nh, H, W, cin, device=DEV, dtype=torch.bfloat16)] + ([hist] if nh else []) + [x])
+    ref = torch.nn.functional.conv3d(frames.float().permute(3, 0, 1, 2)[None], wt.float(), b, padding=(0, 1, 1))[0].permute(1, 2, 3, 0)
+    if resid:
+        ref = ref + r.float()
+    assert got.shape == ref.shape
+    assert rel_l2_dev(got.float(), ref) < 4e-3 and rel_l2_dev(gather.float(), ref) < 4e-3
+    assert rel_l2_dev(got.float(), gather.float()) < 3e-3

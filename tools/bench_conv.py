@@ -25,7 +25,7 @@ SHAPES = [  # Cin, Cout, T, H, W, what
 
 def main():
     g = torch.Generator(device=DEV).manual_seed(0)
-    print("tuning:", {k: ops.get_tuning(k) for k in ("conv_xcd", "conv_fast")})
+    print("tuning:", {k: ops.get_tuning(k) for k in ("conv_xcd", "conv_fast", "conv_patch")})
     for cin, cout, T, H, W, what in SHAPES:
         co = max(cout, 8)
         K = 27 * cin

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -43,6 +44,7 @@ struct ConvArgs {
     unsigned cin_magic;          // ceil(2^32 / Cin)
     unsigned div_w_mul, div_w_sh, div_h_mul, div_h_sh;   // q = (a * mul) >> sh divides by KW / KH (171, 9 for 3; 1, 0 for 1)
     int xcd_slabs;               // 1: XCD-contiguous tile slabs (default), 0: plain order (A/B switch WAN_CONV_XCD=0)
+    int pth, ptw;                // conv3_patch_kernel: tiles along H / W
 };
 
 __device__ __forceinline__ int div3(int a) { return (a * 171) >> 9; }   // exact for 0 <= a < 256
@@ -314,6 +316,242 @@ wan_status_t launch_conv(const ConvArgs& g, hipStream_t s) {
     return fits && wan_tune(WAN_TUNE_CONV_FAST) ? launch_conv_t<NT, true>(g, s) : launch_conv_t<NT, false>(g, s);
 }
 
+// ------------------------------------------------------------------ causal 3x3x3, stride 1: the input patch lives in LDS
+// The residual blocks' CausalConv3d(3x3x3, stride 1, padding (2,1,1)) carry ~all of the VAE's FLOPs.  As an implicit GEMM
+// every 16-byte chunk of the A tile is gathered separately -- 27 times per input element, each with its own address and
+// bounds arithmetic (conv_cl_kernel: ~100 VALU instructions per 24 MFMAs at Cout = 96).  Here a workgroup owns 8 x 32 output
+// pixels of one frame and loads their (3 frames) x 10 x 34 input patch for 32 channels ONCE into LDS (64 KiB, zero-filled
+// outside the image / before the sequence start, history frames from `hist`); the 27 taps are then 27 shifted views of the same
+// patch, read by ds_read_b128 at (pixel + tap shift) -- no global address arithmetic in the K loop at all.
+//   K loop: for each 32-channel chunk (patch double-buffered, the next chunk's patch streams in one 1-KiB piece per step under this
+//   chunk's first 16 taps), for each tap: one 96 x 32 weight slice through a 5-deep LDS ring (issued 4 steps ahead, counted vmcnt,
+//   published one step before its use), the NEXT step's 4 A + 6 W fragments read into a second register set between this step's
+//   first MFMAs, 12 x v_mfma_f32_32x32x16_bf16 per wave (wave tile 64 pixels x 96 channels = 2 rows x 32 columns; one wave per SIMD,
+//   so the 32-cycle MFMA is the one whose issue gaps hold the step's ~50 other instructions), one barrier.
+//   LDS: pixel-major, 64 B per pixel (weights: per output channel); the 16-byte chunk position is XOR-swizzled by bits 2..3 of the
+//   pixel index -- conflict-free for ds_read_b128's lane groups at every tap alignment (the four pixels of a lane group that share
+//   pixel & 3 sit 12 / 20 / 24 pixels apart: (pixel >> 2) & 3 takes four different values).
+constexpr int PT_H = 8, PT_W = 32, PP_H = PT_H + 2, PP_W = PT_W + 2, PP_FR = PP_H * PP_W, PP_PX = 3 * PP_FR;   // 1020 patch pixels
+constexpr int kPatchBytes = 1024 * 64;
+constexpr int kWSlice = 96 * 64, kWRing = 5;
+constexpr int kPatchLds = 2 * kPatchBytes + kWRing * kWSlice + 2048;       // all 163 840 B (2 KiB: the dummy DMA target)
+
+__global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wring = smem + 2 * kPatchBytes;
+    int t = blockIdx.x;
+    if (g.xcd_slabs) {
+        const int nwg = gridDim.x;
+        const int xcd = t & 7, loc = t >> 3, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int sl = t % g.tiles_n; t /= g.tiles_n;
+    const int twi = t % g.ptw; t /= g.ptw;
+    const int thi = t % g.pth;
+    const int t0 = t / g.pth;
+    const int h0 = thi * PT_H, w0 = twi * PT_W, n0 = sl * 96;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = g.hist_frames;
+
+    // ---- patch staging: DMA instruction i of this wave fills patch pixels (wid*16 + i)*16 .. +15, lane -> (pixel, chunk slot)
+    unsigned pel[16];
+    unsigned pvalid = 0, phist = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int px = (wid * 16 + i) * 16 + (lane >> 2);
+        const int f = px / PP_FR, rem = px - f * PP_FR;
+        const int r = rem / PP_W, c = rem - r * PP_W;
+        const int kgl = (lane & 3) ^ ((px >> 2) & 3);
+        const int tsel = t0 - 2 + f + hf, hi = h0 - 1 + r, wi = w0 - 1 + c;          // frames counted from the first history frame
+        const bool ok = px < PP_PX && (unsigned)hi < (unsigned)g.H_in && (unsigned)wi < (unsigned)g.W_in && tsel >= 0;
+        pel[i] = mad24(mad24(mad24((unsigned)tsel, (unsigned)g.H_in, (unsigned)hi), (unsigned)g.W_in, (unsigned)wi), (unsigned)g.Cin,
+                       (unsigned)(kgl * 8));
+        pvalid |= (unsigned)ok << i;
+        phist |= (unsigned)(tsel < hf) << i;
+    }
+    const uint64_t frame_bytes = (uint64_t)g.H_in * g.W_in * g.Cin * 2;
+    const uint64_t xbase = (uint64_t)g.x - (uint64_t)hf * frame_bytes;
+    const uint64_t hbase = hf ? (uint64_t)g.hist : xbase;
+    const uint64_t zpage = (uint64_t)wan_zero_page;
+    auto issue_patch_piece = [&](int chunk, int buf, int i) {
+        const uint64_t b = (phist >> i) & 1 ? hbase : xbase;
+        const uint64_t a = b + ((uint64_t)(pel[i] + (unsigned)chunk * 32u) << 1);
+        glds16(reinterpret_cast<const void*>((pvalid >> i) & 1 ? a : zpage), smem + buf * kPatchBytes + (wid * 16 + i) * 1024);
+    };
+
+    // ---- weight slices: six 16-row DMA pieces per 96-row slice; wave w stages piece w, waves 0 / 1 also pieces 4 / 5, waves 2 / 3
+    // a dummy piece into 1 KiB of spare LDS instead (every wave issues exactly two DMA instructions per step -- the counted
+    // vmcnt below relies on it -- and no exec-masked branch splits the step's basic block)
+    const int nrowA = 16 * wid + (lane >> 2), nrowB = 64 + 16 * (wid & 1) + (lane >> 2);
+    const bf16_t* wA = g.w + (int64_t)min(n0 + nrowA, g.Cout - 1) * g.ldw + (((lane & 3) ^ ((nrowA >> 2) & 3)) << 3);
+    const bf16_t* wB = g.w + (int64_t)min(n0 + nrowB, g.Cout - 1) * g.ldw + (((lane & 3) ^ ((nrowB >> 2) & 3)) << 3);
+    char* const wspare = wring + kWRing * kWSlice + (wid & 1) * 1024;
+    auto issue_w = [&](int chunk, int tap, int slot) {
+        const int koff = tap * g.Cin + chunk * 32;
+        char* dst = wring + slot * kWSlice;
+        glds16(wA + koff, dst + wid * 1024);
+        glds16(wB + koff, wid < 2 ? dst + (4 + wid) * 1024 : wspare);
+    };
+
+    // ---- fragment addresses (32x32x16: lane -> row lane & 31 of the tile, 8 channels at 16 * kstep + 8 * (lane >> 5))
+    const int m32 = lane & 31, hi1 = lane >> 5;
+    int pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pb[i] = (2 * wid + i) * PP_W + m32;
+    const int woff0 = (m32 << 6) | (((hi1 ^ (m32 >> 2)) & 3) << 4);          // k-step 0; k-step 1 is this ^ 32; n-tile j adds j * 2048
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nch = g.Cin >> 5;
+    bf16x8 af[2][2][2], wf[2][3][2];          // [set][tile][k-step]
+    auto a_addr = [&](int i, int shift) {
+        const int px = pb[i] + shift;
+        return (px << 6) | (((hi1 ^ (px >> 2)) & 3) << 4);
+    };
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) issue_patch_piece(0, 0, i);
+        issue_w(0, 0, 0);
+        issue_w(0, 1, 1);
+        issue_w(0, 2, 2);
+        issue_w(0, 3, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int a0 = a_addr(i, 0);
+            af[0][i][0] = *reinterpret_cast<const bf16x8*>(smem + a0);
+            af[0][i][1] = *reinterpret_cast<const bf16x8*>(smem + (a0 ^ 32));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            wf[0][j][0] = *reinterpret_cast<const bf16x8*>(wring + woff0 + j * 2048);
+            wf[0][j][1] = *reinterpret_cast<const bf16x8*>(wring + (woff0 ^ 32) + j * 2048);
+        }
+    }
+    int slot_use = 0;          // ring slot of the current step's slice; the slice issued now goes 4 slots further
+    auto run_chunk = [&](int c, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
+        const char* pbuf = smem + (c & 1) * kPatchBytes;
+        const char* pother = smem + ((c + 1) & 1) * kPatchBytes;
+#pragma unroll
+        for (int s = 0; s < 27; ++s) {
+            const int slot_next = slot_use == kWRing - 1 ? 0 : slot_use + 1;
+            // this step's 12 MFMAs run on the fragment set loaded one step ago; the NEXT step's fragments (its slice was published
+            // by the previous barrier, the patch is stable) are read between the first ten of them, one read per MFMA, so their LDS
+            // latency hides under the rest.  The order is pinned (sched_barrier): left to itself the scheduler sinks the reads to
+            // the end of the step, where the barrier waits their latency out.
+            {
+                const int cur = s & 1, nxt = cur ^ 1;
+                const char* pnext = s == 26 ? pother : pbuf;
+                const int tnext = s == 26 ? 0 : s + 1;
+                const int shift = (tnext / 9) * PP_FR + ((tnext / 3) % 3) * PP_W + (tnext % 3);
+                const char* wb = wring + slot_next * kWSlice;
+                const int an[2] = {a_addr(0, shift), a_addr(1, shift)};
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const int ks = k / 6, i = (k % 6) / 3, j = k % 3;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][j][ks], af[cur][i][ks], acc[i][j], 0, 0, 0);
+                    if (k < 10) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k < 4) af[nxt][k >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(pnext + (an[k >> 1] ^ ((k & 1) << 5)));
+                        else wf[nxt][(k - 4) >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(wb + ((woff0 ^ ((k & 1) << 5)) + ((k - 4) >> 1) * 2048));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            {   // weight slice of step + 4 (past the end: the last slice again, into a slot nobody reads any more)
+                int s4 = s + 4, c4 = c;
+                if (s4 >= 27) { s4 -= 27; c4 += 1; }
+                if (!more && c4 != c) { c4 = c; s4 = 26; }
+                issue_w(c4, s4, slot_use == 0 ? kWRing - 1 : slot_use - 1);
+            }
+            if (s < 16 && more) issue_patch_piece(c + 1, (c + 1) & 1, s);      // the next patch, one of its 16 pieces per step
+            // the slice of step + 2 must have landed before the barrier publishes it.  vmcnt retires in order: behind that slice
+            // in the queue are the slices of steps + 3 and + 4 (2 DMA instructions each) and the patch pieces issued in this
+            // step and the two before it (steps 0..15 of a chunk with a successor issue one each)
+            // (a bare s_barrier: __syncthreads() carries a fence that waits for vmcnt(0) and would serialise the ring)
+            __builtin_amdgcn_sched_barrier(0);          // all MFMAs of the step are issued before it waits
+            {
+                constexpr auto pieces = [](int a) { return a >= 0 && a < 16 ? 1 : 0; };
+                const int np = more ? pieces(s - 2) + pieces(s - 1) + pieces(s) : 0;
+                if (np == 3) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                else if (np == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else if (np == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);          // nothing of this step sinks below its barrier, nothing of the next rises
+            slot_use = slot_next;
+        }
+        // 27 steps per chunk: the set prefetched by the last step is set 1, the next chunk starts on set 0
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { af[0][i][0] = af[1][i][0]; af[0][i][1] = af[1][i][1]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { wf[0][j][0] = wf[1][j][0]; wf[0][j][1] = wf[1][j][1]; }
+    };
+    for (int c = 0; c + 1 < nch; ++c) run_chunk(c, std::true_type{});
+    run_chunk(nch - 1, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy tail slices still write LDS
+
+    // ---- epilogue: lane holds pixel m32 of row i, channels n0 + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int h = h0 + 2 * wid + i, w_ = w0 + m32;
+        if (h >= g.H_out || w_ >= g.W_out) continue;
+        const int64_t orow = ((int64_t)t0 * g.H_out + h) * g.W_out + w_;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + j * 32 + q * 8 + hi1 * 4;
+                if (n >= g.Cout) continue;
+                float v0 = acc[i][j][q * 4], v1 = acc[i][j][q * 4 + 1], v2 = acc[i][j][q * 4 + 2], v3 = acc[i][j][q * 4 + 3];
+                if (g.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
+                    v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+                }
+                if (g.resid) {
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(g.resid + orow * g.ldo + n);
+                    v0 += bf16lo_to_f32(rv[0]); v1 += bf16hi_to_f32(rv[0]);
+                    v2 += bf16lo_to_f32(rv[1]); v3 += bf16hi_to_f32(rv[1]);
+                }
+                u32x2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                *reinterpret_cast<u32x2*>(g.out + orow * g.ldo + n) = o;
+            }
+    }
+}
+
+wan_status_t launch_conv3_patch(ConvArgs g, hipStream_t s) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds);
+        if (e != hipSuccess) {
+            wan_set_error("wan_conv_cl: cannot reserve %d B of LDS: %s", kPatchLds, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
+    g.pth = (g.H_out + PT_H - 1) / PT_H;
+    g.ptw = (g.W_out + PT_W - 1) / PT_W;
+    g.tiles_n = (g.Cout + 95) / 96;
+    const int64_t nwg = (int64_t)g.T_out * g.pth * g.ptw * g.tiles_n;
+    hipLaunchKernelGGL(conv3_patch_kernel, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
+    WAN_CHECK_LAUNCH("wan_conv_cl");
+    return WAN_OK;
+}
+
 // ------------------------------------------------------------------ per-pixel RMS_norm (+SiLU)
 // F.normalize(x, dim=channel) * sqrt(C) * gamma  (wan_vae.py:43-58), optional SiLU.  A pixel's C channels are
 // C/8 16-byte chunks; LPP = 8/16/32/64 lanes share a pixel (the next power of two >= C/8), so a wave normalises
@@ -447,6 +685,18 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
     g.xcd_slabs = wan_tune(WAN_TUNE_CONV_XCD) != 0;      // developer A/B switch (wan_set_tuning)
     g.tiles_m = (g.M + BM - 1) / BM;
     hipStream_t s = (hipStream_t)stream;
+    {   // causal 3x3x3 / stride 1 with whole 96-channel output slices: the LDS-patch kernel
+        const int64_t px = (int64_t)(p->T_in + hist_frames) * p->H_in * p->W_in;
+        const int mode = wan_tune(WAN_TUNE_CONV_PATCH);
+        const bool shape_ok = ntaps == 27 && p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 2 && p->ph == 1 && p->pw == 1 &&
+                              !p->upsample2x && !p->time_interleave && p->Cin % 32 == 0 && p->Cout % 96 == 0 &&
+                              p->T_out == p->T_in && p->H_out == p->H_in && p->W_out == p->W_in &&
+                              px < (1 << 24) && px * p->Cin < (1LL << 32);
+        if (mode && shape_ok) {
+            const int64_t nwg = (int64_t)p->T_out * ((p->H_out + PT_H - 1) / PT_H) * ((p->W_out + PT_W - 1) / PT_W) * (p->Cout / 96);
+            if (mode == 2 || nwg >= 256) return launch_conv3_patch(g, s);       // fewer workgroups than CUs: the 128-pixel tiles fill more of them
+        }
+    }
     if (p->Cout <= 32) { g.tiles_n = 1; return launch_conv<1>(g, s); }      // decoder head (3), latent convs (16 / 32)
     if (p->Cout <= 96) { g.tiles_n = (p->Cout + 95) / 96; return launch_conv<3>(g, s); }
     if (p->Cout % 192 == 0) { g.tiles_n = p->Cout / 192; return launch_conv<6>(g, s); }
