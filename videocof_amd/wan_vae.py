@@ -157,7 +157,9 @@ class AutoencoderKLWan(nn.Module):
     def _push_hist(self, name: str, x: torch.Tensor, keep: int = 2):
         old = self._hist.get(name)
         if x.shape[0] >= keep:
-            self._hist[name] = x[-keep:].clone()
+            # a VIEW of the chunk's last frames, not a copy: every op of this module writes a fresh output tensor, so the
+            # chunk is never modified after the conv that read it; the view keeps it alive until the next chunk replaces it
+            self._hist[name] = x[-keep:]
         else:
             if old is None:
                 old = torch.zeros(keep, *x.shape[1:], device=x.device, dtype=x.dtype)
@@ -224,13 +226,13 @@ class AutoencoderKLWan(nn.Module):
             name = p + ".time_conv"
             if not self._seen.get(p):
                 self._seen[p] = True                                       # seed, no conv (:150-152)
-                self._hist[name] = x[-1:].clone()
+                self._hist[name] = x[-1:]
             else:
                 tc = self._c[name]
                 T2 = x.shape[0]
                 y = ops.conv_cl(x, tc.w, tc.b, tc.cout, tc.k, out_thw=((T2 + 1 - 3) // 2 + 1, x.shape[1], x.shape[2]),
                                 stride=(2, 1, 1), pad=(1, 0, 0), hist=self._hist[name])
-                self._hist[name] = x[-1:].clone()
+                self._hist[name] = x[-1:]
                 x = y
         return x
 
