@@ -555,7 +555,7 @@ def test_gemm_256_tile_kernels_all_epilogues(M, N, K, w4):
     acc = a.double() @ w.double().t() + bias.double()
     ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
     ops.set_tuning("gemm_variant", 2)
-    ops.set_tuning("gemm_w4", w4)
+    ops.set_tuning("gemm_w4", 3 if w4 else 0)          # 3 = the 4-wave kernel whenever K % 128 == 0 (the default takes it from K = 4096)
     try:
         o_bf = ops.gemm(ad, wd, bd, ops.EPI_BF16)
         o_ge = ops.gemm(ad, wd, bd, ops.EPI_GELU_BF16)
@@ -566,7 +566,7 @@ def test_gemm_256_tile_kernels_all_epilogues(M, N, K, w4):
         o_t = ops.gemm(ad, wd, bd, ops.EPI_BF16_T)
     finally:
         ops.set_tuning("gemm_variant", 0)
-        ops.set_tuning("gemm_w4", 2)
+        ops.set_tuning("gemm_w4", 1)
     assert rel_l2(o_bf, acc) < 4e-3 and rel_l2(o_f32, acc) < 1e-5
     x = acc.float().double()
     assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3

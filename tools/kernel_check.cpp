@@ -174,7 +174,7 @@ static void check_rmsnorm_rope() {
 static void check_gemm() {
   for (const char* var : {"1", "2", "2w"}) {       // 1 = 128^2, 2 = 256^2 8-wave phased, 2w = 256^2 4-wave (K % 128 == 0 shapes)
     WAN(wan_set_tuning("gemm_variant", var[0] == '1' ? 1 : 2));
-    WAN(wan_set_tuning("gemm_w4", strlen(var) > 1 ? 1 : 0));
+    WAN(wan_set_tuning("gemm_w4", strlen(var) > 1 ? 3 : 0));
     printf("wan_gemm_bf16 variant %s\n", var);
     struct Shape { int M, N, K; };
     for (Shape sh : {Shape{300, 384, 256}, Shape{128, 128, 64}, Shape{515, 64, 1024}, Shape{77, 1536, 192}, Shape{1100, 520, 448}, Shape{1100, 520, 512}}) {
@@ -372,12 +372,12 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         for (int round = 0; round < 2; ++round)
         for (const char* var : {"1", "2", "2w"}) {           // 1 = 128^2 kernel, 2 = 256^2 8-wave phased, 2w = 256^2 4-wave
             WAN(wan_set_tuning("gemm_variant", var[0] == '1' ? 1 : 2));
-            WAN(wan_set_tuning("gemm_w4", strlen(var) > 1 ? 1 : 0));
+            WAN(wan_set_tuning("gemm_w4", strlen(var) > 1 ? 3 : 0));
             double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
                                                         g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
             printf("  gemm[v%s] %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", var, g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
         }
-        WAN(wan_set_tuning("gemm_variant", 0)); WAN(wan_set_tuning("gemm_w4", 2));
+        WAN(wan_set_tuning("gemm_variant", 0)); WAN(wan_set_tuning("gemm_w4", 1));
     }
     struct A_ { int Lq, Lk, H; const char* what; };
     if (gemm_only) return;

@@ -53,7 +53,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"gemm_variant", "WAN_GEMM_VARIANT", 0},    // 1 = force the 128^2 GEMM, 2 = force the 256^2 GEMM, 0 = by shape
     {"conv_xcd", "WAN_CONV_XCD", 1},            // XCD slab rasterisation of wan_conv_cl
     {"attn_w4", "WAN_ATTN_W4", 1},              // max-free main launch on the 4-wave / 64-rows-per-wave kernel (0 = 8-wave)
-    {"gemm_w4", "WAN_GEMM_W4", 2},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 when K % 128 == 0, 2 deep K only
+    {"gemm_w4", "WAN_GEMM_W4", 1},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 K >= 4096, 2 K >= 8192, 3 whenever K % 128 == 0
     {"conv_fast", "WAN_CONV_FAST", 1},          // wan_conv_cl gather addresses on the branch-free 24-bit multiply path (0 = general 64-bit path)
     {"conv_patch", "WAN_CONV_PATCH", 1},        // causal 3x3x3 stride-1 convs with Cout % 96 == 0 on the LDS-patch kernel (0 = the gather kernel)
 };

@@ -301,46 +301,70 @@ __global__ __launch_bounds__(kThreads, 2) void gemm256_kernel(GemmArgs g) {
     // ---- epilogue (same register -> element maps as gemm_bf16.hip)
     const int l15 = lane & 15, l4 = (lane >> 4) * 4;
     if constexpr (!kTransposed) {
+        // Per output column group j the bias (and fp8 weight scale) is loaded ONCE; the fp32 read-modify-write epilogue reads
+        // its 8 float4 of the residual stream (and the gate rows) for two row groups back to back and waits once -- written
+        // element by element the compiler emitted load / wait / store 32 times in sequence (32 memory round trips per tile).
+        // Out-of-range rows / columns read a clamped (valid) address and are not stored.
+        int nn[4];
+        bool nok[4];
+        float4 bj[4], snj[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + l15;
-            if (m >= g.M) continue;
-            const int64_t b = g.gate ? (int64_t)m / g.rows_per_batch : 0;
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + l4;
+            nok[j] = n < g.N;
+            nn[j] = nok[j] ? n : 0;
+            bj[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nn[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (FP8) snj[j] = *reinterpret_cast<const float4*>(g.sw + nn[j]);
+        }
+        const int rpb = g.gate ? (int)g.rows_per_batch : 1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wc * 64 + j * 16 + l4;
-                if (n >= g.N) continue;
-                f32x4 v = acc[i][j];
-                if constexpr (FP8) {
-                    const float sm = g.sa[m];
-                    const float4 sn = *reinterpret_cast<const float4*>(g.sw + n);
-                    v[0] *= sm * sn.x; v[1] *= sm * sn.y; v[2] *= sm * sn.z; v[3] *= sm * sn.w;
-                }
-                if (g.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if constexpr (EPI == WAN_EPI_GELU_BF16) {
+        for (int ig = 0; ig < 8; ig += 2) {
+            int mm[2];
+            bool mok[2];
+            float sm[2];
+            float4 xr[2][4], gv[2][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
-                }
-                if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
-                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)m * g.ldo + n) = o;
-                } else if constexpr (EPI == WAN_EPI_F32) {
-                    *reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    float4* p = reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n);
-                    float4 x = *p;
-                    if (g.gate) {
-                        const float4 gv = *reinterpret_cast<const float4*>(g.gate + b * g.N + n);
-                        x.x += v[0] * gv.x; x.y += v[1] * gv.y; x.z += v[2] * gv.z; x.w += v[3] * gv.w;
-                    } else {
-                        x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+            for (int ii = 0; ii < 2; ++ii) {
+                const int m = m0 + wr * 128 + (ig + ii) * 16 + l15;
+                mok[ii] = m < g.M;
+                mm[ii] = mok[ii] ? m : g.M - 1;
+                if constexpr (FP8) sm[ii] = g.sa[mm[ii]];
+                if constexpr (EPI == WAN_EPI_RESID_F32) {
+                    const int64_t brow = g.gate ? (int64_t)(mm[ii] / rpb) * g.N : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        xr[ii][j] = *reinterpret_cast<const float4*>((const float*)g.out + (int64_t)mm[ii] * g.ldo + nn[j]);
+                        gv[ii][j] = g.gate ? *reinterpret_cast<const float4*>(g.gate + brow + nn[j]) : make_float4(1.f, 1.f, 1.f, 1.f);
                     }
-                    *p = x;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);          // all loads of the batch are issued before the first use waits
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[ig + ii][j];
+                    if constexpr (FP8) {
+                        v[0] *= sm[ii] * snj[j].x; v[1] *= sm[ii] * snj[j].y; v[2] *= sm[ii] * snj[j].z; v[3] *= sm[ii] * snj[j].w;
+                    }
+                    v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w;
+                    if constexpr (EPI == WAN_EPI_GELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
+                    }
+                    if (!(mok[ii] && nok[j])) continue;
+                    const int64_t off = (int64_t)mm[ii] * g.ldo + nn[j];
+                    if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
+                        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2*>((bf16_t*)g.out + off) = o;
+                    } else if constexpr (EPI == WAN_EPI_F32) {
+                        *reinterpret_cast<float4*>((float*)g.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        const float4 x = xr[ii][j], gq = gv[ii][j];
+                        *reinterpret_cast<float4*>((float*)g.out + off) =
+                            make_float4(x.x + v[0] * gq.x, x.y + v[1] * gq.y, x.z + v[2] * gq.z, x.w + v[3] * gq.w);
+                    }
+                }
         }
     } else {
 #pragma unroll
@@ -534,43 +558,79 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     // ---- epilogue.  Swapped product (W fragment as A operand): lane (l31, hi) holds output row m = .. + l31 and, per
     // accumulator register quad q, the 4 consecutive columns n = .. + 8 q + 4 hi .. + 3.  Transposed store: roles exchanged.
     if constexpr (!kTransposed) {
+        // Batches of 4 (the four register quads of one 32 x 32 tile): bias, residual stream and gate rows of a
+        // batch are loaded back to back, one batch ahead of their use (element by element the compiler serialised 64 round trips per
+        // tile -- and with one workgroup per CU nothing else runs meanwhile).  Out-of-range rows / columns read a clamped
+        // address and are not stored.
+        // (the two wave-uniform options -- bias? gate? -- select one of four straight-line copies: tested per element they put a
+        // scalar branch and a conservative vmcnt wait between the loads of a batch)
+        auto epilogue_rows = [&](auto has_bias, auto has_gate) {
+            constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_GATE = decltype(has_gate)::value;
+            const int rpb = HAS_GATE ? (int)g.rows_per_batch : 1;
+            struct Batch {
+                float4 bq[4], xr[4], gq[4];
+                int nn[4], mm;
+                bool nok[4], mok;
+            };
+            auto load_batch = [&](int bi, Batch& B) {          // batch bi = 32-row group bi >> 2, 32-column tile bi & 3
+                const int m = m0 + wr * 128 + (bi >> 2) * 32 + l31;
+                B.mok = m < g.M;
+                B.mm = B.mok ? m : g.M - 1;
+                const int64_t brow = HAS_GATE ? (int64_t)(B.mm / rpb) * g.N : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 128 + i * 32 + l31;
-            if (m >= g.M) continue;
-            const int64_t b = g.gate ? (int64_t)m / g.rows_per_batch : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int t = 0; t < 4; ++t) {
+                    const int n = n0 + wc * 128 + (bi & 3) * 32 + 8 * t + 4 * hi;
+                    B.nok[t] = n < g.N;
+                    B.nn[t] = B.nok[t] ? n : 0;
+                    if constexpr (HAS_BIAS) B.bq[t] = *reinterpret_cast<const float4*>(g.bias + B.nn[t]);
+                    else B.bq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (EPI == WAN_EPI_RESID_F32) {
+                        B.xr[t] = *reinterpret_cast<const float4*>((const float*)g.out + (int64_t)B.mm * g.ldo + B.nn[t]);
+                        if constexpr (HAS_GATE) B.gq[t] = *reinterpret_cast<const float4*>(g.gate + brow + B.nn[t]);
+                        else B.gq[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    }
+                }
+            };
+            auto store_batch = [&](int bi, const Batch& B) {
+                const int i = bi >> 2, j = bi & 3;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wc * 128 + j * 32 + 8 * q + 4 * hi;
-                    if (n >= g.N) continue;
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    if (g.bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
-                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                    }
+                    f32x4 v = {acc[i][j][4 * q] + B.bq[q].x, acc[i][j][4 * q + 1] + B.bq[q].y, acc[i][j][4 * q + 2] + B.bq[q].z,
+                               acc[i][j][4 * q + 3] + B.bq[q].w};
                     if constexpr (EPI == WAN_EPI_GELU_BF16) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
                     }
+                    if (!(B.mok && B.nok[q])) continue;
+                    const int64_t off = (int64_t)B.mm * g.ldo + B.nn[q];
                     if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
                         u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)m * g.ldo + n) = o;
+                        *reinterpret_cast<u32x2*>((bf16_t*)g.out + off) = o;
                     } else if constexpr (EPI == WAN_EPI_F32) {
-                        *reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>((float*)g.out + off) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
-                        float4* p = reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n);
-                        float4 x = *p;
-                        if (g.gate) {
-                            const float4 gv = *reinterpret_cast<const float4*>(g.gate + b * g.N + n);
-                            x.x += v[0] * gv.x; x.y += v[1] * gv.y; x.z += v[2] * gv.z; x.w += v[3] * gv.w;
-                        } else {
-                            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
-                        }
-                        *p = x;
+                        *reinterpret_cast<float4*>((float*)g.out + off) =
+                            make_float4(B.xr[q].x + v[0] * B.gq[q].x, B.xr[q].y + v[1] * B.gq[q].y, B.xr[q].z + v[2] * B.gq[q].z,
+                                        B.xr[q].w + v[3] * B.gq[q].w);
                     }
                 }
+            };
+            // two batches in flight: the loads of batch b + 1 are issued before batch b is combined and stored
+            Batch B[2];
+            load_batch(0, B[0]);
+#pragma unroll
+            for (int bi = 0; bi < 16; ++bi) {
+                if (bi + 1 < 16) load_batch(bi + 1, B[(bi + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                store_batch(bi, B[bi & 1]);
+            }
+        };
+        if (g.bias) {
+            if (g.gate) epilogue_rows(std::true_type{}, std::true_type{});
+            else epilogue_rows(std::true_type{}, std::false_type{});
+        } else {
+            if (g.gate) epilogue_rows(std::false_type{}, std::true_type{});
+            else epilogue_rows(std::false_type{}, std::false_type{});
         }
     } else {
 #pragma unroll
@@ -701,11 +761,12 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     g.gm = g.tiles_n >= 40 ? 2 : 3;
     if (const int gm = wan_tune(WAN_TUNE_GEMM_GM); gm > 0) g.gm = gm;       // developer A/B switches (wan_set_tuning)
     const int phases = wan_tune(WAN_TUNE_GEMM_PHASES) > 0 ? wan_tune(WAN_TUNE_GEMM_PHASES) : kDefaultPhases;
-    // gemm_w4: 0 never, 1 whenever the shape allows (K % 128 == 0), 2 (default) where it measured faster: deep K (ffn.2,
-    // K = 13 824: 1.20 vs 1.16 PFLOP/s; 8-way shard 1.05 vs 0.99).  At K = 5120 the two kernels tie (1.25-1.30) and at
-    // K = 1536 the 4-wave one loses 10-15 %: profiles/r02/gemm_w4_ab.log.
+    // gemm_w4: 0 never, 1 (default) for K % 128 == 0 and K >= 4096, 2 deep K only (K >= 8192), 3 whenever K % 128 == 0.  With the
+    // batched epilogues the 4-wave kernel is ahead on every 14B shape in process (o/q 2.675 vs 2.686 ms, q|k 5.43 vs 5.46, ffn.0
+    // 7.33 vs 7.68, ffn.2 7.72 vs 7.98; 8-way shards +3..7 %) and by 0.45 % of a whole step in situ
+    // (profiles/r02/gemm_epilogue_ab.txt); at K = 1536 it loses 10-15 % (profiles/r02/gemm_w4_ab.log).
     const int w4mode = wan_tune(WAN_TUNE_GEMM_W4);
-    const bool w4 = K % (2 * BK) == 0 && (w4mode == 1 || (w4mode == 2 && K >= 8192));
+    const bool w4 = K % (2 * BK) == 0 && ((w4mode == 1 && K >= 4096) || (w4mode == 2 && K >= 8192) || w4mode == 3);
 #define WAN_G256(E) (w4 ? launch_w4<E>(g, s) : phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
     switch (epilogue) {
         case WAN_EPI_BF16: return WAN_G256(WAN_EPI_BF16);
