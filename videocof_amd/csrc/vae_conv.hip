@@ -550,38 +550,64 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
         {
             char* stg = smem + ((gc - 1) & 1) * kPatchBytes + wid * 16384;
             constexpr int kStgPx = 96 * 4 + 16;                     // bytes per pixel in the staging rows (+16: spreads the banks)
+            // the two wave-uniform options (bias? residual?) select one of four straight-line copies, and all loads of a row --
+            // staging reads, bias, residual -- are issued before the first is used: tested per element the compiler put a scalar
+            // branch and a wait between them, 12 memory round trips per tile with nothing else running on the CU
+            auto write_rows = [&](auto has_bias, auto has_resid) {
+                constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_RESID = decltype(has_resid)::value;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<f32x4*>(stg + m32 * kStgPx + (j * 32 + q * 8 + hi1 * 4) * 4) =
-                            f32x4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                const int h = cur.h0 + 2 * wid + i;
-                const int64_t orow0 = ((int64_t)cur.t0 * g.H_out + h) * g.W_out + cur.w0;
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<f32x4*>(stg + m32 * kStgPx + (j * 32 + q * 8 + hi1 * 4) * 4) =
+                                f32x4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                    const int h = cur.h0 + 2 * wid + i;
+                    const int64_t orow0 = ((int64_t)cur.t0 * g.H_out + h) * g.W_out + cur.w0;
+                    f32x4 lo[6], hi[6];
+                    float4 b0[6], b1[6];
+                    u32x4 rv[6];
+                    int64_t off[6];
+                    bool ok[6];
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int e = it * 64 + lane, px = e / 12, ch = e - px * 12;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * kStgPx + ch * 32);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * kStgPx + ch * 32 + 16);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const int n = cur.n0 + ch * 8;
-                    if (h < g.H_out && cur.w0 + px < g.W_out) {
-                        if (g.bias) {
-                            const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
-                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    for (int it = 0; it < 6; ++it) {
+                        const int e = it * 64 + lane, px = e / 12, ch = e - px * 12;
+                        const int n = cur.n0 + ch * 8;
+                        lo[it] = *reinterpret_cast<const f32x4*>(stg + px * kStgPx + ch * 32);
+                        hi[it] = *reinterpret_cast<const f32x4*>(stg + px * kStgPx + ch * 32 + 16);
+                        ok[it] = h < g.H_out && cur.w0 + px < g.W_out;
+                        off[it] = ok[it] ? (orow0 + px) * g.ldo + n : 0;          // out of range: a valid address, not stored
+                        if constexpr (HAS_BIAS) {
+                            b0[it] = *reinterpret_cast<const float4*>(g.bias + n);
+                            b1[it] = *reinterpret_cast<const float4*>(g.bias + n + 4);
                         }
-                        const int64_t off = (orow0 + px) * g.ldo + n;
-                        if (g.resid) {
-                            const u32x4 rv = *reinterpret_cast<const u32x4*>(g.resid + off);
+                        if constexpr (HAS_RESID) rv[it] = *reinterpret_cast<const u32x4*>(g.resid + off[it]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) { v[2 * k] += bf16lo_to_f32(rv[k]); v[2 * k + 1] += bf16hi_to_f32(rv[k]); }
+                    for (int it = 0; it < 6; ++it) {
+                        float v[8] = {lo[it][0], lo[it][1], lo[it][2], lo[it][3], hi[it][0], hi[it][1], hi[it][2], hi[it][3]};
+                        if constexpr (HAS_BIAS) {
+                            v[0] += b0[it].x; v[1] += b0[it].y; v[2] += b0[it].z; v[3] += b0[it].w;
+                            v[4] += b1[it].x; v[5] += b1[it].y; v[6] += b1[it].z; v[7] += b1[it].w;
                         }
-                        *reinterpret_cast<u32x4*>(g.out + off) =
-                            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        if constexpr (HAS_RESID) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { v[2 * k] += bf16lo_to_f32(rv[it][k]); v[2 * k + 1] += bf16hi_to_f32(rv[it][k]); }
+                        }
+                        if (ok[it])
+                            *reinterpret_cast<u32x4*>(g.out + off[it]) =
+                                u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                     }
                 }
+            };
+            if (g.bias) {
+                if (g.resid) write_rows(std::true_type{}, std::true_type{});
+                else write_rows(std::true_type{}, std::false_type{});
+            } else {
+                if (g.resid) write_rows(std::false_type{}, std::true_type{});
+                else write_rows(std::false_type{}, std::false_type{});
             }
         }
         cur = nxt;
