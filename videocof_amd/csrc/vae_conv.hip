@@ -249,43 +249,67 @@ __global__ __launch_bounds__(kThreads, NT == 6 ? 1 : 2) void conv_cl_kernel(Conv
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds pixel m = l&15, channels n = (l>>4)*4 + r
+    // ---- epilogue: lane holds pixel m = l&15, channels n = (l>>4)*4 + r.  The bias of the NT column groups is loaded once, the
+    // residual values of one pixel group back to back (clamped addresses, guarded stores), and the wave-uniform options (bias?
+    // residual?) select one of four straight-line copies: written element by element the compiler emitted load / wait / store once
+    // per (pixel group, column group).
     const int l15 = lane & 15, l4 = (lane >> 4) * 4;
     const int Ch = g.interleave ? g.Cout >> 1 : g.Cout;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + l15;
-        if (m >= g.M) continue;
-        int64_t orow = m;
-        int to = 0, rem = 0;
-        if (g.interleave) {
-            const int hw = g.H_out * g.W_out;
-            to = m / hw;
-            rem = m - to * hw;
-        }
+    auto write_tiles = [&](auto has_bias, auto has_resid) {
+        constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_RESID = decltype(has_resid)::value;
+        int col[NT], half[NT];
+        bool nok[NT];
+        float4 bv[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wc * (16 * NT) + j * 16 + l4;
-            if (n >= g.Cout) continue;
-            f32x4 v = acc[i][j];
-            if (g.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            int col = n;
-            if (g.interleave) {            // frame 2t + half, channel n - half*Ch   (wan_vae.py:138-141)
-                const int half = n >= Ch;
-                col = n - half * Ch;
-                orow = (int64_t)(2 * to + half) * (g.H_out * g.W_out) + rem;
-            }
-            if (g.resid) {
-                const u32x2 rv = *reinterpret_cast<const u32x2*>(g.resid + orow * g.ldo + col);
-                v[0] += bf16lo_to_f32(rv[0]); v[1] += bf16hi_to_f32(rv[0]);
-                v[2] += bf16lo_to_f32(rv[1]); v[3] += bf16hi_to_f32(rv[1]);
-            }
-            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(g.out + orow * g.ldo + col) = o;
+            int n = n0 + wc * (16 * NT) + j * 16 + l4;
+            nok[j] = n < g.Cout;
+            n = nok[j] ? n : 0;
+            if constexpr (HAS_BIAS) bv[j] = *reinterpret_cast<const float4*>(g.bias + n);
+            half[j] = g.interleave && n >= Ch;          // frame 2t + half, channel n - half*Ch   (wan_vae.py:138-141)
+            col[j] = n - half[j] * Ch;
         }
+        const int hw = g.H_out * g.W_out;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + l15;
+            const bool mok = m < g.M;
+            const int mm = mok ? m : 0;
+            int to = 0, rem = 0;
+            if (g.interleave) {
+                to = mm / hw;
+                rem = mm - to * hw;
+            }
+            int64_t off[NT];
+            u32x2 rv[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t orow = g.interleave ? (int64_t)(2 * to + half[j]) * hw + rem : (int64_t)mm;
+                off[j] = orow * g.ldo + col[j];
+                if constexpr (HAS_RESID) rv[j] = *reinterpret_cast<const u32x2*>(g.resid + off[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 v = acc[i][j];
+                if constexpr (HAS_BIAS) { v[0] += bv[j].x; v[1] += bv[j].y; v[2] += bv[j].z; v[3] += bv[j].w; }
+                if constexpr (HAS_RESID) {
+                    v[0] += bf16lo_to_f32(rv[j][0]); v[1] += bf16hi_to_f32(rv[j][0]);
+                    v[2] += bf16lo_to_f32(rv[j][1]); v[3] += bf16hi_to_f32(rv[j][1]);
+                }
+                if (mok && nok[j]) {
+                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(g.out + off[j]) = o;
+                }
+            }
+        }
+    };
+    if (g.bias) {
+        if (g.resid) write_tiles(std::true_type{}, std::true_type{});
+        else write_tiles(std::true_type{}, std::false_type{});
+    } else {
+        if (g.resid) write_tiles(std::false_type{}, std::true_type{});
+        else write_tiles(std::false_type{}, std::false_type{});
     }
 }
 
