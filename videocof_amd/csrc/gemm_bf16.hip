@@ -156,42 +156,63 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     // ---- epilogue
     const int l15 = lane & 15, l4 = (lane >> 4) * 4;
     if constexpr (!kTransposed) {
+        // The bias of a column group is loaded once; the fp32 read-modify-write epilogue reads the residual stream (and the gate
+        // rows) of two row groups back to back and waits once (element by element the compiler emitted load / wait / store per
+        // 4-element group).  Out-of-range rows / columns read a clamped (valid) address and are not stored.
+        int nn[4];
+        bool nok[4];
+        float4 bj[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + l15;
-            if (m >= g.M) continue;
-            const int64_t b = g.gate ? (int64_t)m / g.rows_per_batch : 0;
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + l4;      // N % 4 == 0 -> whole 4-group in or out
+            nok[j] = n < g.N;
+            nn[j] = nok[j] ? n : 0;
+            bj[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nn[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int rpb = g.gate ? (int)g.rows_per_batch : 1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wc * 64 + j * 16 + l4;
-                if (n >= g.N) continue;      // N % 4 == 0 -> whole 4-group in or out
-                f32x4 v = acc[i][j];
-                if (g.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if constexpr (EPI == WAN_EPI_GELU_BF16) {
+        for (int ig = 0; ig < 4; ig += 2) {
+            int mm[2];
+            bool mok[2];
+            float4 xr[2][4], gv[2][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
-                }
-                if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
-                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)m * g.ldo + n) = o;
-                } else if constexpr (EPI == WAN_EPI_F32) {
-                    *reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-                } else {   // WAN_EPI_RESID_F32
-                    float4* p = reinterpret_cast<float4*>((float*)g.out + (int64_t)m * g.ldo + n);
-                    float4 x = *p;
-                    if (g.gate) {
-                        const float4 gv = *reinterpret_cast<const float4*>(g.gate + b * g.N + n);
-                        x.x += v[0] * gv.x; x.y += v[1] * gv.y; x.z += v[2] * gv.z; x.w += v[3] * gv.w;
-                    } else {
-                        x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+            for (int ii = 0; ii < 2; ++ii) {
+                const int m = m0 + wr * 64 + (ig + ii) * 16 + l15;
+                mok[ii] = m < g.M;
+                mm[ii] = mok[ii] ? m : g.M - 1;
+                if constexpr (EPI == WAN_EPI_RESID_F32) {
+                    const int64_t brow = g.gate ? (int64_t)(mm[ii] / rpb) * g.N : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        xr[ii][j] = *reinterpret_cast<const float4*>((const float*)g.out + (int64_t)mm[ii] * g.ldo + nn[j]);
+                        gv[ii][j] = g.gate ? *reinterpret_cast<const float4*>(g.gate + brow + nn[j]) : make_float4(1.f, 1.f, 1.f, 1.f);
                     }
-                    *p = x;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);          // all loads of the batch are issued before the first use waits
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[ig + ii][j];
+                    v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w;
+                    if constexpr (EPI == WAN_EPI_GELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
+                    }
+                    if (!(mok[ii] && nok[j])) continue;
+                    const int64_t off = (int64_t)mm[ii] * g.ldo + nn[j];
+                    if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
+                        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2*>((bf16_t*)g.out + off) = o;
+                    } else if constexpr (EPI == WAN_EPI_F32) {
+                        *reinterpret_cast<float4*>((float*)g.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {   // WAN_EPI_RESID_F32
+                        const float4 x = xr[ii][j], gq = gv[ii][j];
+                        *reinterpret_cast<float4*>((float*)g.out + off) =
+                            make_float4(x.x + v[0] * gq.x, x.y + v[1] * gq.y, x.z + v[2] * gq.z, x.w + v[3] * gq.w);
+                    }
+                }
         }
     } else {
         // out[n, m..m+3]: lane holds n = l&15, m = (l>>4)*4 + r
