@@ -54,6 +54,25 @@ def test_argument_errors_map_to_python_exceptions():
         _lib.check(st, "wan_attention_fwd")
     st = lib.wan_gemm_bf16(1, 100, 1, 100, None, 1, 128, 4, 128, 100, 0, None, 0, None)
     assert st == _lib.WAN_ERR_UNSUPPORTED      # K not a multiple of 64
+    # the composites validate before they enqueue anything
+    st = lib.wan_dit_block_forward(None, None, None, None, None, None, None, None, None, 1, 420, 420, None)
+    assert st == _lib.WAN_ERR_INVALID
+    st = lib.wan_dit_forward(None, 0, None, 0, None, None, None, None, None, None, None, None, None, 1, 7, 12, 20, 420, 0, None)
+    assert st == _lib.WAN_ERR_INVALID
+    with pytest.raises(ValueError, match="null argument"):
+        _lib.check(st, "wan_dit_forward")
+    # a latent that is not a multiple of the patch (weights / workspace only need to be non-null for this check to be reached)
+    import ctypes
+    w, ws, rp = _lib.DitWeights(), _lib.DitWorkspace(), _lib.RopeParams()
+    bw = (_lib.BlockWeights * 1)()
+    w.num_layers, w.blocks, w.pt, w.ph, w.pw = 1, bw, 1, 2, 2
+    w.pe_w = w.pe_b = w.head_w = w.head_b = 8
+    ws.x = ws.tokens = ws.head_out = 8
+    ptrs = (ctypes.c_void_p * 1)(8)
+    st = lib.wan_dit_forward(8, 0, 8, 0, 8, 8, ptrs, ptrs, ctypes.byref(w), ctypes.byref(ws), 8, 8, ctypes.byref(rp), 1, 7, 13, 20, 420, 0, None)
+    assert st == _lib.WAN_ERR_INVALID
+    with pytest.raises(ValueError, match="not a multiple of the patch"):
+        _lib.check(st, "wan_dit_forward")
 
 
 def test_attention_tail_plan_is_pure_host_logic():
