@@ -809,7 +809,7 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
         const bool shape_ok = ntaps == 27 && p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 2 && p->ph == 1 && p->pw == 1 &&
                               !p->upsample2x && !p->time_interleave && p->Cin % 32 == 0 && p->Cout % 96 == 0 &&
                               p->T_out == p->T_in && p->H_out == p->H_in && p->W_out == p->W_in &&
-                              px < (1 << 24) && px * p->Cin < (1LL << 32) && ldo % 8 == 0 &&
+                              px < (1 << 24) && px * p->Cin < (1LL << 31) && ldo % 8 == 0 &&          // element offsets in int
                               ((uintptr_t)out & 15) == 0 && ((uintptr_t)resid & 15) == 0;          // 16-byte output stores
         if (mode && shape_ok) return launch_conv3_patch(g, s);      // also with fewer tiles than CUs (1 latent frame: 544 vs 285 TFLOP/s)
     }
