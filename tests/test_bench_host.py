@@ -1,0 +1,56 @@
+"""CPU: the host arithmetic behind bench.py's JSON line -- workload table, FLOP formula, PMC traffic reader,
+timing helper.  (The measured numbers themselves come from the GPU box; these pin what they are divided by.)"""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tokens(wl):
+    return (wl["fs"] + wl["g"] + wl["ft"]) * (wl["h"] // 2) * (wl["w"] // 2)
+
+
+def test_workloads_are_the_baseline_configs():
+    w = bench.WORKLOADS
+    assert tokens(w["14b-cof"]) == 67080 and tokens(w["1.3b-cof"]) == 67080          # [src 21 | ground 1 | tgt 21] x 30 x 52
+    assert tokens(w["1.3b-small"]) == 2304                                            # configs[0]: 9 x 32 x 32 latent
+    assert tokens(w["14b-720p"]) == 75600                                             # configs[3]: 21 x 45 x 80
+    assert tokens(w["14b-cof-321f-720p"]) == 586800                                   # configs[4]
+    for name in ("14b-cof", "14b-t2v", "14b-720p", "14b-cof-321f-720p"):
+        assert (w[name]["dim"], w[name]["ffn_dim"], w[name]["num_heads"], w[name]["num_layers"]) == (5120, 13824, 40, 40)
+    assert (w["1.3b-cof"]["dim"], w["1.3b-cof"]["ffn_dim"], w["1.3b-cof"]["num_heads"], w["1.3b-cof"]["num_layers"]) == (1536, 8960, 12, 30)
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        assert len(json.load(f)["configs"]) == 5
+
+
+def test_flop_formula_at_the_north_star_shape():
+    total, attn = bench.dit_flops(67080, 5120, 13824, 40)
+    # one forward = 5.32 PFLOP, 70 % of it self-attention; one self-attention launch = 4 L^2 C = 9.215e13
+    assert abs(total / 5.32e15 - 1) < 5e-3
+    assert abs(attn / 40 / 9.215e13 - 1) < 1e-3
+    assert 0.68 < attn / total < 0.72
+
+
+def test_pmc_traffic_reads_the_newest_committed_profile():
+    total, d = bench.pmc_traffic("14b-cof", 1)
+    assert d is not None and d["source"].startswith("profiles/r") and d["source"].endswith("bench14b_pmc_summary.json")
+    with open(os.path.join(ROOT, d["source"])) as f:
+        raw = next(v for k, v in json.load(f).items() if "attn_fwd" in k and "<0" in k)
+    assert d["fetch_bytes_x2_corrected"] == raw["fetch"]["avg_counter"] * 1024 * 2        # the guide's gfx950 FETCH_SIZE correction
+    assert d["write_bytes"] == raw["write"]["avg_counter"] * 1024
+    assert total == d["fetch_bytes_x2_corrected"] + d["write_bytes"]
+    assert d["algorithmic_bytes"] == 4 * 67080 * 5120 * 2                                   # q, k, v read + o written, bf16
+    assert 1.0 < total / d["algorithmic_bytes"] < 10.0
+    assert bench.pmc_traffic("14b-cof", 8) == (None, None) and bench.pmc_traffic("1.3b-small", 1) == (None, None)
+
+
+def test_timing_helper_and_host_threads():
+    calls = []
+    best, mean, n = bench._time_reps(lambda: calls.append(1), 3, 1e-3)
+    assert 3 <= n <= 8 and len(calls) == n + 1 and 0 <= best <= mean  # one warm-up call, then min_reps .. 8 repetitions
+    import time
+    best, mean, n = bench._time_reps(lambda: time.sleep(0.02), 3, 0.01)
+    assert n == 1 and best == mean >= 0.02                            # a first call over budget is the single sample
+    assert 1 <= bench.host_threads() <= (os.cpu_count() or 1)
