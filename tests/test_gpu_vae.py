@@ -242,6 +242,7 @@ def test_lds_patch_conv_vs_torch_and_vs_gather_kernel(cin, cout, T, H, W, nh, re
     try:
         ops.set_tuning("conv_patch", 2)
         got = run()
+        assert torch.equal(run(), got)          # persistent workgroups, fixed tile walk: bitwise reproducible
         ops.set_tuning("conv_patch", 0)
         gather = run()
     finally:
