@@ -303,7 +303,8 @@ wan_status_t wan_lincomb(void* out, int dtype, const void* x0, const void* x1, c
  * WanVAE (videox_fun/models/wan_vae.py).  Activations are CHANNELS-LAST bf16 [T, H, W, C].
  * ------------------------------------------------------------------------- */
 
-/* a18/a19  every convolution of the VAE as one implicit-GEMM kernel:
+/* a18/a19  every convolution of the VAE through one entry (two kernels behind it: the causal 3x3x3 / stride-1 convolutions with
+ *     Cin % 32 == 0 and Cout % 96 == 0 keep their input patch in LDS; everything else is an implicit GEMM with a gathered A tile):
  *     out[(to,ho,wo), n] = bias[n] + sum_{kt,kh,kw,ci} in[to*st+kt-pt, ho*sh+kh-ph, wo*sw+kw-pw, ci] * w[n,(kt,kh,kw,ci)]
  *                          (+ resid[(to,ho,wo), n])
  *     replaces: CausalConv3d.forward incl. the cache_x halo (wan_vae.py:21-40: frames with negative
