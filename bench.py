@@ -10,10 +10,13 @@ SURVEY.md section 8d) and are resident in HBM before the timed region.  `value` 
 latent tokens/s = B * L * K / wall with L = ALL DiT tokens per sample (the quantity the FLOP
 formula is written in); `denoised_only_tokens_per_s` scales it by (G+Ft)/(Fs+G+Ft).
 
-N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ...`): the SAME video is
-sequence-sharded over the N GPUs with Ulysses head all-to-all on RCCL (strong scaling), or
-`--mode dp` runs N independent replicas (weak scaling; what the reference CLI does,
-fast_infer.py:272).
+N > 1: one process per GPU (fast_infer.py:218-222 runs under torchrun).  Either launched as `python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or as plain `python bench.py --gpus N`, which
+re-executes itself under torch.distributed.run (free port on 127.0.0.1).  The SAME video is sequence-sharded over
+the N GPUs with Ulysses head all-to-all on RCCL (strong scaling), or `--mode dp` runs N independent replicas (weak
+scaling; what the reference CLI does, fast_infer.py:272).  The N > 1 line adds `ranks_seen`, `exposed_comm_ms`
+(HIP events around the exchanges the projections do not cover: the waits before attention and the inverse exchange)
+and the roofline of the local head shard.
 
 Rank 0 prints ONE JSON line; it also carries
   roofline      -- the dominant kernel (self-attention flash kernel): algorithmic FLOP per launch
@@ -103,29 +106,32 @@ def host_threads():
 
 
 def _time_reps(fn, min_reps, budget_s):
-    """Wall time per call.  The first (warm-up) call is timed too: if it alone exceeds the budget -- a slow host -- it
-    is the single sample; otherwise >= min_reps further repetitions (more while the budget lasts, at most 8)."""
-    t0 = time.perf_counter()
-    fn()
-    first = time.perf_counter() - t0
-    if first > budget_s:
-        return first, first, 1
+    """Wall times of repeated calls.  Every call is timed, the first (cold caches, first-touch allocations) included and
+    labelled; if it alone exceeds the budget -- a slow host -- it is the single sample; otherwise min_reps - 1 further
+    repetitions (more while the budget lasts, at most 8 in all).  Returns (best, mean of the warm ones, all times)."""
     ts = []
     t_start = time.perf_counter()
-    while len(ts) < min_reps or (time.perf_counter() - t_start < budget_s and len(ts) < 8):
+    while True:
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
-    return min(ts), sum(ts) / len(ts), len(ts)
+        spent = time.perf_counter() - t_start
+        if len(ts) == 1 and ts[0] > budget_s:
+            break
+        if len(ts) >= min_reps and (spent >= budget_s or len(ts) >= 8):
+            break
+    warm = ts[1:] or ts
+    return min(ts), sum(warm) / len(warm), ts
 
 
 def cpu_baseline(wl, L_target, budget_s=30.0):
     """the CPU oracle (port of the reference's fp32 math, oracle/wan_oracle.py) on the host
-    cores, at three MEASURED points -- (a) BASELINE configs[0] end to end (1.3B dims, 9x32x32 latent, L = 2 304),
-    (b) one block of the workload's width at L = 2 304 and (c) at L = 8 192 -- and an EXTRAPOLATION of (b),(c) to the
+    cores, at MEASURED points -- (a) BASELINE configs[0] end to end (1.3B dims, 9x32x32 latent, L = 2 304), (b) one
+    block of the workload's width at L = 2 304, 4 096 and 8 192, >= 3 timed calls each -- and an EXTRAPOLATION of (b) to the
     workload's token count with the section-8d FLOP formula: per-layer time = lin_flop(L) / R_lin + attn_flop(L) /
-    R_attn with the two rates solved from the two measured block points (the share of attention grows with L, so one
-    rate for both would flatter the CPU at L = 2 304 and penalise it at L = 67 080)."""
+    R_attn, the two rates fitted (least squares) to the three block points (the share of attention grows with L, so one
+    rate for both would flatter the CPU at L = 2 304 and penalise it at L = 67 080).  The spread of the extrapolation =
+    the three values the three PAIRS of points give."""
     from oracle import wan_oracle as O
     cores = host_threads()
     torch.set_num_threads(cores)
@@ -153,46 +159,68 @@ def cpu_baseline(wl, L_target, budget_s=30.0):
     def attn_flop(L):
         return 4 * L * L * C + 4 * L * 512 * C
 
+    def rnd(ts):
+        return [round(t, 3) for t in ts]
+
     points = []
     with torch.no_grad():
-        for grid, reps, share in (((9, 16, 16), 3, 0.2), ((8, 32, 32), 3, 0.5)):
+        for grid, share in (((9, 16, 16), 0.12), ((8, 32, 16), 0.2), ((8, 32, 32), 0.4)):
             L = grid[0] * grid[1] * grid[2]
             x = torch.randn(L, C, generator=g)
-            best, mean, n = _time_reps(lambda: O.block_forward(x, e0, ctx, sd, 0, cfg, grid, ang, 4, (4, 5), L), reps,
-                                       budget_s * share)
-            points.append({"L": L, "s_per_block_min": round(best, 4), "s_per_block_mean": round(mean, 4), "reps": n,
-                           "gflops": round((lin_flop(L) + attn_flop(L)) / best / 1e9, 1)})
+            best, mean, ts = _time_reps(lambda: O.block_forward(x, e0, ctx, sd, 0, cfg, grid, ang, 4, (4, 5), L), 3,
+                                        budget_s * share)
+            points.append({"L": L, "s_per_block_min": round(best, 4), "s_per_block_mean_warm": round(mean, 4), "reps": len(ts),
+                           "s_all": rnd(ts), "gflops": round((lin_flop(L) + attn_flop(L)) / best / 1e9, 1)})
         # (a) configs[0] end to end: the real 1.3B architecture on a 9x32x32 latent
         from videocof_amd.weights import dit_param_shapes
         cfg0 = O.DiTConfig(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30)
         sd0 = {k: torch.randn(v, generator=g) * (0.02 if len(v) > 1 else 0.1)
                for k, v in dit_param_shapes(dim=1536, ffn_dim=8960, num_layers=30).items()}
         lat0, ctx0 = torch.randn(1, 16, 9, 32, 32, generator=g), [torch.randn(37, 4096, generator=g)]
-        b0, m0, n0 = _time_reps(lambda: O.dit_forward(sd0, cfg0, lat0, torch.tensor([500]), ctx0, 2304, [4], [(4, 5)]), 1,
-                                budget_s * 0.3)
+        b0, m0, ts0 = _time_reps(lambda: O.dit_forward(sd0, cfg0, lat0, torch.tensor([500]), ctx0, 2304, [4], [(4, 5)]), 3,
+                                 budget_s * 0.3)
     config0 = {"workload": "BASELINE configs[0]: Wan2.1-T2V-1.3B single forward, 9x32x32 latent, L=2304, fp32",
-               "s_per_forward_min": round(b0, 3), "s_per_forward_mean": round(m0, 3), "reps": n0,
+               "s_per_forward_min": round(b0, 3), "s_per_forward_mean_warm": round(m0, 3), "reps": len(ts0), "s_all": rnd(ts0),
                "tokens_per_s": round(2304 / b0, 1)}
-    # two-rate fit from the two block points:  t = lin/R_lin + attn/R_attn
-    (La, ta), (Lb, tb) = [(q["L"], q["s_per_block_min"]) for q in points]
-    a11, a12, a21, a22 = lin_flop(La), attn_flop(La), lin_flop(Lb), attn_flop(Lb)
-    det = a11 * a22 - a12 * a21
-    inv_rlin, inv_rattn = (ta * a22 - tb * a12) / det, (a11 * tb - a21 * ta) / det
-    fit = "two-rate (linear | attention) fit of the two measured block points"
-    if inv_rlin <= 0 or inv_rattn <= 0:        # noisy timing: fall back to one rate from the larger point
-        inv_rlin = inv_rattn = tb / (a21 + a22)
+
+    # two-rate model t = lin/R_lin + attn/R_attn: least squares over the block points, and each pair of points on its own
+    def solve(pts):
+        a = torch.tensor([[lin_flop(q["L"]), attn_flop(q["L"])] for q in pts], dtype=torch.float64)
+        b = torch.tensor([q["s_per_block_min"] for q in pts], dtype=torch.float64)
+        sc = a.abs().max(dim=0).values                      # column scaling: the two FLOP columns differ by orders of magnitude
+        x = torch.linalg.lstsq(a / sc, b[:, None]).solution[:, 0] / sc
+        return float(x[0]), float(x[1])
+
+    def per_layer(il, ia):
+        return lin_flop(L_target) * il + attn_flop(L_target) * ia
+
+    inv_rlin, inv_rattn = solve(points)
+    fit = "two-rate (linear | attention) least-squares fit of the three measured block points"
+    if inv_rlin <= 0 or inv_rattn <= 0:        # noisy timing: fall back to one rate from the largest point
+        q = points[-1]
+        inv_rlin = inv_rattn = q["s_per_block_min"] / (lin_flop(q["L"]) + attn_flop(q["L"]))
         fit = "single rate from the L=8192 point (the two-rate fit was ill-conditioned)"
-    t_layer = lin_flop(L_target) * inv_rlin + attn_flop(L_target) * inv_rattn
+    t_layer = per_layer(inv_rlin, inv_rattn)
     value = L_target / (t_layer * layers)
+    pair_values = []
+    for i in range(len(points)):
+        for j in range(i + 1, len(points)):
+            il, ia = solve([points[i], points[j]])
+            if il > 0 and ia > 0:
+                pair_values.append(round(L_target / (per_layer(il, ia) * layers), 3))
+    resid = [round((lin_flop(q["L"]) * inv_rlin + attn_flop(q["L"]) * inv_rattn) / q["s_per_block_min"] - 1.0, 4) for q in points]
+    pts_txt = ", ".join(f"L={q['L']} ({q['reps']} calls, min {q['s_per_block_min']:.2f} s)" for q in points)
     return {"value": round(value, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
             "extrapolated": True,
             "sample": f"oracle/wan_oracle.py (fp32 torch-CPU port of the reference), {cores} host threads.  MEASURED: one "
-                      f"{C}-wide block at L={La} ({points[0]['reps']} reps, min {ta:.2f} s) and L={Lb} ({points[1]['reps']} reps, min "
-                      f"{tb:.2f} s); configs[0] end to end ({n0} reps, {b0:.2f} s).  `value` is EXTRAPOLATED to L={L_target} x "
-                      f"{layers} layers with the SURVEY 8d FLOP formula, {fit}: {t_layer:.1f} s/layer.",
+                      f"{C}-wide block at {pts_txt}; configs[0] end to end ({len(ts0)} calls, min {b0:.2f} s).  `value` is "
+                      f"EXTRAPOLATED to L={L_target} x {layers} layers with the SURVEY 8d FLOP formula, {fit}: "
+                      f"{t_layer:.1f} s/layer; pairwise fits give {min(pair_values or [value]):.2f}..{max(pair_values or [value]):.2f} tokens/s.",
             "measured_points": {"block": points, "config0_end_to_end": config0},
             "fit": {"linear_gflops": round(1e-9 / inv_rlin, 1), "attention_gflops": round(1e-9 / inv_rattn, 1),
-                    "s_per_layer_at_target": round(t_layer, 2), "s_per_step_at_target": round(t_layer * layers, 1)}}
+                    "s_per_layer_at_target": round(t_layer, 2), "s_per_step_at_target": round(t_layer * layers, 1),
+                    "relative_residual_at_points": resid,
+                    "value_spread_pairwise_fits": [min(pair_values or [value]), max(pair_values or [value])]}}
 
 
 def verify_last_block(model, wl, lat, t, ctx, seq_len, fsi, gfi, out, L):
@@ -230,6 +258,22 @@ def verify_last_block(model, wl, lat, t, ctx, seq_len, fsi, gfi, out, L):
             "tolerance": {"rel_l2": 1e-2, "cosine": 0.9999}, "ok": bool(rel < 1e-2 and cos > 0.9999)}
 
 
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, rendezvous
+    on a free port of 127.0.0.1 (the container hostname may not resolve).  Rank 0's JSON line goes to the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,10 +299,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-        args.gpus = world
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_spawn(args.gpus))        # no launcher: become one (the ranks come back through main())
+    args.gpus = world
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -307,6 +350,8 @@ def main():
 
     prof = [] if not args.no_kernel_events else None
     model._attn_events = prof
+    comm = [] if (sp and prof is not None) else None
+    model._comm_events = comm
 
     fwd = model
     if args.graph:
@@ -338,6 +383,10 @@ def main():
         run(max(args.warmup, 2) if args.graph else args.warmup)      # graph: one eager call + the capture
     if prof is not None:
         prof.clear()
+    if comm is not None:
+        comm.clear()
+    if model._ws_self.buf is not None:
+        model._ws_self.buf[8:12].zero_()          # scratch header word [2]: repair events of the lazy softmax reference
     fence()
     t0 = time.perf_counter()
     out = run(args.steps)
@@ -379,9 +428,13 @@ def main():
         flop = 4.0 * Lq * Lk * heads_local * 128
         ach = flop / (avg_ms * 1e-3) / 1e12
         traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1)
-        roof = {"kernel": "attn_fwd_w4_kernel<0> = self-attention, pre-scaled q, max-free 4-wave kernel (per wan_attention_fwd call: this "
-                          "main launch + the MODE 2 fix-up launch attn_fwd_v2_kernel<0, true, false, 2> + the split-KV tail round "
-                          "attn_fwd_v2_kernel<0, true, true, 0> + merge)", "bound": "mfma", "achieved": round(ach, 1),
+        from videocof_amd import _lib
+        vcode = int(model._last_attn_variant)
+        repairs = int(model._ws_self.buf[8:12].view(torch.int32).item()) if model._ws_self.buf is not None else None
+        roof = {"kernel": "self-attention wan_attention_fwd: " + _lib.attn_variant_name(vcode), "variant_code": vcode,
+                "kernel_reported_by": "wan_get_tuning('last_attn_variant') right after the launch",
+                "attn_repair_events": repairs, "heads_local": heads_local,
+                "bound": "mfma", "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
@@ -408,6 +461,13 @@ def main():
         "model_tflops_per_s": round(units * tot_flop * args.steps / wall / 1e12, 1),
         "mfma_frac_whole_step": round(units * tot_flop * args.steps / wall / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": roof,
+        "ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (host-staged, numbers meaningless)")) if world > 1 else None,
+        "exposed_comm_ms": None if not comm else {
+            "per_step": round(sum(a.elapsed_time(b) for a, b in comm) / args.steps, 3),
+            "per_layer": round(sum(a.elapsed_time(b) for a, b in comm) / args.steps / wl["num_layers"], 4),
+            "what": "HIP events on the compute stream around (i) wait_k / wait_v / V^T unpack / wait_q before attention and "
+                    "(ii) the inverse (o) exchange; the k and V^T exchanges themselves run under the V and q projections"},
         "parity": parity,
         "graph": bool(args.graph),
     }

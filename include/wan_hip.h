@@ -47,9 +47,19 @@ const char* wan_last_error(void);
  * "attn_fast", "attn_xcd_map", "attn_w4", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
  * "debug_checks" = 1 turns on SYNCHRONISING contract checks (V^T pad columns of wan_attention_fwd are finite).
  * wan_set_tuning is an atomic store: safe against concurrent launches, which see the old or the new value.
- * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code). */
+ * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code).
+ * Read-only key "last_attn_variant": what the most recent wan_attention_fwd call of this process launched, as
+ * WAN_ATTN_VARIANT_* (kernel family | WAN_ATTN_VARIANT_XCD_PINNED | WAN_ATTN_VARIANT_SPLIT_TAIL) -- so that a benchmark
+ * reports the kernel the dispatcher picked instead of a literal. */
 wan_status_t wan_set_tuning(const char* key, int value);
 int wan_get_tuning(const char* key);
+#define WAN_ATTN_VARIANT_W4_LAZY 1          /* attn_fwd_w4_kernel<.,.,false>: 4 waves, lazy softmax reference (the product path) */
+#define WAN_ATTN_VARIANT_W4_MAXFREE 2       /* attn_fwd_w4_kernel<.,false,true> + checked fix-up launch ("attn_fast" = 1) */
+#define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* attn_fwd_v2_kernel, 8 waves, running max per tile ("attn_w4" = 0) */
+#define WAN_ATTN_VARIANT_W8_MAXFREE 4       /* attn_fwd_v2_kernel<.,true,false,1> + fix-up ("attn_w4" = 0, "attn_fast" = 1) */
+#define WAN_ATTN_VARIANT_FAMILY_MASK 15
+#define WAN_ATTN_VARIANT_XCD_PINNED 16      /* every (batch, head) pinned to one XCD */
+#define WAN_ATTN_VARIANT_SPLIT_TAIL 32      /* the last partial round ran split over the keys (+ merge kernel) */
 
 /* ---------------------------------------------------------------------------
  * a4  LayerNorm (no affine) + adaLN modulate, or LayerNorm with affine.

@@ -48,9 +48,32 @@ def test_pmc_traffic_reads_the_newest_committed_profile():
 
 def test_timing_helper_and_host_threads():
     calls = []
-    best, mean, n = bench._time_reps(lambda: calls.append(1), 3, 1e-3)
-    assert 3 <= n <= 8 and len(calls) == n + 1 and 0 <= best <= mean  # one warm-up call, then min_reps .. 8 repetitions
+    best, mean, ts = bench._time_reps(lambda: calls.append(1), 3, 1e-3)
+    assert 3 <= len(ts) <= 8 and len(calls) == len(ts) and 0 <= best <= max(ts)   # every call is timed, >= min_reps of them
     import time
-    best, mean, n = bench._time_reps(lambda: time.sleep(0.02), 3, 0.01)
-    assert n == 1 and best == mean >= 0.02                            # a first call over budget is the single sample
+    best, mean, ts = bench._time_reps(lambda: time.sleep(0.02), 3, 0.01)
+    assert len(ts) == 1 and best == mean >= 0.02                      # a first call over budget is the single sample
     assert 1 <= bench.host_threads() <= (os.cpu_count() or 1)
+
+
+def test_self_spawn_builds_a_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run on 127.0.0.1 (the
+    driver's first multi-GPU run must not die on a missing launcher)."""
+    import subprocess
+    import sys
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.self_spawn(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -114,6 +114,126 @@ def test_sp_forward_over_rccl_equals_single_device():
     assert all(r[1] < 2e-3 and r[2] for r in res), res
 
 
+def _rccl_ws1_worker(port, q_out):
+    """One rank, backend nccl (= RCCL), force_ulysses: every collective of the Ulysses branch is a real RCCL call on the
+    process group's own stream, issued async and waited for on the compute stream."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from videocof_amd import WanTransformer3DModel
+        from videocof_amd import dist as vdist
+        from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+        heads, layers = 4, 6
+        cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=layers, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+        m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=layers, text_dim=64)
+        m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+        lat = det_uniform("sp.lat", (2, 16, 7, 12, 20), 1.0).cuda()
+        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda(), det_uniform("sp.c1", (5, 64), 1.0).cuda()]
+        t = torch.tensor([749, 749], device="cuda:0")
+        kw = dict(frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
+        single = m(lat, t, ctx, 420, **kw)
+        vdist.init_sequence_parallel()
+        m.enable_multi_gpus_inference()
+        m.force_ulysses = True
+        assert m.sp_world_size == 1 and not vdist.get_sp_group()._host_staged
+        comm = m._comm_events = []
+        sharded = m(lat, t, ctx, 420, **kw)               # 420 -> 424 rows (multiple of 8): also the padded-key masking
+        assert m._usp and m._bufs[1].vt is None and m._bufs[1].kw_s is not None     # really the wire-buffer branch
+        again = m(lat, t, ctx, 420, **kw)                 # persistent wire buffers reused: a reuse hazard shows up here
+        lat2 = det_uniform("sp.lat2", (2, 16, 7, 12, 20), 1.0).cuda()
+        other = m(lat2, t, ctx, 420, **kw)                # other data through the same buffers ...
+        third = m(lat, t, ctx, 420, **kw)                 # ... and back
+        torch.cuda.synchronize()
+        n_ev = len(comm)
+        ms = sum(a.elapsed_time(b) for a, b in comm)
+        m.force_ulysses = False
+        m._comm_events = None
+        plain_again = m(lat, t, ctx, 420, **kw)
+        torch.cuda.synchronize()
+        q_out.put((float((sharded - single).norm() / single.norm()), bool(torch.equal(sharded, single)),
+                   bool(torch.equal(again, sharded)), bool(torch.equal(third, sharded)), bool(torch.equal(other, sharded)),
+                   bool(torch.equal(plain_again, single)), n_ev, ms, layers))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sp_async_path_over_rccl_on_one_gpu():
+    """The Ulysses branch on its REAL transport with one rank: backend "nccl" = RCCL, device buffers, `all_to_all_single(async_op=True)`
+    on the group's stream, every wait_*() ordering against the compute stream, the persistent wire buffers -- the code that
+    the 2-GPU test below covers but that a 1-GPU box otherwise never executes.  With P = 1 the exchanges are identities, so
+    the result must equal the plain forward (different GEMM split: q and k projected separately) and repeat bitwise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_ws1_worker, args=(_free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    rel, bitwise_single, again, third, other_equal, plain_ok, n_ev, ms, layers = q.get(timeout=5)
+    assert rel < 2e-3, rel
+    assert again and third, "the Ulysses forward does not repeat bitwise: a wire buffer is reused before its consumer finished"
+    assert not other_equal and plain_ok
+    assert n_ev == 2 * layers * 4                        # 4 forwards x (waits before attention + inverse exchange) per layer
+    print(f"rccl world_size=1: rel={rel:.2e} bitwise_vs_single={bitwise_single} exposed_comm={ms:.2f} ms over {n_ev} windows")
+
+
+def _shard_shape_worker(rank, world, port, q_out):
+    """14B width (40 heads -> 5 per rank at P = 8: no XCD pinning, split-KV tail round on), L = 16 384."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videocof_amd import WanTransformer3DModel, ops, _lib
+        from videocof_amd import dist as vdist
+        from videocof_amd.weights import random_dit_state_dict
+        dev = torch.device("cuda", 0)
+        shapes = dict(dim=5120, ffn_dim=13824, num_layers=1)
+        m = WanTransformer3DModel(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1)
+        m.load_state_dict(random_dit_state_dict(dev, seed=3, exercise_epilogues=True, **shapes), device=dev)
+        g = torch.Generator(device=dev).manual_seed(5)
+        lat = torch.randn(1, 16, 16, 64, 64, device=dev, generator=g).bfloat16()          # grid (16, 32, 32) = 16 384 tokens
+        ctx = [torch.randn(37, 4096, device=dev, generator=g).bfloat16()]
+        t = torch.tensor([500], device=dev)
+        kw = dict(frame_split_indices=[7], ground_frame_indices=[(7, 8)])
+        single = m(lat, t, ctx, 16384, **kw)
+        vdist.init_sequence_parallel()
+        m.enable_multi_gpus_inference()
+        ev = m._attn_events = []
+        sharded = m(lat, t, ctx, 16384, **kw)
+        torch.cuda.synchronize()
+        variant = int(m._last_attn_variant)
+        planned = int(_lib.load().wan_attention_workspace_bytes(1, 16384, 16384, 40 // world, 128))
+        q_out.put((rank, float((sharded.float() - single.float()).norm() / single.float().norm()), variant, planned))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sp_equals_single_device_at_the_14b_shard_shape():
+    """SP == single device where the shard arithmetic of the headline configuration is live: 40 heads over 8 ranks = 5 local
+    heads (nbh % 8 != 0 -> no XCD pinning), 64 query blocks x 5 heads = 320 workgroups = 256 + 64 -> the split-KV tail round
+    runs, 14B width (C = 5120, ffn 13 824, K = 5120 / 13 824 GEMM dispatch), non-zero biases and non-unit gains."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_shape_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    from videocof_amd import _lib
+    assert all(r[1] < 3e-3 for r in res), res
+    assert len({round(r[1], 9) for r in res}) == 1
+    assert all(r[2] & _lib.ATTN_VARIANT_SPLIT_TAIL and not (r[2] & _lib.ATTN_VARIANT_XCD_PINNED) for r in res), res
+    assert all(r[3] > 4096 for r in res)             # the tail plan asked for scratch
+
+
 def _alloc_worker(rank, world, port, q_out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

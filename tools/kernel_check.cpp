@@ -272,7 +272,10 @@ static void check_attn() {
     const bool pre = var[0] == '3';
     printf("wan_attention_fwd variant %s (+ wan_transpose_bf16)\n", var);
     struct Shape { int Lq, Lk, H; float qs; };
-    for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f}, Shape{86 * 256 + 10, 1100, 3, 1.f}}) {
+    // qscale 40 / 100: log2-domain scores of +-300 .. +-1000 -- far outside any fixed window, tile maxima that differ by > 100:
+    // the lazy softmax reference of the 4-wave kernel has to repair (and exp2 overflows to Inf before it does)
+    for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{520, 512, 2, 3.f}, Shape{33, 1000, 1, 6.f},
+                     Shape{520, 1500, 2, 40.f}, Shape{256, 4096, 1, 100.f}, Shape{86 * 256 + 10, 1100, 3, 1.f}}) {
         const int Lq = sh.Lq, Lk = sh.Lk, H = sh.H, C = H * 128;
         auto q = bf_round(randn((size_t)Lq * C, sh.qs)), k = bf_round(randn((size_t)Lk * C)), v = bf_round(randn((size_t)Lk * C));
         // make V asymmetric across d and key so a transposed/permuted read cannot pass
@@ -419,6 +422,17 @@ int main(int argc, char** argv) {
     }
     if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
     if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
+    if (mode == "attnarms") {     // check_attn under every dispatch arm of wan_attention_fwd
+        struct Arm { const char* name; int w4, fast, ref; };
+        for (Arm arm : {Arm{"w4 lazy, reference in the accumulator", 1, 0, 1}, Arm{"w4 lazy, packed shift", 1, 0, 2},
+                        Arm{"w4 max-free + fix-up", 1, 1, 1}, Arm{"8-wave running max", 0, 0, 1}}) {
+            printf("==== arm: %s\n", arm.name);
+            WAN(wan_set_tuning("attn_w4", arm.w4)); WAN(wan_set_tuning("attn_fast", arm.fast)); WAN(wan_set_tuning("attn_ref", arm.ref));
+            check_attn();
+            printf("  last variant 0x%x\n", wan_get_tuning("last_attn_variant"));
+        }
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+    }
     if (mode == "attnprof") {     // one shape, final kernel only: the target of the rocprofv3 --pmc passes (tools/profile_attn.sh)
         const int L = 67080, H = 40, C = H * 128; const int64_t ldvt = (L + 63) / 64 * 64;
         auto hq = to_bf(randn((size_t)4096 * 128));
@@ -447,11 +461,12 @@ int main(int argc, char** argv) {
         fill(q);
         const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
         Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
-        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp"};
-        int defaults[4]; for (int i = 0; i < 4; ++i) defaults[i] = wan_get_tuning(keys[i]);
+        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp", "attn_w4", "attn_ref"};
+        const int nkeys = 6;
+        int defaults[6]; for (int i = 0; i < nkeys; ++i) defaults[i] = wan_get_tuning(keys[i]);
         for (int round = 0; round < 2; ++round)
         for (int ai = first; ai < argc; ++ai) {
-            for (int i = 0; i < 4; ++i) WAN(wan_set_tuning(keys[i], defaults[i]));
+            for (int i = 0; i < nkeys; ++i) WAN(wan_set_tuning(keys[i], defaults[i]));
             std::string arm = argv[ai], tok;
             for (size_t p0 = 0; p0 < arm.size();) {
                 size_t p1 = arm.find(',', p0); if (p1 == std::string::npos) p1 = arm.size();
@@ -460,7 +475,7 @@ int main(int argc, char** argv) {
                 if (eq != std::string::npos) WAN(wan_set_tuning(tok.substr(0, eq).c_str(), atoi(tok.c_str() + eq + 1)));
             }
             double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr)); }, 4, 1);
-            printf("  attnx[%-28s] L=%d H=%d: %.3f ms  %.0f TFLOP/s\n", arm.c_str(), L, H, ms, 4.0 * L * L * C / ms / 1e9);
+            printf("  attnx[%-28s] L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", arm.c_str(), L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
             fflush(stdout);
         }
     }

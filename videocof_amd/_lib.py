@@ -16,6 +16,21 @@ LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
 ABI_VERSION = 3
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
+# wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
+ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax reference)",
+                      2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free) + attn_fwd_v2_kernel<.,true,false,2> fix-up",
+                      3: "attn_fwd_v2_kernel (8-wave, running max)",
+                      4: "attn_fwd_v2_kernel<.,true,false,1> (8-wave, max-free) + fix-up"}
+ATTN_VARIANT_XCD_PINNED, ATTN_VARIANT_SPLIT_TAIL = 16, 32
+
+
+def attn_variant_name(code: int) -> str:
+    name = ATTN_VARIANT_NAMES.get(code & 15, f"unknown({code})")
+    if code & ATTN_VARIANT_XCD_PINNED:
+        name += ", heads pinned to XCDs"
+    if code & ATTN_VARIANT_SPLIT_TAIL:
+        name += " + split-KV tail round (4-wave SPLIT kernel + attn_combine_kernel)"
+    return name
 
 WAN_OK, WAN_ERR_INVALID, WAN_ERR_UNSUPPORTED, WAN_ERR_LAUNCH = 0, 1, 2, 3
 EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32, EPI_BF16_T = 0, 1, 2, 3, 4

@@ -56,6 +56,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"gemm_w4", "WAN_GEMM_W4", 1},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 K >= 4096, 2 K >= 8192, 3 whenever K % 128 == 0
     {"conv_fast", "WAN_CONV_FAST", 1},          // wan_conv_cl gather addresses on the branch-free 24-bit multiply path (0 = general 64-bit path)
     {"conv_patch", "WAN_CONV_PATCH", 1},        // causal 3x3x3 stride-1 convs with Cout % 96 == 0 on the LDS-patch kernel (0 = the gather kernel)
+    {"attn_ref", "WAN_ATTN_REF", 1},            // lazy softmax reference of the 4-wave kernel: 1 = -m splat in the accumulator, 2 = packed subtract
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];
@@ -74,6 +75,9 @@ Tuning& tuning() {
 
 int wan_tune(int which) { return tuning().v[which].load(std::memory_order_relaxed); }
 
+static std::atomic<int> g_last_attn_variant{0};
+void wan_note_attn_variant(int variant) { g_last_attn_variant.store(variant, std::memory_order_relaxed); }
+
 extern "C" wan_status_t wan_set_tuning(const char* key, int value) {
     WAN_REQUIRE(key != nullptr, WAN_ERR_INVALID, "wan_set_tuning: null key");
     for (int i = 0; i < WAN_TUNE_COUNT; ++i)
@@ -86,6 +90,7 @@ extern "C" wan_status_t wan_set_tuning(const char* key, int value) {
 }
 
 extern "C" int wan_get_tuning(const char* key) {
+    if (key && !strcmp(key, "last_attn_variant")) return g_last_attn_variant.load(std::memory_order_relaxed);
     if (key)
         for (int i = 0; i < WAN_TUNE_COUNT; ++i)
             if (!strcmp(key, kTuningKeys[i].key)) return wan_tune(i);

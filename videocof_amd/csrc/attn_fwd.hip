@@ -504,7 +504,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 // ====================================================================================================
 constexpr int kW4Threads = 256;
 
-__device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 lds_read16_at(unsigned lds_byte_address) {
+    return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_byte_address;
+}
 
 // Pipeline: K(t+2) / V(t+1) are requested (LDS-DMA) during the S segment of interval t and waited for (vmcnt(0) + barrier)
 // at its end; rings K 2 x 16 KiB + V 2 x 16 KiB, as in the 8-wave kernel.  Measured alternative that did not pay
@@ -516,15 +518,39 @@ __device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret
 // 1.66 GHz, profiles/r02/attn_w4_pmc.json); what is left is energy per tile, not issue slots.
 constexpr int kLdsBytesW4 = 2 * kKTileBytes + 2 * kVTileBytes;
 
-template <int VARIANT>
+// MAXFREE = true: the max-free form described above (softmax reference 0, checked at the end, flagged workgroups redone by
+// the MODE 2 launch).  MAXFREE = false: the SAME loop with a LAZY softmax reference, which needs no second launch and has no
+// input-dependent cliff:
+//   * the reference m of a query row starts as the exact row max of tile 0 and rides in the MFMA accumulator (every S chain
+//     starts from a 16-register splat of -m, as in the 8-wave PRE form), so p = exp2(S') costs no extra VALU;
+//   * softmax does not care WHICH reference is used as long as nothing overflows or vanishes, and bf16 P / fp32 sums have
+//     ~2^127 of head-room: instead of a row max per tile (32 v_max3 + a lane exchange + a branch), the loop tests the row
+//     SUMS it computes anyway -- one v_max + one v_cmp per tile at MIDCHECK, where all four P fragments of the tile exist
+//     and none has been consumed.  While every lane's tile sum stays <= 2^40 nothing happens (m <= true max always holds, so
+//     no term that matters can vanish);
+//   * a sum above 2^40 (or Inf/NaN: a score more than 127 above m) takes the wave-uniform repair path: exact row max of the
+//     tile, O / l / the already accumulated next-tile scores rescaled to the new reference, the tile's P recomputed.  Every
+//     repair raises m by > 2^34, so even adversarial inputs repair a handful of times per row, not per tile.
+// SPLIT: the split-KV tail round (un-normalised O, m, l to the caller's scratch; see plan_tail).
+// Plain (not pre-scaled) q: the Q fragments are multiplied by softmax_scale * log2(e) once in the prologue, in fp32, and
+// rounded back to bf16 -- one extra bf16 rounding of q (2^-9 relative), stated in include/wan_hip.h.
+constexpr float kW4Trigger = 0x1p40f;
+
+// REF: 0 = max-free, 1 = lazy reference riding in the accumulator (-m splats, 32 VGPRs, no extra VALU),
+//      2 = lazy reference subtracted from the scores two at a time (v_pk_add_f32: 4 VGPRs, +32 VALU per tile).
+template <int VARIANT, bool SPLIT, int REF>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {
+    constexpr bool MAXFREE = REF == 0, SPLAT = REF == 1, PKSUB = REF == 2;
+    static_assert(!(SPLIT && MAXFREE), "the split tail round runs the lazy-reference form");
     const int wg_linear = blockIdx.x;
-    int* const hdr = a.flags - 4;
-    if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;
-    if (hdr[0] != 0) {                                       // sticky "fast path off": hand everything to the fix-up launch
-        if (threadIdx.x == 0) a.flags[wg_linear] = 1;
-        return;
+    if constexpr (MAXFREE) {
+        int* const hdr = a.flags - 4;
+        if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;
+        if (hdr[0] != 0) {                                       // sticky "fast path off": hand everything to the fix-up launch
+            if (threadIdx.x == 0) a.flags[wg_linear] = 1;
+            return;
+        }
     }
     int qblk, bh;
     if (a.xcd_map) {
@@ -535,17 +561,21 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         bh = wg_linear / a.nqb;
         qblk = wg_linear - bh * a.nqb;
     }
-    const int batch = bh / a.H, head = bh - batch * a.H;
+    const int bz = bh / a.H, head = bh - bz * a.H;
+    const int batch = SPLIT ? bz / a.nsplit : bz;
+    const int split = SPLIT ? bz - batch * a.nsplit : 0;
+    const int t0 = split * a.tiles_per_split;                     // first KV tile of this split
+    if constexpr (SPLIT) qblk += a.qblk0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int Lk = a.Lk;
+    const int Lk = SPLIT ? min(a.Lk - t0 * kKV, a.tiles_per_split * kKV) : a.Lk;
     const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
-    const bf16_t* K = a.k + batch * a.k_bs + head * kD;
-    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt;
+    const bf16_t* K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
+    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt + t0 * kKV;
     bf16_t* O = a.o + batch * a.o_bs + head * kD;
 
     // ---- Q fragments of the wave's two query blocks (B operands of S^T = K.Q^T), kept in AGPRs by the "a" constraints
@@ -557,6 +587,16 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         const bf16_t* qp = Q + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+    }
+    if (!PKSUB && a.scale_log2e != 1.0f) {           // plain q (kernel-argument uniform): fold softmax_scale * log2(e) into the fragments
+        const float c = a.scale_log2e;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    qf[qb][ks][w] = pack_bf16x2(bf16lo_to_f32(qf[qb][ks][w]) * c, bf16hi_to_f32(qf[qb][ks][w]) * c);
     }
 
     char* const kring = smem;
@@ -596,13 +636,15 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 
     const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     const int k_rowoff = pi * 256, k_sw = pi & 15;
-    int k_off[8];
+    // absolute LDS byte addresses (ds_read operands of both the C++ reads and the inline-asm reads below)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned k_adr[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) k_off[ks] = k_rowoff + (((2 * ks + hi) ^ k_sw) << 4);
+    for (int ks = 0; ks < 8; ++ks) k_adr[ks] = lds_base + k_rowoff + (((2 * ks + hi) ^ k_sw) << 4);
     const int v_rowoff = l31 * 128, v_sw = (l31 >> 1) & 7;
-    int v_off[4];
+    unsigned v_adr[4];          // carries the V ring base
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v_off[t] = 2 * kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
+    for (int t = 0; t < 4; ++t) v_adr[t] = lds_base + 2 * kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
 
     f32x16 o[2][4];
 #pragma unroll
@@ -630,13 +672,21 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 // "=&v": an 8-pass MFMA reads A/B over several passes, so D must not share registers with them (hipcc marks its own
 // MFMAs early-clobber for the same reason)
 #define W4_MFMA0(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(D) : "v"(A), "a"(B))
+// one accumulator register *= a VGPR factor, through one scratch VGPR (the repair path of the lazy reference): written as
+// asm because hipcc's own AGPR <-> VGPR traffic for `o *= alpha` at a point where ~225 VGPRs are live ends in spills
+#define W4_SCALE_ACC(ACC, F) do { float t_; asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_mul_f32 %0, %0, %2\n\tv_accvgpr_write_b32 %1, %0" : "=&v"(t_), "+a"(ACC) : "v"(F)); } while (0)
+// W4A_*: the A operand (K / V^T fragment) in an AGPR, the lazy-reference form's steady state
+#define W4A_MFMA_C(D, A, B, C) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C))
+#define W4A_MFMA0(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(D) : "a"(A), "a"(B))
+#define W4A_MFMA_S(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B))
+#define W4A_MFMA_O(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "a"(A), "v"(B))
 #define W4_MFMA_S(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "a"(B))
 #define W4_MFMA_O(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B))
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            const u32x4 kf0 = lds_read16(kring + kt * 32 * 256 + k_off[ks]);
+            const u32x4 kf0 = lds_read16_at(k_adr[ks] + kt * 32 * 256);
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 if (ks == 0) W4_MFMA0(s0[qb][kt], kf0, qf[qb][0]);
@@ -645,6 +695,40 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         }
     __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // S(0) is read by VALU code below: cover the MFMA -> VALU wait states
+
+    // ---- lazy reference (see the kernel header): -m of each query block as a 16-register splat = the C operand that starts
+    // every S chain.  It starts as the exact row max of tile 0 (of its valid keys when tile 0 is also the last tile).
+    f32x16 negm[2];             // SPLAT only
+    float nm[2] = {0.f, 0.f};   // -m of the wave's two query blocks (log2 units)
+    f32x2 nmp[2];               // PKSUB: (-m, -m), the v_pk_add_f32 operand
+    if constexpr (!MAXFREE) {
+        if (nkv == 1 && Lk < kKV) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7) >= Lk) s0[qb][kt][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float mx = max_with_lane_xor32(rowmax32(s0[qb]));
+            nm[qb] = PKSUB ? -mx * a.scale_log2e : -mx;        // softmax_scale > 0 (checked by the launcher): max commutes with the scale
+            nmp[qb] = f32x2{nm[qb], nm[qb]};
+            if constexpr (SPLAT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[qb][r] = -mx;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s0[qb][kt][r] -= mx;
+            }
+        }
+    }
+    // a score as the exponent sees it: SPLAT scores are already relative to m (it rode in the accumulator)
+    auto rel = [&](float x, int qb) -> float { return PKSUB ? __builtin_fmaf(x, a.scale_log2e, nm[qb]) : x; };
+    const f32x2 cpk = {a.scale_log2e, a.scale_log2e};
 
     // ---- softmax bookkeeping.  The 160 micro-ops of a tile run as one continuous stream of 2.5 per MFMA slot that starts in
     // the PV segment of the PREVIOUS interval (P fragments tt = 0, 1 -> `pn`, their row sums -> `carry`) and ends in the S
@@ -658,43 +742,113 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         for (int tt = 0; tt < 2; ++tt) {
             float p[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(s0[qb][0][8 * tt + j]); carry[qb] += p[j]; }
+            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(rel(s0[qb][0][8 * tt + j], qb)); carry[qb] += p[j]; }
             u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
             pa[qb][tt] = w;
         }
 
-    // ---- one interval: tile t lives in `sc` (its P fragments 0, 1 in `pc`); S(t+1) is produced into `sn` and its P
-    // fragments 0, 1 into `pn`; K(t+2) and V(t+1) are staged.  kslot_next = (t + 1) & 1 and vslot = t & 1 are literals at
-    // every call site, so every ds_read address is a loop-invariant VGPR + an immediate.
-    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], u32x4 (&pn)[2][2], int kslot_next, int vslot,
+    // ---- the repair path of the lazy reference (wave-uniform, rare): called at MIDCHECK of the interval of tile t when a
+    // row sum of that tile left the window.  `sc` = S(t) (both key halves intact), `sn` = S(t+1) (complete, accumulated on the
+    // OLD reference), `pc` / pf23 = the four P fragments of tile t, not yet consumed.
+    auto repair = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], float& ps0, float& ps1) __attribute__((always_inline)) {
+        // straight-line and cut into small steps by sched_barriers: at this point ~225 VGPRs are live, and a scheduler that
+        // overlaps the steps for latency (as it would by default) spills
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // sn's accumulate chains ended in the last MFMA slots
+        if (a.flags != nullptr && lane == 0) atomicAdd(a.flags - 2, 1);       // scratch header word [2]: repair events (statistics)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float delta = fmaxf(rel(max_with_lane_xor32(rowmax32(sc[qb])), qb), 0.f);       // >= 0: the reference only rises
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l_run[qb] *= alpha;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) W4_SCALE_ACC(o[qb][dt][r], alpha);
+            __builtin_amdgcn_sched_barrier(0);
+            nm[qb] -= delta;
+            const float sh = PKSUB ? nm[qb] : -delta;               // what the exponent adds to a (scaled) score of `sc` from now on
+            nmp[qb] = f32x2{nm[qb], nm[qb]};
+            if constexpr (SPLAT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[qb][r] = nm[qb];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sn[qb][kt][r] -= delta;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(PKSUB ? __builtin_fmaf(sc[qb][tt >> 1][8 * (tt & 1) + j], a.scale_log2e, sh) : sc[qb][tt >> 1][8 * (tt & 1) + j] + sh); psum += p[j]; }
+                const u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+                if (tt < 2) pc[qb][tt] = w; else pf23[qb][tt - 2] = w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (qb == 0) ps0 = psum; else ps1 = psum;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7" ::: "memory");                  // VALU-written P fragments / O -> MFMA operands
+    };
+
+    // MAXFREE = false: the K / V^T fragments are read by inline-asm ds_read_b128 straight into AGPRs (they are MFMA A operands
+    // only), which frees the 32 VGPRs the two -m splats need; hipcc does not track asm LDS reads, so the generated schedule
+    // carries the s_waitcnt lgkmcnt count of every first use (LDS reads return in order).
+    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], u32x4 (&pn)[2][2], auto kslot_c, auto vslot_c,
                         int t) __attribute__((always_inline)) {
-        const char* kb = kring + kslot_next * kKTileBytes;
-        const char* vb = smem + vslot * kVTileBytes;          // + v_off (which carries the V ring base)
+        constexpr int kslot_next = decltype(kslot_c)::value, vslot = decltype(vslot_c)::value;
         u32x4 kfr[4], vfr[4];
         const __amdgpu_buffer_rsrc_t rk = k_rsrc(t + 2), rv = v_rsrc(t + 1);
         float e[64];
+        f32x2 dd[32];                                         // PKSUB: shifted score pairs
         float ps0 = carry[0], ps1 = carry[1];                // this tile's row sums so far (first key half)
         float cn0 = 0.f, cn1 = 0.f;                           // the next tile's
 #define SB() __builtin_amdgcn_sched_barrier(0)
-#define RDK(f) kfr[(f) & 3] = lds_read16(kb + ((f) & 1) * 32 * 256 + k_off[(f) >> 1])
-#define RDV(f) vfr[(f) & 3] = lds_read16(vb + ((f) & 3) * 32 * 128 + v_off[(f) >> 2])
+#define W4_DSREAD_A(D, ADR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(D) : "v"(ADR), "i"(OFF))
+#define W4_LGKM(w) do { if constexpr ((w) >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"((w) < 0 ? 0 : (w))); } while (0)
+#define RDK(f) do { if constexpr (MAXFREE) kfr[(f) & 3] = lds_read16_at(k_adr[(f) >> 1] + kslot_next * kKTileBytes + ((f) & 1) * 32 * 256); \
+                    else W4_DSREAD_A(kfr[(f) & 3], k_adr[(f) >> 1], kslot_next * kKTileBytes + ((f) & 1) * 32 * 256); } while (0)
+#define RDV(f) do { if constexpr (MAXFREE) vfr[(f) & 3] = lds_read16_at(v_adr[(f) >> 2] + vslot * kVTileBytes + ((f) & 3) * 32 * 128); \
+                    else W4_DSREAD_A(vfr[(f) & 3], v_adr[(f) >> 2], vslot * kVTileBytes + ((f) & 3) * 32 * 128); } while (0)
 // the MFMA is pinned at the head of its slot (a sched_barrier on both sides): left free, hipcc sinks the fillers of every
 // other slot above their MFMA, which pairs the MFMAs up (gap 0) and doubles the fillers of the next gap (8-10 > the ~5 that hide)
-#define QK(qb, kt, ks, f) do { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); SB(); } while (0)
-#define PV(qb, dt, tt, f) do { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); SB(); } while (0)
+#define QK(qb, kt, ks, f, w) do { if constexpr (MAXFREE) { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } \
+                                  else { W4_LGKM(w); if ((ks) == 0) { if constexpr (SPLAT) W4A_MFMA_C(sn[qb][kt], kfr[(f) & 3], qf[qb][0], negm[qb]); else W4A_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); } \
+                                         else W4A_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } SB(); } while (0)
+#define MIDCHECK() do { if constexpr (!MAXFREE) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } while (0)
+#define PV(qb, dt, tt, f, w) do { if constexpr (MAXFREE) { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } \
+                                  else { W4_LGKM(w); if ((tt) < 2) W4A_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4A_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } SB(); } while (0)
 #define G(j) do { if ((j) < 4) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 4); } while (0)
 // score i = 32 qb + 8 tt + j: tt >= 2 reads the current tile (key half kt = 1), tt < 2 the next tile (kt = 0)
-#define E(i) e[i] = __builtin_amdgcn_exp2f((((i) >> 4) & 1) ? sc[(i) >> 5][1][(i) & 15] : sn[(i) >> 5][0][(i) & 15])
+#define SRC(i) ((((i) >> 4) & 1) ? sc[(i) >> 5][1][(i) & 15] : sn[(i) >> 5][0][(i) & 15])
+// PKSUB: scores leave the accumulator raw; D(p) turns the pair (2p, 2p + 1) into exponent arguments s * c - m with one v_pk_fma_f32
+// (c = softmax_scale * log2(e) for plain q, exactly 1 for pre-scaled q), scheduled >= 1 op ahead of the first exp that reads it
+#define D(p) do { const f32x2 s2_ = {SRC(2 * (p)), SRC(2 * (p) + 1)}; dd[p] = __builtin_elementwise_fma(s2_, cpk, nmp[(p) >> 4]); } while (0)
+#define E(i) do { if constexpr (PKSUB) e[i] = __builtin_amdgcn_exp2f(dd[(i) >> 1][(i) & 1]); else e[i] = __builtin_amdgcn_exp2f(SRC(i)); } while (0)
 #define A(i) do { if (((i) >> 4) & 1) { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } else { if ((i) < 32) cn0 += e[i]; else cn1 += e[i]; } } while (0)
 #define C(w) do { const unsigned pk_ = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1]); \
                   if (((w) >> 3) & 1) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; else pn[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; } while (0)
+        if constexpr (PKSUB) {
+#include "attn_w4_sched_pk.inc"
+        } else {
 #include "attn_w4_sched.inc"
+        }
 #undef RDK
 #undef RDV
 #undef QK
+#undef MIDCHECK
+#undef W4_DSREAD_A
+#undef W4_LGKM
 #undef PV
 #undef G
 #undef E
+#undef D
+#undef SRC
 #undef A
 #undef C
         l_run[0] += ps0;
@@ -707,13 +861,13 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     int it = 0;
     bool last_in_s1 = false;
     for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
-        interval(s0, s1, pa, pb, 1, 0, it);
+        interval(s0, s1, pa, pb, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, it);
         fence();
-        interval(s1, s0, pb, pa, 0, 1, it + 1);
+        interval(s1, s0, pb, pa, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, it + 1);
         fence();
     }
     if (it < nfull) {
-        interval(s0, s1, pa, pb, 1, 0, it);
+        interval(s0, s1, pa, pb, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, it);
         fence();
         ++it;
         last_in_s1 = true;
@@ -723,7 +877,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     {
         u32x4 pf[2][4];
         const int kv0 = it * kKV;
-        const char* vb = smem + (it & 1) * kVTileBytes;
+        const unsigned vb = (it & 1) * kVTileBytes;
         if (last_in_s1) {                                  // value copies (a select of array lvalues would pin both in memory)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
@@ -733,19 +887,39 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float psum = 0.f;
+            f32x16 sl[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x16 sl = s0[qb][kt];
+                sl[kt] = s0[qb][kt];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= Lk) sl[r] = -INFINITY;
+                    if (key >= Lk) sl[kt][r] = -INFINITY;
                 }
+            }
+            float delta = 0.f;
+            if constexpr (!MAXFREE) {
+                // the last tile takes the classical step: exact row max of its valid keys, rescale if it exceeds the reference
+                delta = fmaxf(rel(max_with_lane_xor32(rowmax32(sl)), qb), 0.f);
+                if (!__all(delta <= 0.f)) {                   // wave-uniform
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) W4_SCALE_ACC(o[qb][dt][r], alpha);
+                }
+                nm[qb] -= delta;
+                delta = PKSUB ? -nm[qb] : delta;              // PKSUB scores are raw: scale, then subtract the whole (new) reference
+            }
+            const float cl = PKSUB ? a.scale_log2e : 1.0f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
                     float p[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(sl[8 * t2 + j]); psum += p[j]; }
+                    for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sl[kt][8 * t2 + j], cl, -delta)); psum += p[j]; }
                     u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
                     pf[qb][2 * kt + t2] = w;
                 }
@@ -753,12 +927,12 @@ void attn_fwd_w4_kernel(AttnArgs a) {
             l_run[qb] += psum;
         }
         SB();
-        asm volatile("s_nop 1" ::: "memory");             // VALU-written P fragments -> MFMA B operand
+        asm volatile("s_nop 7" ::: "memory");             // VALU-written P fragments (and a rescaled O) -> MFMA operands
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const u32x4 vf0 = lds_read16(vb + dt * 32 * 128 + v_off[tt]);
+                const u32x4 vf0 = lds_read16_at(v_adr[tt] + vb + dt * 32 * 128);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) W4_MFMA_O(o[qb][dt], vf0, pf[qb][tt]);
             }
@@ -766,31 +940,59 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     }
 #undef SB
 #undef W4_MFMA0
+#undef W4A_MFMA_C
+#undef W4_SCALE_ACC
+#undef W4A_MFMA_S
+#undef W4A_MFMA0
+#undef W4A_MFMA_O
 #undef W4_MFMA_S
 #undef W4_MFMA_O
 
-    bool ok = true;
-    float inv[2];
+    if constexpr (SPLIT) {
+        // partial result of this KV range: un-normalised O, its reference (log2 units) and its sum
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-        ok = ok && ((l_tot >= 0x1p-90f && l_tot <= 0x1p100f) || qrow[qb] >= a.Lq);     // NaN fails both comparisons
-        inv[qb] = 1.0f / l_tot;
-    }
-    const int bad = __syncthreads_or(!ok);
-    if (tid == 0) a.flags[wg_linear] = bad;
+        for (int qb = 0; qb < 2; ++qb) {
+            const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+            if (qrow[qb] >= a.Lq) continue;
+            const int64_t r = ((int64_t)(batch * a.nsplit + split) * a.H + head) * a.rows_tail + (qrow[qb] - a.row0);
+            float* wo = a.ws_o + r * kD + 4 * hi;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        if (qrow[qb] >= a.Lq) continue;
-        bf16_t* op = O + (int64_t)qrow[qb] * a.ldo + 4 * hi;
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w = {pack_bf16x2(o[qb][dt][4 * g + 0] * inv[qb], o[qb][dt][4 * g + 1] * inv[qb]),
-                           pack_bf16x2(o[qb][dt][4 * g + 2] * inv[qb], o[qb][dt][4 * g + 3] * inv[qb])};
-                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wo + 32 * dt + 8 * g) =
+                        make_float4(o[qb][dt][4 * g + 0], o[qb][dt][4 * g + 1], o[qb][dt][4 * g + 2], o[qb][dt][4 * g + 3]);
+            if (hi == 0) {
+                a.ws_ml[2 * r] = -nm[qb];
+                a.ws_ml[2 * r + 1] = l_tot;
             }
+        }
+    } else {
+        bool ok = true;
+        float inv[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+            ok = ok && ((l_tot >= 0x1p-90f && l_tot <= 0x1p100f) || qrow[qb] >= a.Lq);     // NaN fails both comparisons
+            inv[qb] = 1.0f / l_tot;
+        }
+        if constexpr (MAXFREE) {
+            const int bad = __syncthreads_or(!ok);
+            if (tid == 0) a.flags[wg_linear] = bad;
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (qrow[qb] >= a.Lq) continue;
+            bf16_t* op = O + (int64_t)qrow[qb] * a.ldo + 4 * hi;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w = {pack_bf16x2(o[qb][dt][4 * g + 0] * inv[qb], o[qb][dt][4 * g + 1] * inv[qb]),
+                               pack_bf16x2(o[qb][dt][4 * g + 2] * inv[qb], o[qb][dt][4 * g + 3] * inv[qb])};
+                    *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+                }
+        }
     }
 }
 
@@ -951,7 +1153,11 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 1>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 1>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 2>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 2>),
-                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1>)};
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 0>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 0>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 1>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 2>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 2>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 2>)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
             if (e != hipSuccess) {
@@ -969,6 +1175,8 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     a.o = (bf16_t*)out; a.ldo = ldo; a.o_bs = o_bstride;
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
     const bool pre = (flags & WAN_ATTN_Q_PRESCALED) != 0;
+    WAN_REQUIRE(pre || (softmax_scale > 0.f && softmax_scale < 1e30f), WAN_ERR_INVALID,
+                "wan_attention_fwd: softmax_scale=%g must be positive and finite", (double)softmax_scale);
     a.scale_log2e = pre ? 1.0f : softmax_scale * 1.4426950408889634f;
     a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr; a.flags = nullptr;
     const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
@@ -1004,37 +1212,58 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     const int64_t nwg = (int64_t)a.nqb * a.nbh;
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     dim3 grid((unsigned)nwg);
-    if (pre && fast && wan_tune(WAN_TUNE_ATTN_W4) != 0) {
-        if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0>), grid, dim3(kW4Threads), kLdsBytesW4, st, a);
-        else hipLaunchKernelGGL((attn_fwd_w4_kernel<1>), grid, dim3(kW4Threads), kLdsBytesW4, st, a);
-    } else if (pre && fast) {
+    const bool w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0, ref2 = wan_tune(WAN_TUNE_ATTN_REF) == 2;
+    const dim3 block4(kW4Threads);
+    int variant;
+    if (w4 && !fast) {               // the product path: lazy-reference 4-wave kernel, one launch, any q form, scratch or not
+        variant = WAN_ATTN_VARIANT_W4_LAZY;
+        if (ref2) {
+            if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 2>), grid, block4, kLdsBytesW4, st, a);
+            else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 2>), grid, block4, kLdsBytesW4, st, a);
+        } else {
+            if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1>), grid, block4, kLdsBytesW4, st, a);
+            else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1>), grid, block4, kLdsBytesW4, st, a);
+        }
+    } else if (w4) {                 // A/B: max-free 4-wave attempt + checked fix-up (round 2's path)
+        variant = WAN_ATTN_VARIANT_W4_MAXFREE;
+        if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 0>), grid, block4, kLdsBytesW4, st, a);
+        else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 0>), grid, block4, kLdsBytesW4, st, a);
+    } else if (fast) {
+        variant = WAN_ATTN_VARIANT_W8_MAXFREE;
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 1>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 1>), grid, block, kLdsBytesV2, st, a);
     } else if (pre) {
+        variant = WAN_ATTN_VARIANT_W8_RUNNING_MAX;
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
     } else {
+        variant = WAN_ATTN_VARIANT_W8_RUNNING_MAX;
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
     }
-    if (pre && fast) {       // same grid, right behind: workgroups whose rows left the checked score window are redone
+    if (fast) {              // same grid, right behind: workgroups whose rows left the checked score window are redone
         WAN_CHECK_LAUNCH("wan_attention_fwd");
         if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 2>), grid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 2>), grid, block, kLdsBytesV2, st, a);
     }
+    if (a.xcd_map) variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (tp.tq > 0) {
         WAN_CHECK_LAUNCH("wan_attention_fwd");
+        variant |= WAN_ATTN_VARIANT_SPLIT_TAIL;
         a.qblk0 = tp.main_qb; a.nsplit = tp.nsplit; a.tiles_per_split = tp.tiles_per_split;
         a.row0 = tp.main_qb * kQPerWG; a.rows_tail = tp.rows_tail;
         a.ws_o = (float*)ws_tail;
         a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
         a.nqb = tp.tq; a.nbh = num_heads * batch * tp.nsplit; a.xcd_map = 0;
         dim3 tgrid((unsigned)((int64_t)a.nqb * a.nbh));
-        if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
+        if (w4 && ref2) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 2>), tgrid, block4, kLdsBytesW4, st, a);
+        else if (w4) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 1>), tgrid, block4, kLdsBytesW4, st, a);
+        else if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
         WAN_CHECK_LAUNCH("wan_attention_fwd (tail)");
         hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)tp.rows_tail, (unsigned)num_heads, (unsigned)batch), dim3(kD), 0, st, a);
     }
+    wan_note_attn_variant(variant);
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;
 }

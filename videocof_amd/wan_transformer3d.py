@@ -116,6 +116,11 @@ class WanTransformer3DModel(nn.Module):
         self.sp_world_size = 1
         self.sp_world_rank = 0
         self._sp = None
+        # Take the Ulysses branch even when the group has ONE rank (tests: the async RCCL exchanges, their waits and the
+        # persistent wire buffers become live code on a single GPU; results equal the plain path).  Off in production.
+        self.force_ulysses = False
+        self._usp = False                   # this forward runs the Ulysses branch (set by forward)
+        self._comm_events = None            # bench.py: list collecting (start, end) HIP events around the EXPOSED exchanges
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
         self._ctx_cache = None
         self._fp8 = ()                      # enable_fp8_linear: which projections run in e4m3 (lossy, opt-in)
@@ -139,6 +144,7 @@ class WanTransformer3DModel(nn.Module):
         self._probe = None
         self._attn_events = None            # bench.py: list collecting (start, end) HIP events per self-attn launch
         self._last_attn_rows = 0
+        self._last_attn_variant = 0
 
     # ------------------------------------------------------------------ properties
     @property
@@ -456,6 +462,19 @@ class WanTransformer3DModel(nn.Module):
             ev[1].record()
             self._attn_events.append(ev)
             self._last_attn_rows = rows
+            self._last_attn_variant = ops.get_tuning("last_attn_variant")      # what the dispatcher launched for THIS call
+
+    def _comm_pair(self):
+        if self._comm_events is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        return a, b
+
+    def _comm_done(self, ev):
+        if ev is not None:
+            ev[1].record()
+            self._comm_events.append(ev)
 
     def _rope_map(self, grid, frame_split_indices, ground_frame_indices, token_offset, rows):
         """The temporal position map of rope_apply_qk (:160-179) as kernel parameters."""
@@ -476,7 +495,7 @@ class WanTransformer3DModel(nn.Module):
     def _workspaces(self, B, Ll, L, seq_len):
         """Per-forward activation buffers (module docstring).  Kept across calls of one shape: the caching allocator
         would hand the same blocks back anyway, and fixed addresses are what a captured hipGraph replays."""
-        key = (B, Ll, L, seq_len, self.sp_world_size, str(self._device))
+        key = (B, Ll, L, seq_len, self.sp_world_size, self._usp, str(self._device))
         if self._bufs is not None and self._bufs[0] == key:
             return self._bufs[1]
         C, dev, M = self.dim, self._device, B * Ll
@@ -487,7 +506,7 @@ class WanTransformer3DModel(nn.Module):
         b.cq = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
         b.ff = torch.empty(M, self.ffn_dim, device=dev, dtype=torch.bfloat16)
         P = self.sp_world_size
-        if P == 1:
+        if not self._usp:
             # V^T pad columns [L, roundup(L, 64)) are never written and must stay finite: zero them once
             b.vt = torch.zeros(B, C, ops.round_up(L, 64), device=dev, dtype=torch.bfloat16)
         else:
@@ -517,8 +536,9 @@ class WanTransformer3DModel(nn.Module):
         em: [6, B, C] = modulation + e0 (:495); ctx_kv: (k [B,512,C], v^T [B,C,512]) of the text tokens."""
         C, H, P, M = self.dim, self.num_heads, self.sp_world_size, B * Ll
         h, qk, att, cq, ff, vt, qk3 = bufs.h, bufs.qk, bufs.att, bufs.cq, bufs.ff, bufs.vt, bufs.qk3
-        f8 = blk.f8 if (blk.f8 and P == 1) else {}
-        if P == 1 and not f8 and self._attn_events is None and self.use_block_composite:
+        usp = self._usp
+        f8 = blk.f8 if (blk.f8 and not usp) else {}
+        if not usp and not f8 and self._attn_events is None and self.use_block_composite:
             # the same launch sequence as below, enqueued by ONE C call (wan_dit_block_forward): 1 FFI crossing instead of 15
             self._block_composite(blk, em, xs, bufs, ctx_kv, rp, B, Ll, L)
             return
@@ -527,18 +547,18 @@ class WanTransformer3DModel(nn.Module):
             ops.ln_modulate_fp8(xs, em[1], em[0], True, Ll, self.eps, out=bufs.hq, out_scale=bufs.rs)
         else:
             ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
-        if P == 1 and "qk" in f8:
+        if not usp and "qk" in f8:
             ops.gemm_fp8(bufs.hq, bufs.rs, *f8["qk"], blk.b_qk, ops.EPI_BF16, out=qk)
             ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
             for b in range(B):
                 ops.gemm_fp8(bufs.hq[b * Ll:(b + 1) * Ll][:L], bufs.rs[b * Ll:(b + 1) * Ll][:L], *f8["v"], blk.b_v,
                              ops.EPI_BF16_T, out=vt[b])
-        elif P == 1:
+        elif not usp:
             ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
             ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
             for b in range(B):
                 ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
-        if P == 1:
+        if not usp:
             ev = self._event_pair()
             ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True,
                               workspace=self._ws_self)
@@ -563,16 +583,20 @@ class WanTransformer3DModel(nn.Module):
             ops.rmsnorm_rope_sp(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, bufs.qw_s, None, P, B,
                                 x0_scale=self._qs)
             wait_q = sp.exchange(bufs.qw_r, bufs.qw_s, async_op=True)
+            cev = self._comm_pair()             # exposed: whatever of the three exchanges the projections did not cover
             wait_k()
             wait_v()
             ops.sp_unpack_vt(bufs.vw_r, bufs.vt_full, P, Ll)
             wait_q()
+            self._comm_done(cev)
             as_bld = lambda w: w.view(Lt, B, Cl).permute(1, 0, 2)          # [B, P*Ll, Cl] view: row stride B*Cl, sample stride Cl
             ev = self._event_pair()
             ops.attention_fwd(as_bld(bufs.qw_r), as_bld(bufs.kw_r), bufs.vt_full, H // P, k_len=L, out=as_bld(bufs.ow_s),
                               q_prescaled=True, workspace=self._ws_self)
             self._event_done(ev, B * seq_len)
+            cev = self._comm_pair()             # exposed: the inverse exchange sits between attention and the o projection
             sp.exchange(bufs.ow_r, bufs.ow_s)
+            self._comm_done(cev)
             ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B)
             o_in = att
         ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
@@ -684,8 +708,9 @@ class WanTransformer3DModel(nn.Module):
         x fp32 [B, L, C]; e fp32 [B, 6, C] (the time projection; the block adds its own ``modulation``, :494);
         context [B, text_len, C] (already through ``text_embedding``); grid_sizes (F, Hp, Wp) with F*Hp*Wp <= L.
         Returns the new residual stream, fp32 [B, L, C].  Single device only."""
-        if self.sp_world_size != 1:
+        if self.sp_world_size != 1 or self.force_ulysses:
             raise NotImplementedError("block_forward is the single-device composite")
+        self._usp = False
         B, Ll, C = x.shape
         grid = tuple(int(v) for v in grid_sizes)
         L = grid[0] * grid[1] * grid[2]
@@ -728,7 +753,8 @@ class WanTransformer3DModel(nn.Module):
         if t.numel() != B or len(context) != B:
             raise ValueError(f"batch mismatch: x has {B} samples, t {t.numel()}, context {len(context)}")
         P, rank = self.sp_world_size, self.sp_world_rank
-        if P > 1:
+        usp = self._usp = self._sp is not None and (P > 1 or self.force_ulysses)
+        if usp:
             # :904-905 pads to a multiple of P; we pad to 8*P so every shard keeps 16-byte aligned rows
             seq_len = int(math.ceil(seq_len / (8 * P))) * 8 * P
         assert L <= seq_len, f"sequence of {L} tokens exceeds seq_len={seq_len}"         # :906
@@ -749,9 +775,9 @@ class WanTransformer3DModel(nn.Module):
             ctx_kv = [None] * self.num_layers
 
         r0 = 0          # rows whose output is needed after the last block start here (non-zero only with skip_source_frames)
-        if self.skip_source_frames and B == 1 and P == 1:
+        if self.skip_source_frames and B == 1 and not usp:
             r0 = min(int(self.skip_source_frames), grid[0]) * grid[1] * grid[2]
-        if (P == 1 and self.use_block_composite and self.use_forward_composite and not self._fp8 and self.teacache is None
+        if (not usp and self.use_block_composite and self.use_forward_composite and not self._fp8 and self.teacache is None
                 and self._probe_layer is None and self._attn_events is None and r0 == 0
                 and dtype in (torch.float32, torch.bfloat16)):
             kvs = ctx_kv if ctx_kv[0] is not None else [self._context_kv(blk, ctx, B) for blk in self.blocks]
@@ -805,7 +831,7 @@ class WanTransformer3DModel(nn.Module):
         else:
             ops.ln_modulate(xs, ehead[1], ehead[0], True, Ll, self.eps, out=h)
             yt = ops.gemm(h, w["head_w"], w["head_b"], ops.EPI_F32).view(B, Ll, -1)
-        if P > 1:
+        if usp:
             yt = self._sp.all_gather_tokens(yt)                                        # :1085-1086
         out_dtype = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
         out = torch.empty(B, self.out_dim, grid[0] * pt, grid[1] * ph, grid[2] * pw, device=dev, dtype=out_dtype)
