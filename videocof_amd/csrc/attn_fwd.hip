@@ -532,8 +532,8 @@ constexpr int kLdsBytesW4 = 2 * kKTileBytes + 2 * kVTileBytes;
 //     tile, O / l / the already accumulated next-tile scores rescaled to the new reference, the tile's P recomputed.  Every
 //     repair raises m by > 2^34, so even adversarial inputs repair a handful of times per row, not per tile.
 // SPLIT: the split-KV tail round (un-normalised O, m, l to the caller's scratch; see plan_tail).
-// Plain (not pre-scaled) q: the Q fragments are multiplied by softmax_scale * log2(e) once in the prologue, in fp32, and
-// rounded back to bf16 -- one extra bf16 rounding of q (2^-9 relative), stated in include/wan_hip.h.
+// Plain (not pre-scaled) q runs REF = 2, whose packed fma applies softmax_scale * log2(e) to the fp32 scores exactly (folding it
+// into the bf16 Q fragments instead was measured: one more rounding of q moves scores of magnitude ~500 by ~1, rel-L2 1.6e-2).
 constexpr float kW4Trigger = 0x1p40f;
 
 // REF: 0 = max-free, 1 = lazy reference riding in the accumulator (-m splats, 32 VGPRs, no extra VALU),
@@ -588,17 +588,6 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
     }
-    if (!PKSUB && a.scale_log2e != 1.0f) {           // plain q (kernel-argument uniform): fold softmax_scale * log2(e) into the fragments
-        const float c = a.scale_log2e;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    qf[qb][ks][w] = pack_bf16x2(bf16lo_to_f32(qf[qb][ks][w]) * c, bf16hi_to_f32(qf[qb][ks][w]) * c);
-    }
-
     char* const kring = smem;
     // ---- staging: this wave copies pieces 4*wid .. 4*wid+3 (1 KiB each) of every K and V^T tile
     const int nkv = (Lk + kKV - 1) / kKV;
@@ -770,15 +759,14 @@ void attn_fwd_w4_kernel(AttnArgs a) {
             const float sh = PKSUB ? nm[qb] : -delta;               // what the exponent adds to a (scaled) score of `sc` from now on
             nmp[qb] = f32x2{nm[qb], nm[qb]};
             if constexpr (SPLAT) {
+                // in-place (asm "+v"): written as plain assignments these values get new registers on this path and the
+                // common path pays for it with 16-register copies at the join
 #pragma unroll
-                for (int r = 0; r < 16; ++r) negm[qb][r] = nm[qb];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 16; ++r) asm volatile("v_mov_b32 %0, %1" : "+v"(negm[qb][r]) : "v"(nm[qb]));
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sn[qb][kt][r] -= delta;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                    for (int r = 0; r < 16; ++r) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(sn[qb][kt][r]) : "v"(delta));
             }
             float psum = 0.f;
 #pragma unroll
@@ -802,7 +790,11 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], u32x4 (&pn)[2][2], auto kslot_c, auto vslot_c,
                         int t) __attribute__((always_inline)) {
         constexpr int kslot_next = decltype(kslot_c)::value, vslot = decltype(vslot_c)::value;
-        u32x4 kfr[4], vfr[4];
+        u32x4 kfr[4], vfr[4];          // MAXFREE (VGPRs, hipcc's own ds_reads)
+        // lazy forms: ONE 5-slot AGPR ring for both operand streams -- K fragment f in slot f & 3 (segment B), V^T fragment f
+        // in slot (f + 4) % 5 (segment C; its first four are requested in B28..B31, when K slots 0..2 and the spare slot 4 are
+        // free, and K fragments 0..3 of the next interval are requested behind the fence)
+        u32x4 fr[5];
         const __amdgpu_buffer_rsrc_t rk = k_rsrc(t + 2), rv = v_rsrc(t + 1);
         float e[64];
         f32x2 dd[32];                                         // PKSUB: shifted score pairs
@@ -812,17 +804,17 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define W4_DSREAD_A(D, ADR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(D) : "v"(ADR), "i"(OFF))
 #define W4_LGKM(w) do { if constexpr ((w) >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"((w) < 0 ? 0 : (w))); } while (0)
 #define RDK(f) do { if constexpr (MAXFREE) kfr[(f) & 3] = lds_read16_at(k_adr[(f) >> 1] + kslot_next * kKTileBytes + ((f) & 1) * 32 * 256); \
-                    else W4_DSREAD_A(kfr[(f) & 3], k_adr[(f) >> 1], kslot_next * kKTileBytes + ((f) & 1) * 32 * 256); } while (0)
+                    else W4_DSREAD_A(fr[(f) & 3], k_adr[(f) >> 1], kslot_next * kKTileBytes + ((f) & 1) * 32 * 256); } while (0)
 #define RDV(f) do { if constexpr (MAXFREE) vfr[(f) & 3] = lds_read16_at(v_adr[(f) >> 2] + vslot * kVTileBytes + ((f) & 3) * 32 * 128); \
-                    else W4_DSREAD_A(vfr[(f) & 3], v_adr[(f) >> 2], vslot * kVTileBytes + ((f) & 3) * 32 * 128); } while (0)
+                    else W4_DSREAD_A(fr[((f) + 4) % 5], v_adr[(f) >> 2], vslot * kVTileBytes + ((f) & 3) * 32 * 128); } while (0)
 // the MFMA is pinned at the head of its slot (a sched_barrier on both sides): left free, hipcc sinks the fillers of every
 // other slot above their MFMA, which pairs the MFMAs up (gap 0) and doubles the fillers of the next gap (8-10 > the ~5 that hide)
 #define QK(qb, kt, ks, f, w) do { if constexpr (MAXFREE) { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } \
-                                  else { W4_LGKM(w); if ((ks) == 0) { if constexpr (SPLAT) W4A_MFMA_C(sn[qb][kt], kfr[(f) & 3], qf[qb][0], negm[qb]); else W4A_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); } \
-                                         else W4A_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } SB(); } while (0)
+                                  else { W4_LGKM(w); if ((ks) == 0) { if constexpr (SPLAT) W4A_MFMA_C(sn[qb][kt], fr[(f) & 3], qf[qb][0], negm[qb]); else W4A_MFMA0(sn[qb][kt], fr[(f) & 3], qf[qb][0]); } \
+                                         else W4A_MFMA_S(sn[qb][kt], fr[(f) & 3], qf[qb][ks]); } SB(); } while (0)
 #define MIDCHECK() do { if constexpr (!MAXFREE) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } while (0)
 #define PV(qb, dt, tt, f, w) do { if constexpr (MAXFREE) { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } \
-                                  else { W4_LGKM(w); if ((tt) < 2) W4A_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4A_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } SB(); } while (0)
+                                  else { W4_LGKM(w); if ((tt) < 2) W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pc[qb][(tt) & 1]); else W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pf23[qb][(tt) & 1]); } SB(); } while (0)
 #define G(j) do { if ((j) < 4) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 4); } while (0)
 // score i = 32 qb + 8 tt + j: tt >= 2 reads the current tile (key half kt = 1), tt < 2 the next tile (kt = 0)
 #define SRC(i) ((((i) >> 4) & 1) ? sc[(i) >> 5][1][(i) & 15] : sn[(i) >> 5][0][(i) & 15])
@@ -832,7 +824,8 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define E(i) do { if constexpr (PKSUB) e[i] = __builtin_amdgcn_exp2f(dd[(i) >> 1][(i) & 1]); else e[i] = __builtin_amdgcn_exp2f(SRC(i)); } while (0)
 #define A(i) do { if (((i) >> 4) & 1) { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } else { if ((i) < 32) cn0 += e[i]; else cn1 += e[i]; } } while (0)
 #define C(w) do { const unsigned pk_ = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1]); \
-                  if (((w) >> 3) & 1) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; else pn[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; } while (0)
+                  if (((w) >> 3) & 1) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; \
+                  else pn[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; } while (0)
         if constexpr (PKSUB) {
 #include "attn_w4_sched_pk.inc"
         } else {
@@ -1212,7 +1205,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     const int64_t nwg = (int64_t)a.nqb * a.nbh;
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     dim3 grid((unsigned)nwg);
-    const bool w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0, ref2 = wan_tune(WAN_TUNE_ATTN_REF) == 2;
+    // plain q always takes the packed-shift form (it applies softmax_scale exactly, in the same fma); pre-scaled q the
+    // accumulator form unless the developer switch asks for the other
+    const bool w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0, ref2 = !pre || wan_tune(WAN_TUNE_ATTN_REF) == 2;
     const dim3 block4(kW4Threads);
     int variant;
     if (w4 && !fast) {               // the product path: lazy-reference 4-wave kernel, one launch, any q form, scratch or not
