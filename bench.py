@@ -291,6 +291,11 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="run the q|k, v, ffn.0 and ffn.2 projections in OCP e4m3 (WanTransformer3DModel.enable_fp8_linear): a "
                          "LOSSY option with its own error statement; the line says so in `dtype` and is never the headline")
+    ap.add_argument("--attn-stress", action="store_true",
+                    help="give the random model checkpoint-like q / k statistics (norm_q / norm_k gains log-normal up to 8, one "
+                         "large-bias channel per head: log2-domain scores of several hundred) -- the input class on which a "
+                         "max-free attention attempt fails its check; the line reports flagged workgroups, the sticky switch "
+                         "and the lazy-reference repair events.  Never the headline line.")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward + CoF mask from a hipGraph (videocof_amd.GraphedForward; text K/V hoisted out of "
                          "the step as WanPipeline does).  For launch-bound small shapes; never the headline line.")
@@ -328,7 +333,16 @@ def main():
     model = WanTransformer3DModel(dim=wl["dim"], ffn_dim=wl["ffn_dim"], num_heads=wl["num_heads"],
                                   num_layers=wl["num_layers"])
     shapes = dict(dim=wl["dim"], ffn_dim=wl["ffn_dim"], num_layers=wl["num_layers"])
-    model.load_state_dict(random_dit_state_dict(dev, seed=0, **shapes), device=dev)
+    sd = random_dit_state_dict(dev, seed=0, **shapes)
+    if args.attn_stress:
+        gs = torch.Generator(device=dev).manual_seed(123)
+        for name, t in sd.items():
+            if name.endswith(("self_attn.norm_q.weight", "self_attn.norm_k.weight")):
+                t.mul_(torch.exp(0.9 * torch.randn(t.shape, device=dev, generator=gs)).clamp(max=8.0))
+            elif name.endswith(("self_attn.q.bias", "self_attn.k.bias")):
+                t.view(-1, 128)[:, 5] = 12.0          # same sign for every token: q . k picks up a large common term
+    model.load_state_dict(sd, device=dev)
+    del sd
     if args.fp8:
         if sp:
             raise SystemExit("--fp8 covers the single-device forward")
@@ -430,10 +444,16 @@ def main():
         traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1)
         from videocof_amd import _lib
         vcode = int(model._last_attn_variant)
-        repairs = int(model._ws_self.buf[8:12].view(torch.int32).item()) if model._ws_self.buf is not None else None
+        hdr = model._ws_self.buf[:16].view(torch.int32).tolist() if model._ws_self.buf is not None else [None] * 4
+        repairs = hdr[2]
         roof = {"kernel": "self-attention wan_attention_fwd: " + _lib.attn_variant_name(vcode), "variant_code": vcode,
                 "kernel_reported_by": "wan_get_tuning('last_attn_variant') right after the launch",
+                "attn_flagged_wgs": hdr[1], "attn_flagged_wgs_of": (model._last_attn_rows + 255) // 256 * heads_local,
+                "attn_max_free_attempt_switched_off": None if hdr[0] is None else bool(hdr[0]),
                 "attn_repair_events": repairs, "heads_local": heads_local,
+                "attn_stats_note": "flagged = workgroups of the LAST self-attention call whose max-free attempt failed its check and "
+                                   "were redone by the lazy-reference launch; repair events = wave-level reference raises of the "
+                                   "lazy form over the whole timed region",
                 "bound": "mfma", "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
@@ -470,6 +490,7 @@ def main():
                     "(ii) the inverse (o) exchange; the k and V^T exchanges themselves run under the V and q projections"},
         "parity": parity,
         "graph": bool(args.graph),
+        "attn_stress": bool(args.attn_stress),
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -42,9 +42,9 @@ int wan_abi_version(void);
 const char* wan_last_error(void);
 
 /* Developer switches (A/B harnesses, bring-up).  The matching environment variables (WAN_ATTN_TAIL, WAN_ATTN_FAST,
- * WAN_ATTN_XCD_MAP, WAN_ATTN_W4, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
+ * WAN_ATTN_XCD_MAP, WAN_ATTN_W4, WAN_ATTN_REF, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
  * read ONCE, at the first call into the library; the launch paths never call getenv().  Keys: "attn_tail",
- * "attn_fast", "attn_xcd_map", "attn_w4", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
+ * "attn_fast", "attn_xcd_map", "attn_w4", "attn_ref", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
  * "debug_checks" = 1 turns on SYNCHRONISING contract checks (V^T pad columns of wan_attention_fwd are finite).
  * wan_set_tuning is an atomic store: safe against concurrent launches, which see the old or the new value.
  * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code).
@@ -53,10 +53,9 @@ const char* wan_last_error(void);
  * reports the kernel the dispatcher picked instead of a literal. */
 wan_status_t wan_set_tuning(const char* key, int value);
 int wan_get_tuning(const char* key);
-#define WAN_ATTN_VARIANT_W4_LAZY 1          /* attn_fwd_w4_kernel<.,.,false>: 4 waves, lazy softmax reference (the product path) */
-#define WAN_ATTN_VARIANT_W4_MAXFREE 2       /* attn_fwd_w4_kernel<.,false,true> + checked fix-up launch ("attn_fast" = 1) */
-#define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* attn_fwd_v2_kernel, 8 waves, running max per tile ("attn_w4" = 0) */
-#define WAN_ATTN_VARIANT_W8_MAXFREE 4       /* attn_fwd_v2_kernel<.,true,false,1> + fix-up ("attn_w4" = 0, "attn_fast" = 1) */
+#define WAN_ATTN_VARIANT_W4_LAZY 1          /* attn_fwd_w4_kernel<.,.,1|2>: 4 waves, lazy softmax reference, one launch */
+#define WAN_ATTN_VARIANT_W4_MAXFREE 2       /* attn_fwd_w4_kernel<.,false,0> + its checked fix-up launch attn_fwd_w4_kernel<.,false,1,true> */
+#define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* attn_fwd_v2_kernel, 8 waves, running max per tile ("attn_w4" = 0: developer A/B partner) */
 #define WAN_ATTN_VARIANT_FAMILY_MASK 15
 #define WAN_ATTN_VARIANT_XCD_PINNED 16      /* every (batch, head) pinned to one XCD */
 #define WAN_ATTN_VARIANT_SPLIT_TAIL 32      /* the last partial round ran split over the keys (+ merge kernel) */
@@ -167,8 +166,10 @@ wan_status_t wan_ln_modulate_fp8(const float* x, const float* scale, const float
  *     out bf16 [B][Lq][H*128]
  *     Keys >= Lk are masked (k_lens semantics of the flash-attn branch, attention_utils.py:95-100).
  *     flags: WAN_ATTN_Q_PRESCALED -- q already carries softmax_scale*log2(e) (written that way by
- *     wan_rmsnorm_rope's x0_scale); softmax_scale is then ignored and the kernel keeps the running
- *     max inside the MFMA accumulator (no per-score multiply-add; ~7 % faster).  0 = plain q.
+ *     wan_rmsnorm_rope's x0_scale); softmax_scale is then ignored and the softmax reference rides inside the MFMA
+ *     accumulator (no per-score multiply-add).  0 = plain q: softmax_scale (> 0) is applied to the fp32 scores exactly.
+ *     Numerics do not depend on the size of the scores: every form keeps a per-row softmax reference that is raised
+ *     (O and the running sum rescaled) whenever a tile's row sums leave the fp32 / bf16 window.
  * ------------------------------------------------------------------------- */
 wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                const void* k, int64_t ldk, int64_t k_bstride,
@@ -177,13 +178,16 @@ wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                int batch, int Lq, int Lk, int num_heads, int head_dim,
                                float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
                                void* stream);
-/* Optional scratch for wan_attention_fwd (16-byte aligned device memory whose first 16 bytes are ZERO when it is first
- * used -- they carry a sticky switch, see (a) -- and otherwise of irrelevant content; reusable across calls on one stream).  With at least this many bytes (a) pre-scaled q runs a max-free kernel (p = exp2(S) without a
- * running max; rows whose sum leaves a checked window flag their workgroup in the scratch and are recomputed by the
- * running-max kernel launched right behind -- same results, ~2 % faster; once more than 1/8 of a launch had to be
- * recomputed the switch in the scratch turns the attempt off for later calls), and (b) the last, partially filled round of
- * workgroups of a long self-attention launch is split over the key range so that it fills the chip (matters when few
- * heads are local, e.g. the 5 heads per GPU of an 8-way Ulysses shard: +15 %).  workspace = NULL is always valid. */
+/* Optional scratch for wan_attention_fwd (16-byte aligned device memory whose first 16 bytes are ZERO when it is first used,
+ * otherwise of irrelevant content; reusable across calls on one stream).  Header words (int32): [0] sticky "max-free attempt
+ * off", [1] workgroups redone by the last call, [2] repair events of the lazy softmax reference since the caller last cleared
+ * it (statistics).  With at least this many bytes (a) pre-scaled q first runs a max-free kernel (p = exp2(S) with reference 0;
+ * rows whose sum leaves a checked window flag their workgroup in the scratch and are recomputed by the lazy-reference kernel
+ * launched right behind -- same results for unflagged workgroups, ~2 % faster; once more than 1/8 of a launch had to be
+ * recomputed word [0] turns the attempt off for later calls, which then cost one lazy-reference launch: 1.36 instead of
+ * 1.40 PFLOP/s, no cliff), and (b) the last, partially filled round of workgroups of a long self-attention launch is split
+ * over the key range so that it fills the chip (matters when few heads are local, e.g. the 5 heads per GPU of an 8-way
+ * Ulysses shard: +15 %).  workspace = NULL is always valid (one lazy-reference launch). */
 int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim);
 #define WAN_ATTN_Q_PRESCALED 1
 #define WAN_ATTN_QSCALE(softmax_scale) ((softmax_scale) * 1.4426950408889634f)

@@ -176,6 +176,55 @@ def test_graph_replay_is_bit_identical(golden, model):
     assert model.mask_source_frames == 0 and model._ctx_cache is None          # the pipeline restored the model
 
 
+def test_graph_entries_pin_their_buffers_and_follow_the_model(model):
+    """A captured graph replays raw device addresses.  (i) Two call shapes A, B, A: shape B (and an eager call of yet another
+    shape) must not free or reuse the workspaces graph A was captured with -- A's replay still equals the eager result, bitwise;
+    (ii) fractional timesteps are not truncated by the static timestep buffer; (iii) reloading the weights drops the captured
+    graphs instead of replaying stale kernels on freed weight tensors; (iv) release_workspaces() does the same."""
+    from videocof_amd import GraphedForward
+    ctx = [det_uniform("gp.ctx", (9, 64), 1.0).to(DEV)]
+    lat_a, lat_b = det_uniform("gp.a", (1, 16, 5, 8, 8), 1.0).to(DEV), det_uniform("gp.b", (1, 16, 7, 12, 20), 1.0).to(DEV)
+    lat_c = det_uniform("gp.c", (1, 16, 3, 16, 16), 1.0).to(DEV)
+    ta, tb = torch.tensor([500], device=DEV), torch.tensor([250], device=DEV)
+    want_a, want_b = model(lat_a, ta, ctx, 80), model(lat_b, tb, ctx, 420)
+    gf = GraphedForward(model)
+    for _ in range(3):                                   # eager, capture + replay, replay
+        got_a = gf(lat_a, ta, ctx, 80)
+    assert torch.equal(got_a, want_a) and gf.replays == 2
+    for _ in range(3):
+        got_b = gf(lat_b, tb, ctx, 420)                  # a second shape: its own workspaces, its own graph
+    assert torch.equal(got_b, want_b) and gf.replays == 4
+    model(lat_c, ta, ctx, 192)                           # an eager call of a third shape evicts only unpinned workspaces
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(64)]     # whatever was freed gets overwritten
+    assert torch.equal(gf(lat_a, ta, ctx, 80), want_a) and torch.equal(gf(lat_b, tb, ctx, 420), want_b)
+    assert gf.replays == 6 and sum(1 for v in model._bufs.values() if v.pinned) == 2
+    del junk
+    # (ii)
+    tf = torch.tensor([500.5], device=DEV)
+    want_f = model(lat_a, tf, ctx, 80)
+    assert not torch.equal(want_f, want_a)
+    for _ in range(2):
+        got_f = gf(lat_a, tf, ctx, 80)
+    assert torch.equal(got_f, want_f)
+    # (iii) other weights: the captured graphs are dropped, the next call is eager again and right
+    sd2 = {k: (v * 1.01 if k.endswith("ffn.0.weight") else v) for k, v in deterministic_dit_state_dict(**TINY).items()}
+    replays = gf.replays
+    model.load_state_dict(sd2, device=DEV)
+    try:
+        want_a2 = model(lat_a, ta, ctx, 80)
+        got_a2 = gf(lat_a, ta, ctx, 80)
+        assert gf.replays == replays and torch.equal(got_a2, want_a2) and not torch.equal(want_a2, want_a)
+        assert all(e.epoch == model._graph_epoch for e in gf._entries.values())
+        gf(lat_a, ta, ctx, 80)                               # captured again
+        # (iv)
+        model.release_workspaces()
+        assert not model._bufs
+        assert torch.equal(gf(lat_a, ta, ctx, 80), want_a2) and len(gf._entries) == 1
+    finally:
+        model.load_state_dict(deterministic_dit_state_dict(**TINY), device=DEV)
+    assert torch.equal(model(lat_a, ta, ctx, 80), want_a)
+
+
 def test_unpatchify_zero_frames_is_the_cof_mask(model):
     lat = det_uniform("zf.lat", (1, 16, 5, 8, 8), 1.0).to(DEV)
     ctx = [det_uniform("zf.ctx", (9, 64), 1.0).to(DEV)]

@@ -105,6 +105,43 @@ def test_fp8_mode_small_model_vs_oracle_and_bf16():
     assert eb < 1e-2 and e8 < 8e-2 and e8 > eb
 
 
+def test_fp8_then_merge_lora_equals_merge_then_fp8():
+    """The reference quantises first and merges the LoRAs afterwards (fast_infer.py:352-359, 371-385).  The e4m3 copies made by
+    enable_fp8_linear must follow the merged bf16 weights: both orders give the same bits, and un-merging restores them."""
+    from types import SimpleNamespace
+    from videocof_amd.lora_utils import merge_lora, unmerge_lora
+    tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    r, C = 4, 256
+    lora = {"blocks.0.self_attn.q.lora_down.weight": det_uniform("f8l.a.down", (r, C), 0.3),
+            "blocks.0.self_attn.q.lora_up.weight": det_uniform("f8l.a.up", (C, r), 0.3),
+            "blocks.1.ffn.0.lora_down.weight": det_uniform("f8l.b.down", (r, C), 0.3),
+            "blocks.1.ffn.0.lora_up.weight": det_uniform("f8l.b.up", (512, r), 0.3),
+            "blocks.1.self_attn.o.lora_down.weight": det_uniform("f8l.c.down", (r, C), 0.3),
+            "blocks.1.self_attn.o.lora_up.weight": det_uniform("f8l.c.up", (C, r), 0.3)}
+    lat = det_uniform("fp8.lat", (1, 16, 7, 12, 20), 1.0).to(DEV)
+    ctx = [det_uniform("fp8.ctx", (37, 64), 1.0).to(DEV)]
+    t = torch.tensor([899], device=DEV)
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    outs = {}
+    for order in ("fp8_then_merge", "merge_then_fp8"):
+        m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+        m.load_state_dict(deterministic_dit_state_dict(**tiny), device=DEV)
+        pipe = SimpleNamespace(transformer=m)
+        if order == "fp8_then_merge":
+            m.enable_fp8_linear(("qkv", "ffn"))
+            plain = m(lat, t, ctx, 420, **kw)
+            merge_lora(pipe, None, 1.5, state_dict=lora)
+        else:
+            merge_lora(pipe, None, 1.5, state_dict=lora)
+            m.enable_fp8_linear(("qkv", "ffn"))
+        outs[order] = m(lat, t, ctx, 420, **kw)
+        if order == "fp8_then_merge":
+            assert rel_l2(outs[order], plain.cpu()) > 1e-3                   # the merge reached the fp8 projections
+            unmerge_lora(pipe, None, 1.5, state_dict=lora)
+            assert rel_l2(m(lat, t, ctx, 420, **kw), plain.cpu()) < 3e-2    # back (up to the bf16 rounding of the merged weights)
+    assert torch.equal(outs["fp8_then_merge"], outs["merge_then_fp8"])
+
+
 def test_fp8_mode_14b_width_block_error_statement():
     """One 14B-width block at 8 192 tokens: the fp8 (qkv + ffn) path against the bf16 path and the fp32 oracle (evaluated by
     torch on the GPU, as in tests/test_gpu_fullsize.py).  Prints the numbers DESIGN.md quotes."""

@@ -332,12 +332,18 @@ def test_attention_split_tail_round(pre):
     assert torch.equal(again, out)
 
 
-def test_attention_max_free_kernel_and_its_fixup():
-    """Pre-scaled q with scratch memory runs the max-free kernel (p = exp2(S), no running max) and, right behind it, the
-    fix-up launch that recomputes every workgroup whose rows left the checked score window.  (i) ordinary scores: no
-    workgroup is flagged, the result matches the running-max kernel (tuning attn_fast = 0) to bf16 noise and the fp32 oracle;
-    (ii) rows with scores of +-150 (log2 domain): flagged, and those workgroups come out BITWISE equal to the
-    running-max kernel; (iii) scores far below zero for every key of a row: same."""
+def _hdr(site):
+    return site.buf[:16].view(torch.int32).tolist()        # [sticky switch, workgroups redone, lazy-reference repair events, -]
+
+
+def test_attention_max_free_attempt_and_lazy_reference_fixup():
+    """Pre-scaled q with scratch memory runs the max-free form (p = exp2(S), reference 0) and, right behind it, the lazy-reference
+    form on every workgroup whose rows left the checked score window.  Without the attempt (tuning attn_fast = 0, or no scratch)
+    ONE launch of the lazy-reference form does everything.  (i) ordinary scores: nothing flagged, no repair, both forms agree to
+    bf16 noise and with the fp32 oracle; (ii) a key with log2-domain score ~ +300 in tile 10: exp2 overflows -> the max-free
+    attempt flags the workgroup, the lazy form repairs its reference, and the flagged workgroups come out BITWISE equal to the
+    one-launch lazy result; (iii) every score of some rows ~ -1000: the attempt's sums vanish -> flagged; the lazy form needs no
+    repair (its reference starts at the row max of tile 0); (iv) the sticky switch; (v) it belongs to the call site."""
     Lq, Lk, H = 600, 1300, 2
     C = H * 128
     g = torch.Generator(device=DEV).manual_seed(12)
@@ -347,29 +353,35 @@ def test_attention_max_free_kernel_and_its_fixup():
     v = torch.randn(Lk, C, device=DEV, generator=g).bfloat16()
     vt = ops.transpose_pad(v)[None]
 
-    site = ops.AttentionWorkspace()        # this call site's scratch (flags + sticky word)
+    site = ops.AttentionWorkspace()        # this call site's scratch (flags + sticky word + statistics)
 
     def run(qf, fast):
         ops.set_tuning("attn_fast", 1 if fast else 0)
         try:
+            if site.buf is not None:
+                site.buf[8:12].zero_()                               # repair-event counter
             out = ops.attention_fwd((qf * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)
+            variant = ops.get_tuning("last_attn_variant") & 15
         finally:
             ops.set_tuning("attn_fast", 1)
         ws = site.buf
-        hdr = ws[:16].view(torch.int32).clone()                     # [sticky switch, workgroups redone, -, -]
+        run.hdr = _hdr(site)
         flags = ws[16: 16 + 4 * 3 * H].view(torch.int32).clone()    # 3 query blocks x H workgroups
-        ws[:4].zero_()                                              # a test must not switch the fast path off for the next one
-        run.hdr = hdr
+        ws[:4].zero_()                                              # a test must not switch the attempt off for the next one
+        assert variant == (2 if fast else 1)                        # WAN_ATTN_VARIANT_W4_MAXFREE / _W4_LAZY
         return out, flags
 
     fast, flags = run(q, True)
-    assert int(flags.sum()) == 0
-    safe, _ = run(q, False)
+    assert int(flags.sum()) == 0 and run.hdr[2] == 0
+    lazy, _ = run(q, False)
+    assert run.hdr[2] == 0                                          # ordinary scores never leave the window of the tile-0 reference
     # two independently bf16-rounded evaluations of one function (different softmax reference point): sqrt(2) x one run's error
-    assert rel_l2(fast, safe.cpu()) < 4.5e-3 and not torch.equal(fast, safe)
+    assert rel_l2(fast, lazy.cpu()) < 4.5e-3 and not torch.equal(fast, lazy)
     qe = (q * c).bfloat16().float() / c
     ref = _attn_ref(qe.view(1, Lq, H, 128).cpu(), k.view(1, Lk, H, 128).cpu(), v.view(1, Lk, H, 128).cpu()).view(1, Lq, C)
-    assert rel_l2(fast, ref) < 6e-3
+    assert rel_l2(fast, ref) < 6e-3 and rel_l2(lazy, ref) < 6e-3
+    nows = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=None)      # default per-stream scratch
+    assert rel_l2(nows, ref) < 6e-3
     # (ii) a key aligned with the queries of block 1, head 0: log2-domain score 40 * 60 * c ~ +306 -> exp2 overflows
     u = torch.ones(128, device=DEV) / 128 ** 0.5
     q2 = q.clone()
@@ -378,43 +390,93 @@ def test_attention_max_free_kernel_and_its_fixup():
     q2[0, 256:512, :128] = 40 * u + 0.1 * q2[0, 256:512, :128]
     k_saved, k = k, k2                                             # `run` reads k from this scope
     fast2, flags2 = run(q2, True)
-    safe2, _ = run(q2, False)
-    assert torch.isfinite(fast2).all()
+    assert run.hdr[2] >= 1                                         # the fix-up launch had to raise its reference
+    lazy2, _ = run(q2, False)
+    assert run.hdr[2] >= 4                                         # >= one repair per wave of the spiked workgroup
+    assert torch.isfinite(fast2).all() and torch.isfinite(lazy2).all()
     flagged = flags2.view(H, 3).bool()                              # wg = qblk + 3 * head
     assert bool(flagged[0, 1]) and int(flags2.ne(0).sum()) >= 1
     for h in range(H):
         for b in range(3):
-            blk_fast, blk_safe = fast2[0, 256 * b:256 * (b + 1), 128 * h:128 * (h + 1)], safe2[0, 256 * b:256 * (b + 1), 128 * h:128 * (h + 1)]
+            blk_fast, blk_lazy = fast2[0, 256 * b:256 * (b + 1), 128 * h:128 * (h + 1)], lazy2[0, 256 * b:256 * (b + 1), 128 * h:128 * (h + 1)]
             if bool(flagged[h, b]):
-                assert torch.equal(blk_fast, blk_safe), (h, b)
+                assert torch.equal(blk_fast, blk_lazy), (h, b)
             else:
-                assert rel_l2(blk_fast, blk_safe.cpu()) < 4.5e-3, (h, b)
+                assert rel_l2(blk_fast, blk_lazy.cpu()) < 4.5e-3, (h, b)
+    qe2 = (q2 * c).bfloat16().float() / c
+    ref2 = _attn_ref(qe2.view(1, Lq, H, 128).cpu(), k.view(1, Lk, H, 128).cpu(), v.view(1, Lk, H, 128).cpu()).view(1, Lq, C)
+    assert rel_l2(lazy2, ref2) < 6e-3
     k = k_saved
-    # (iii) every score of some rows far below the window: l underflows in the max-free kernel -> flagged -> exact
+    # (iii) every score of some rows far below the window: l underflows in the max-free attempt -> flagged -> exact
     q3 = q.clone()
     kk = k.clone()
     kk[0, :, 128:] = (torch.ones(Lk, 128, device=DEV) * 4).bfloat16()
     q3[0, :40, 128:] = -16.0                                                                 # score = -16*4*128*c ~ -1000
     k = kk
     fast3, flags3 = run(q3, True)
-    safe3, _ = run(q3, False)
+    lazy3, _ = run(q3, False)
+    assert run.hdr[2] == 0
     assert torch.isfinite(fast3).all() and bool(flags3.view(H, 3)[1, 0])
-    assert torch.equal(fast3[0, :256, 128:], safe3[0, :256, 128:])
+    assert torch.equal(fast3[0, :256, 128:], lazy3[0, :256, 128:])
     # (iv) the sticky switch: 1 of 6 workgroups redone (> 1/8) turns the attempt off for later calls on this scratch;
-    #      they then run the running-max kernel for every workgroup
-    ws = site.buf
-    assert int(ws[:4].view(torch.int32)) == 0
+    #      they then run the lazy-reference kernel for every workgroup
+    assert _hdr(site)[0] == 0
     out_a = ops.attention_fwd((q3 * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)
-    assert ws[:8].view(torch.int32).tolist() == [1, 1] and torch.equal(out_a, fast3)   # this call itself was still fast
+    assert _hdr(site)[:2] == [1, 1] and torch.equal(out_a, fast3)   # this call itself was still an attempt
     k = k_saved
     out_b = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)   # harmless input, switch still on
-    assert ws[:8].view(torch.int32).tolist() == [1, 6] and torch.equal(out_b, safe)
-    # (v) the switch belongs to the call site: another site (another layer type, another model) still runs the fast kernel
+    assert _hdr(site)[:2] == [1, 6] and torch.equal(out_b, lazy)
+    # (v) the switch belongs to the call site: another site (another layer type, another model) still makes the attempt
     other = ops.AttentionWorkspace()
     assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=other), fast)
-    assert other.buf[:8].view(torch.int32).tolist() == [0, 0]
+    assert _hdr(other)[:2] == [0, 0]
     site.reset()
     assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site), fast)
+
+
+@pytest.mark.parametrize("pre", [True, False])
+def test_attention_checkpoint_like_statistics(pre):
+    """Scores shaped like a trained checkpoint's rather than a random initialisation's: RMS-normed q / k with per-channel
+    gains log-normal up to 8 and one outlier channel per head that carries a large common offset (the massive-activation pattern)
+    -- log2-domain scores of several hundred,
+    row maxima that differ by > 100 between rows and grow along the sequence.  No window fits; the lazy reference must repair,
+    and the result must still be the oracle's (attention_utils.py:115-146 has no input-dependent behaviour either)."""
+    Lq, Lk, H = 1024, 4096, 2
+    C = H * 128
+    g = torch.Generator(device=DEV).manual_seed(77)
+    gq = torch.exp(0.9 * torch.randn(C, device=DEV, generator=g)).clamp(max=8.0)
+    gk = torch.exp(0.9 * torch.randn(C, device=DEV, generator=g)).clamp(max=8.0)
+
+    def rms(x):
+        x = x.view(-1, H, 128)
+        return (x / x.pow(2).mean(-1, keepdim=True).sqrt()).view(-1, C)
+    ramp = torch.linspace(0.2, 1.5, Lk, device=DEV)[:, None]                      # later keys score higher: references must rise
+    qf = rms(torch.randn(Lq, C, device=DEV, generator=g)) * gq
+    kf = rms(torch.randn(Lk, C, device=DEV, generator=g)) * gk * ramp
+    for h in range(H):                                                            # outlier channels: same sign for every token
+        qf[:, h * 128 + 5] = 40.0 + qf[:, h * 128 + 5].abs()
+        kf[:, h * 128 + 5] = (45.0 + kf[:, h * 128 + 5].abs()) * ramp[:, 0]
+    c = ops.q_prescale(128)
+    k = kf.bfloat16()[None]
+    v = (torch.randn(Lk, C, device=DEV, generator=g) + torch.arange(C, device=DEV) % 128 * 0.01).bfloat16()
+    vt = ops.transpose_pad(v)[None]
+    site = ops.AttentionWorkspace()
+    if pre:
+        qd = (qf * c).bfloat16()[None]
+        qe = qd[0].float() / c
+    else:
+        qd = qf.bfloat16()[None]
+        qe = qd[0].float()
+    out = ops.attention_fwd(qd, k, vt, H, q_prescaled=pre, workspace=site)
+    hdr = _hdr(site)
+    s_max = float((qe[:, :128] @ k[0, :, :128].float().t()).abs().max() * c)
+    ref = _attn_ref(qe.view(1, Lq, H, 128).cpu(), k.view(1, Lk, H, 128).cpu(), v.view(1, Lk, H, 128).cpu()).view(1, Lq, C)
+    assert torch.isfinite(out).all()
+    assert s_max > 300                                                             # really outside every fixed window
+    assert hdr[2] >= 1, hdr                                                        # the lazy reference had to move
+    assert rel_l2(out, ref) < 6e-3, (rel_l2(out, ref), hdr)
+    print(f"checkpoint-like scores (pre={pre}): max |log2 score| {s_max:.0f}, flagged/redone workgroups {hdr[1]}, repair events {hdr[2]}, "
+          f"rel_l2 {rel_l2(out, ref):.2e}")
 
 
 def test_attention_rejects_unbuilt_options():

@@ -142,7 +142,8 @@ def _rccl_ws1_worker(port, q_out):
         assert m.sp_world_size == 1 and not vdist.get_sp_group()._host_staged
         comm = m._comm_events = []
         sharded = m(lat, t, ctx, 420, **kw)               # 420 -> 424 rows (multiple of 8): also the padded-key masking
-        assert m._usp and m._bufs[1].vt is None and m._bufs[1].kw_s is not None     # really the wire-buffer branch
+        wb = m._bufs[m._bufs_last]
+        assert m._usp and wb.vt is None and wb.kw_s is not None     # really the wire-buffer branch
         again = m(lat, t, ctx, 420, **kw)                 # persistent wire buffers reused: a reuse hazard shows up here
         lat2 = det_uniform("sp.lat2", (2, 16, 7, 12, 20), 1.0).cuda()
         other = m(lat2, t, ctx, 420, **kw)                # other data through the same buffers ...

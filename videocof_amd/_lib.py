@@ -18,9 +18,8 @@ ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
 ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax reference)",
-                      2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free) + attn_fwd_v2_kernel<.,true,false,2> fix-up",
-                      3: "attn_fwd_v2_kernel (8-wave, running max)",
-                      4: "attn_fwd_v2_kernel<.,true,false,1> (8-wave, max-free) + fix-up"}
+                      2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free attempt) + attn_fwd_w4_kernel<.,false,1,true> (lazy-reference fix-up of flagged workgroups)",
+                      3: "attn_fwd_v2_kernel (8-wave, running max)"}
 ATTN_VARIANT_XCD_PINNED, ATTN_VARIANT_SPLIT_TAIL = 16, 32
 
 

@@ -44,7 +44,7 @@ namespace {
 struct TuningKey { const char* key; const char* env; int def; };
 const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"attn_tail", "WAN_ATTN_TAIL", 1},          // split-KV tail round of wan_attention_fwd
-    {"attn_fast", "WAN_ATTN_FAST", 1},          // max-free first attempt (+ checked fix-up) for pre-scaled q
+    {"attn_fast", "WAN_ATTN_FAST", 1},          // max-free first attempt (+ checked lazy-reference fix-up) for pre-scaled q with scratch
     {"attn_xcd_map", "WAN_ATTN_XCD_MAP", 1},    // heads pinned to XCDs (one head's K/V per XCD L2 at a time)
     {"gemm_gm", "WAN_GEMM_GM", 0},              // M tiles per rasterisation group of the 256^2 GEMM (0 = by shape)
     {"gemm_phases", "WAN_GEMM_PHASES", 0},      // K-loop phasing of the 256^2 GEMM (0 = default)
@@ -52,7 +52,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"attn_exp", "WAN_ATTN_EXP", 0},            // experiment selector of the attention kernel (0 = product path)
     {"gemm_variant", "WAN_GEMM_VARIANT", 0},    // 1 = force the 128^2 GEMM, 2 = force the 256^2 GEMM, 0 = by shape
     {"conv_xcd", "WAN_CONV_XCD", 1},            // XCD slab rasterisation of wan_conv_cl
-    {"attn_w4", "WAN_ATTN_W4", 1},              // max-free main launch on the 4-wave / 64-rows-per-wave kernel (0 = 8-wave)
+    {"attn_w4", "WAN_ATTN_W4", 1},              // 4-wave / 64-rows-per-wave kernel (0 = the 8-wave running-max kernel, developer A/B)
     {"gemm_w4", "WAN_GEMM_W4", 1},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 K >= 4096, 2 K >= 8192, 3 whenever K % 128 == 0
     {"conv_fast", "WAN_CONV_FAST", 1},          // wan_conv_cl gather addresses on the branch-free 24-bit multiply path (0 = general 64-bit path)
     {"conv_patch", "WAN_CONV_PATCH", 1},        // causal 3x3x3 stride-1 convs with Cout % 96 == 0 on the LDS-patch kernel (0 = the gather kernel)

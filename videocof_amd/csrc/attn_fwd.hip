@@ -53,7 +53,7 @@ struct AttnArgs {
     int qblk0, nsplit, tiles_per_split, row0, rows_tail;
     float* ws_o;          // [batch][nsplit][H][rows_tail][128] un-normalised partial outputs
     float* ws_ml;         // [batch][nsplit][H][rows_tail][2]   running max (log2 units), sum
-    int* flags;           // MODE 1 / 2: one word per workgroup of the main launch, != 0 -> recompute with the running max
+    int* flags;           // scratch words behind the 16-byte header: one per workgroup of the main launch, != 0 -> the fix-up launch redoes it
     // 1-D grid decode: workgroup w -> (query block, head, z) with z = batch (or batch * nsplit + split).
     // xcd_map != 0 (needs nbh % 8 == 0): workgroups are dispatched round-robin over the 8 XCDs, so w & 7 IS the XCD;
     // (head, z) pair bh = 8 * ((w >> 3) / nqb) + (w & 7) pins every head to one XCD, whose 32 CUs walk that head's query
@@ -140,17 +140,11 @@ __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
 // wan_rmsnorm_rope's x0_scale).  The running max then rides in the MFMA accumulator: S' = K.Q^T + (-m)
 // starts from a 16-register splat of -m instead of the inline constant 0, so p = exp2(S') needs no
 // per-score fma: 32 fewer VALU per wave and tile (+6..8 % end to end on this VALU-co-limited loop).
-// MODE 0: the kernel as described above.
-// MODE 1 (PRE only): NO running max at all.  softmax is invariant to the reference point and bf16 P / fp32 accumulators
-//         have head-room for log2-domain scores in about [-90, 100], so p = exp2(S) is taken directly: no row max, no
-//         lane exchange, no rescale branch, S chains start from the inline constant 0 (-37 VALU per wave and tile, and a
-//         straight-line loop).  The assumption is CHECKED: a row whose sum leaves [2^-90, 2^100] (or is not finite)
-//         flags its workgroup, and
-// MODE 2: the MODE 0 kernel launched right behind on the same grid, recomputes exactly the flagged workgroups (all
-//         others exit at once).  DiT activations never raise a flag; adversarial inputs cost a second pass, not accuracy.
-template <int VARIANT, bool PRE, bool SPLIT = false, int MODE = 0>
+// (Rounds 1-2 also instantiated this kernel max-free -- p = exp2(S) without a running max, checked at the end, flagged workgroups
+// redone by a second launch; that role has moved to the 4-wave kernel below, and this one is the developer A/B partner
+// behind the "attn_w4" = 0 switch.)
+template <int VARIANT, bool PRE, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
-    static_assert(MODE == 0 || (PRE && !SPLIT), "fast / fixup modes exist for the pre-scaled, unsplit launch only");
     const int wg_linear = blockIdx.x;
     int qblk_l, bh;
     if (a.xcd_map) {
@@ -162,23 +156,6 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         qblk_l = wg_linear - bh * a.nqb;
     }
     const int bz = bh / a.H;
-    // scratch header (the 4 ints in front of the flags): [0] sticky "fast path off", [1] workgroups redone by this call
-    int* const hdr = (MODE != 0) ? a.flags - 4 : nullptr;
-    if constexpr (MODE == 2) {
-        if (a.flags[wg_linear] == 0) return;          // workgroup-uniform
-        if (threadIdx.x == 0) {
-            // if more than 1/8 of a launch had to be redone, later calls on this scratch skip the max-free attempt
-            const int redone = atomicAdd(&hdr[1], 1) + 1;
-            if (redone * 8 > (int)gridDim.x) hdr[0] = 1;
-        }
-    }
-    if constexpr (MODE == 1) {
-        if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;     // the fix-up launch of this call starts counting at 0
-        if (hdr[0] != 0) {                                       // workgroup-uniform: hand everything to the fix-up launch
-            if (threadIdx.x == 0) a.flags[wg_linear] = 1;
-            return;
-        }
-    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -337,7 +314,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
         const char* kb = kring + kslot_next * kKTileBytes;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            if constexpr (!PRE || MODE == 1) {
+            if constexpr (!PRE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
             }
@@ -348,7 +325,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * 256 + k_off[ks]);
-                if (PRE && MODE != 1 && ks == 0) {
+                if (PRE && ks == 0) {
                     sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, negm, 0, 0, 0);
                 } else {
                     sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
@@ -382,7 +359,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
             s0[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q_frag(ks), s0[kt], 0, 0, 0);
         }
     }
-    float mx_part = MODE == 1 ? 0.f : rowmax32(s0);
+    float mx_part = rowmax32(s0);
     __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
 
     const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
@@ -392,12 +369,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     // one interval: tile t lives in `sc`, S(t+1) is produced into `sn`
     auto interval = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int kslot_next, int vslot) {
         float mc = 0.f;
-        if constexpr (MODE != 1) mc = seg_a(mx_part, sc);
+        mc = seg_a(mx_part, sc);
         float ps = 0.f;
         seg_b(sc, sn, kslot_next, mc, pf, ps);
         pv(vslot, pf, &sc[1], mc, &ps);
         l_run += ps;
-        if constexpr (MODE != 1) mx_part = rowmax32(sn);
+        mx_part = rowmax32(sn);
     };
     for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
         prefetch(it);
@@ -428,10 +405,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
                     const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
                     if (key >= Lk) sl[kt][r] = -INFINITY;
                 }
-            if constexpr (MODE != 1) mx_part = rowmax32(sl);
+            mx_part = rowmax32(sl);
         }
         float mc = 0.f;
-        if constexpr (MODE != 1) mc = seg_a(mx_part, sl);
+        mc = seg_a(mx_part, sl);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -442,12 +419,6 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if constexpr (MODE == 1) {
-        // the checked assumption of MODE 1 (NaN fails both comparisons)
-        const bool ok = (l_tot >= 0x1p-90f && l_tot <= 0x1p100f) || qrow >= a.Lq;
-        const int bad = __syncthreads_or(!ok);
-        if (tid == 0) a.flags[wg_linear] = bad;
-    }
     if constexpr (SPLIT) {
         // partial result of this KV range: un-normalised O, its reference max (log2 units) and its sum
         if (qrow < a.Lq) {
@@ -481,7 +452,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 }
 
 // ====================================================================================================
-// 4-wave kernel: the main launch of the max-free (MODE 1) path.
+// 4-wave kernel: every product launch of wan_attention_fwd (round 2: the max-free main launch only).
 //
 // Same workgroup (256 queries of one (batch, head)), same LDS images, same products and key permutation as the 8-wave
 // kernel above, but FOUR waves of 64 query rows each -- one wave per SIMD with the whole 512-register file:
@@ -499,8 +470,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
 //   * MFMA-written S -> VALU read: S(t+1) is produced in interval t and first read in interval t+1, behind the
 //     s_waitcnt + s_barrier of the fence; the prologue's S(0) and the final O are followed by an explicit s_nop;
 //   * accumulate chains (same D as C) have 4 (S) / 8 (O) independent MFMAs between links, far above the 43-cycle cliff.
-// Rows whose scores leave the checked window flag the workgroup exactly like the 8-wave MODE 1 kernel, and the
-// MODE 2 launch of the 8-wave kernel recomputes it (same 256-query workgroup <-> flag mapping).
+// Three forms of the softmax reference (template parameter REF, below): max-free with a checked window, and two lazy forms.
 // ====================================================================================================
 constexpr int kW4Threads = 256;
 
@@ -518,9 +488,12 @@ __device__ __forceinline__ u32x4 lds_read16_at(unsigned lds_byte_address) {
 // 1.66 GHz, profiles/r02/attn_w4_pmc.json); what is left is energy per tile, not issue slots.
 constexpr int kLdsBytesW4 = 2 * kKTileBytes + 2 * kVTileBytes;
 
-// MAXFREE = true: the max-free form described above (softmax reference 0, checked at the end, flagged workgroups redone by
-// the MODE 2 launch).  MAXFREE = false: the SAME loop with a LAZY softmax reference, which needs no second launch and has no
-// input-dependent cliff:
+// MAXFREE (REF = 0): softmax reference 0 -- p = exp2(S) directly; bf16 P / fp32 sums have head-room for log2-domain scores in
+// about [-90, 100].  The assumption is CHECKED: a row whose sum leaves [2^-90, 2^100] (or is not finite) flags its workgroup
+// in the caller's scratch, and the FIX launch right behind (the lazy form below, same grid) redoes exactly the flagged
+// workgroups; a sticky word in the scratch turns the attempt off once more than 1/8 of a launch had to be redone.
+// MAXFREE = false: the SAME loop with a LAZY softmax reference, which needs no second launch and has no input-dependent
+// cliff (1.36 vs 1.40 PFLOP/s for the max-free attempt at L = 67 080 x 40 heads, profiles/r03/attn_lazy_ab.log):
 //   * the reference m of a query row starts as the exact row max of tile 0 and rides in the MFMA accumulator (every S chain
 //     starts from a 16-register splat of -m, as in the 8-wave PRE form), so p = exp2(S') costs no extra VALU;
 //   * softmax does not care WHICH reference is used as long as nothing overflows or vanishes, and bf16 P / fp32 sums have
@@ -538,12 +511,23 @@ constexpr float kW4Trigger = 0x1p40f;
 
 // REF: 0 = max-free, 1 = lazy reference riding in the accumulator (-m splats, 32 VGPRs, no extra VALU),
 //      2 = lazy reference subtracted from the scores two at a time (v_pk_add_f32: 4 VGPRs, +32 VALU per tile).
-template <int VARIANT, bool SPLIT, int REF>
+// FIX: the launch right behind a max-free attempt on the same grid -- only flagged workgroups run (all others exit at once).
+template <int VARIANT, bool SPLIT, int REF, bool FIX = false>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {
     constexpr bool MAXFREE = REF == 0, SPLAT = REF == 1, PKSUB = REF == 2;
     static_assert(!(SPLIT && MAXFREE), "the split tail round runs the lazy-reference form");
+    static_assert(!FIX || (!SPLIT && !MAXFREE), "the fix-up launch is the unsplit lazy-reference form");
     const int wg_linear = blockIdx.x;
+    if constexpr (FIX) {
+        if (a.flags[wg_linear] == 0) return;          // workgroup-uniform
+        if (threadIdx.x == 0) {
+            // if more than 1/8 of a launch had to be redone, later calls on this scratch skip the max-free attempt
+            int* const hdr = a.flags - 4;
+            const int redone = atomicAdd(&hdr[1], 1) + 1;
+            if (redone * 8 > (int)gridDim.x) hdr[0] = 1;
+        }
+    }
     if constexpr (MAXFREE) {
         int* const hdr = a.flags - 4;
         if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;
@@ -1144,10 +1128,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 1>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 1>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, false, 2>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true, false, 2>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 0>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 0>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 1>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, true>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 2>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 2>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 2>)};
@@ -1181,8 +1164,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         const wan_status_t cs = check_vt_padding(a, batch, lk_pad, st);
         if (cs != WAN_OK) return cs;
     }
-    // With scratch memory: (1) pre-scaled q runs the max-free kernel (MODE 1) followed by the fix-up launch (MODE 2) that
-    // recomputes flagged workgroups only; (2) the last partial round of a long launch is split over the keys (plan_tail).
+    // With scratch memory: (1) pre-scaled q first runs the max-free form, followed by the FIX launch of the lazy-reference form
+    // on the flagged workgroups only; (2) the last partial round of a long launch is split over the keys (plan_tail).
+    // Without scratch (or attn_fast = 0): ONE launch of the lazy-reference form.
     // attn_fast / attn_tail (wan_set_tuning, or WAN_ATTN_FAST / WAN_ATTN_TAIL read once at load) are developer A/B switches.
     TailPlan tp;
     bool fast = false;
@@ -1191,7 +1175,7 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
         const int64_t fb = flag_bytes(batch, Lq, num_heads);
         if (workspace_bytes >= fb) {
-            fast = pre && wan_tune(WAN_TUNE_ATTN_FAST) != 0;
+            fast = pre && wan_tune(WAN_TUNE_ATTN_FAST) != 0 && wan_tune(WAN_TUNE_ATTN_W4) != 0;
             a.flags = (int*)workspace + 4;
             ws_tail = (char*)workspace + fb;
             tp = plan_tail(batch, Lq, Lk, num_heads);
@@ -1210,7 +1194,7 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     const bool w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0, ref2 = !pre || wan_tune(WAN_TUNE_ATTN_REF) == 2;
     const dim3 block4(kW4Threads);
     int variant;
-    if (w4 && !fast) {               // the product path: lazy-reference 4-wave kernel, one launch, any q form, scratch or not
+    if (w4 && !fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
         variant = WAN_ATTN_VARIANT_W4_LAZY;
         if (ref2) {
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 2>), grid, block4, kLdsBytesW4, st, a);
@@ -1219,27 +1203,22 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1>), grid, block4, kLdsBytesW4, st, a);
             else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1>), grid, block4, kLdsBytesW4, st, a);
         }
-    } else if (w4) {                 // A/B: max-free 4-wave attempt + checked fix-up (round 2's path)
+    } else if (w4) {                 // max-free attempt (2 % faster), then the lazy-reference kernel on the flagged workgroups only
         variant = WAN_ATTN_VARIANT_W4_MAXFREE;
         if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 0>), grid, block4, kLdsBytesW4, st, a);
         else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 0>), grid, block4, kLdsBytesW4, st, a);
-    } else if (fast) {
-        variant = WAN_ATTN_VARIANT_W8_MAXFREE;
-        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 1>), grid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 1>), grid, block, kLdsBytesV2, st, a);
-    } else if (pre) {
-        variant = WAN_ATTN_VARIANT_W8_RUNNING_MAX;
-        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
-    } else {
-        variant = WAN_ATTN_VARIANT_W8_RUNNING_MAX;
-        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
-    }
-    if (fast) {              // same grid, right behind: workgroups whose rows left the checked score window are redone
         WAN_CHECK_LAUNCH("wan_attention_fwd");
-        if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, false, 2>), grid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true, false, 2>), grid, block, kLdsBytesV2, st, a);
+        if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, true>), grid, block4, kLdsBytesW4, st, a);
+        else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1, true>), grid, block4, kLdsBytesW4, st, a);
+    } else {                         // developer A/B partner: the round-1 8-wave kernel, running max per tile
+        variant = WAN_ATTN_VARIANT_W8_RUNNING_MAX;
+        if (pre) {
+            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
+            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
+        } else {
+            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
+            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
+        }
     }
     if (a.xcd_map) variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (tp.tq > 0) {

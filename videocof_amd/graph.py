@@ -9,7 +9,13 @@ with new latents / timestep / prompt:
 * latents and timestep live in static buffers that are overwritten before each replay;
 * the step-invariant text K/V are hoisted (``cache_context``) and recomputed EAGERLY, in place, when the prompt changes,
   so the graph never contains them and stays valid across prompts of the same batch size;
-* activation workspaces and the attention scratch are the model's cached buffers (fixed addresses);
+* activation workspaces and the attention scratch are the model's cached buffers; every entry PINS the set it was captured
+  with (the model keeps one workspace set per call shape and never evicts a pinned one; the entry also holds the attention
+  scratch tensors), so a second call shape, a larger scratch request or an eager call in between can never free memory a
+  captured graph still writes to;
+* anything that replaces device memory the graph has baked in -- ``load_state_dict``, ``enable / disable_fp8_linear``,
+  ``release_workspaces()`` -- bumps the model's ``_graph_epoch``; entries of an older epoch are dropped, not replayed
+  (``merge_lora`` edits the weights in place: same addresses, the next replay reads the merged values);
 * the CoF mask is part of the captured unpatchify kernel (``mask_source_frames``).
 
 A replay executes the same kernels with the same arguments in the same order as the eager call: the result is
@@ -25,7 +31,7 @@ __all__ = ["GraphedForward"]
 
 
 class _Entry:
-    __slots__ = ("x", "t", "graph", "out", "calls", "kv")
+    __slots__ = ("x", "t", "graph", "out", "calls", "kv", "epoch", "bufs", "attn_bufs")
 
 
 class GraphedForward:
@@ -40,6 +46,9 @@ class GraphedForward:
         self.replays = 0
 
     def reset(self) -> None:
+        for ent in self._entries.values():
+            if ent.bufs is not None:
+                ent.bufs.pinned = False
         self._entries.clear()
 
     @torch.no_grad()
@@ -51,16 +60,28 @@ class GraphedForward:
             raise NotImplementedError("TeaCache decides per step on the host whether the blocks run: not capturable")
         if isinstance(x, (list, tuple)):
             x = torch.stack(list(x))
-        key = (tuple(x.shape), x.dtype, int(seq_len), tuple(frame_split_indices or ()),
+        t = t.reshape(-1)
+        if t.is_floating_point() and bool((t != t.round()).any()):
+            # the eager forward takes fractional timesteps; a static integer buffer would truncate them silently
+            key_t = t.dtype
+        else:
+            key_t = torch.int64
+        key = (tuple(x.shape), x.dtype, key_t, int(seq_len), tuple(frame_split_indices or ()),
                tuple(tuple(g) for g in (ground_frame_indices or ())), int(m.skip_source_frames),
-               int(m.mask_source_frames), len(context), torch.cuda.current_device())
+               int(m.mask_source_frames), len(context), torch.cuda.current_device(), tuple(m._fp8),
+               bool(m.use_block_composite), bool(m.use_forward_composite))
+        epoch = m._graph_epoch
+        for k in [k for k, e in self._entries.items() if e.epoch != epoch]:
+            stale = self._entries.pop(k)                 # weights / fp8 copies / workspaces were replaced since the capture
+            if stale.bufs is not None:
+                stale.bufs.pinned = False
         ent = self._entries.get(key)
         if ent is None:
             ent = self._entries[key] = _Entry()
-            ent.x, ent.t = torch.empty_like(x), torch.empty(x.shape[0], device=x.device, dtype=torch.int64)
-            ent.graph, ent.out, ent.calls, ent.kv = None, None, 0, None
+            ent.x, ent.t = torch.empty_like(x), torch.empty(x.shape[0], device=x.device, dtype=key_t)
+            ent.graph, ent.out, ent.calls, ent.kv, ent.epoch, ent.bufs, ent.attn_bufs = None, None, 0, None, epoch, None, None
         ent.x.copy_(x)
-        ent.t.copy_(t.reshape(-1).to(torch.int64).expand(x.shape[0]))
+        ent.t.copy_(t.to(key_t).expand(x.shape[0]))
         prev = m.cache_context
         m.cache_context = True
         try:
@@ -82,6 +103,12 @@ class GraphedForward:
                 finally:
                     m._attn_events = events
                 ent.graph = graph
+                # pin what the graph has baked in besides x / t / out / kv: the activation workspace set of this shape and the
+                # attention scratch tensors of the four call sites (a later, larger request re-allocates the site's scratch;
+                # this reference keeps the captured one alive)
+                ent.bufs = m._bufs[m._bufs_last]
+                ent.bufs.pinned = True
+                ent.attn_bufs = [ws.buf for ws in (m._ws_self, m._ws_cross, m._ws_self_sfx, m._ws_cross_sfx)]
             ent.graph.replay()
             self.replays += 1
             return ent.out.clone()

@@ -139,6 +139,10 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
     model.lora_layers_merged = merged                 # the reference returns the pipeline, so the count rides here
     if hasattr(model, "_ctx_cache"):
         model._ctx_cache = None          # hoisted text K/V were built from the old cross-attention weights
+    if getattr(model, "_fp8", ()):
+        # the reference quantises first and merges afterwards (fast_infer.py:352-359, 371-385): the e4m3 copies made by
+        # enable_fp8_linear must follow the merged bf16 weights, or q|k / v / ffn keep running the pre-LoRA values
+        model.enable_fp8_linear(model._fp8)
     return pipeline
 
 

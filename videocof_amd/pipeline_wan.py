@@ -261,6 +261,10 @@ class WanPipeline:
                 self.transformer.skip_source_frames = prev_skip
             if prev_mask is not None:
                 self.transformer.mask_source_frames = prev_mask
+            if hasattr(self.transformer, "release_workspaces"):
+                # 7 GB of activation buffers at 14B / 67k tokens: hand them back before the VAE decode (and to whatever else
+                # shares the device); the sets a captured graph replays from stay
+                self.transformer.release_workspaces(keep_pinned=True)
 
         # -- decode (:757-790)
         ground_video = edit_video = video_out = None

@@ -127,7 +127,14 @@ class WanTransformer3DModel(nn.Module):
         self.use_block_composite = True     # single-device blocks through wan_dit_block_forward (one C call per block)
         self.use_forward_composite = True   # ... and, when nothing hooks into the block loop, the whole token path through wan_dit_forward
         self._cdw = None                    # ctypes wan_dit_weights of the loaded blocks (built on first use)
-        self._bufs = None                   # cached activation workspaces of the last call shape (_workspaces)
+        # cached activation workspaces by call shape (_workspaces): the eager forward keeps ONE (the last shape; another shape
+        # evicts it), a captured hipGraph PINS the set it was recorded with (videocof_amd/graph.py) so that it is never freed
+        # under the graph
+        self._bufs = {}
+        self._bufs_last = None
+        # bumped whenever device memory a captured graph may have baked in is replaced (weights reloaded, fp8 copies rebuilt,
+        # workspaces released): GraphedForward entries of an older epoch are discarded instead of replayed
+        self._graph_epoch = 0
         # Number of leading latent frames whose prediction the caller discards (WanPipeline zeroes
         # noise_pred[:, :, :condition_count], pipeline_wan.py:736).  When set (B = 1, no SP) the LAST block and
         # the head run only on the remaining tokens' query rows -- their keys/values still cover every token --
@@ -235,6 +242,9 @@ class WanTransformer3DModel(nn.Module):
                           ang[..., 1].to(torch.float32).contiguous().to(dev))
         self._device = dev
         self._ctx_cache = None
+        self._graph_epoch += 1                         # new weight tensors
+        for ws in (self._ws_self, self._ws_cross, self._ws_self_sfx, self._ws_cross_sfx):
+            ws.reset()                                 # the sticky "max-free attempt off" word described the OLD weights' scores
         if self._fp8:
             self.enable_fp8_linear(self._fp8)          # re-quantise from the new bf16 weights
         return IncompatibleKeys(missing, extra)
@@ -339,13 +349,15 @@ class WanTransformer3DModel(nn.Module):
             if "ffn" in layers:
                 blk.f8["w1"], blk.f8["w2"] = ops.quantize_weight_fp8(blk.w1), ops.quantize_weight_fp8(blk.w2)
         self._fp8 = layers
-        self._bufs = None
+        self._bufs, self._bufs_last = {}, None
+        self._graph_epoch += 1              # new e4m3 tensors: a graph captured before must not replay the old ones
 
     def disable_fp8_linear(self):
         for blk in self.blocks:
             blk.f8 = None
         self._fp8 = ()
-        self._bufs = None
+        self._bufs, self._bufs_last = {}, None
+        self._graph_epoch += 1
 
     def clear_context_cache(self):
         """Drop the hoisted text K/V^T (0.8 GB at 14B) and the references that keep the prompt embeddings alive."""
@@ -495,9 +507,13 @@ class WanTransformer3DModel(nn.Module):
     def _workspaces(self, B, Ll, L, seq_len):
         """Per-forward activation buffers (module docstring).  Kept across calls of one shape: the caching allocator
         would hand the same blocks back anyway, and fixed addresses are what a captured hipGraph replays."""
-        key = (B, Ll, L, seq_len, self.sp_world_size, self._usp, str(self._device))
-        if self._bufs is not None and self._bufs[0] == key:
-            return self._bufs[1]
+        key = (B, Ll, L, seq_len, self.sp_world_size, self._usp, str(self._device), tuple(self._fp8))
+        b = self._bufs.get(key)
+        if b is not None:
+            self._bufs_last = key
+            return b
+        for k in [k for k, v in self._bufs.items() if not getattr(v, "pinned", False)]:
+            del self._bufs[k]                                  # eager use keeps one shape; pinned sets belong to captured graphs
         C, dev, M = self.dim, self._device, B * Ll
         b = SimpleNamespace()
         b.h = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
@@ -523,12 +539,22 @@ class WanTransformer3DModel(nn.Module):
             if "ffn" in self._fp8:
                 b.ffq = torch.empty(M, self.ffn_dim, device=dev, dtype=ops.FP8)
                 b.ffs = torch.empty(M, device=dev, dtype=torch.float32)
-        self._bufs = (key, b)
+        b.pinned = False
+        self._bufs[key] = b
+        self._bufs_last = key
         return b
 
-    def release_workspaces(self):
-        """Free the cached activation buffers (7 GB at 14B / L = 67 080) and the hoisted text K/V."""
-        self._bufs = None
+    def release_workspaces(self, keep_pinned: bool = False):
+        """Free the cached activation buffers (7 GB at 14B / L = 67 080) and the hoisted text K/V.  ``keep_pinned``: leave the
+        sets a captured hipGraph replays from (``WanPipeline`` passes it when it owns a ``GraphedForward``); without it every
+        captured graph of this model is invalidated (``_graph_epoch``)."""
+        if keep_pinned:
+            for k in [k for k, v in self._bufs.items() if not getattr(v, "pinned", False)]:
+                del self._bufs[k]
+        else:
+            self._bufs = {}
+            self._graph_epoch += 1
+        self._bufs_last = None
         self._ctx_cache = None
 
     def _run_block(self, blk: _Block, em, xs, bufs, ctx_kv, rp, B, Ll, L, seq_len):
