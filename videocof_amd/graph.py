@@ -46,10 +46,17 @@ class GraphedForward:
         self.replays = 0
 
     def reset(self) -> None:
+        """Drop every captured graph and un-pin its workspaces (the model's next eager call of another shape frees them)."""
         for ent in self._entries.values():
             if ent.bufs is not None:
                 ent.bufs.pinned = False
         self._entries.clear()
+
+    def __del__(self):
+        try:
+            self.reset()
+        except Exception:
+            pass
 
     @torch.no_grad()
     def __call__(self, x, t, context, seq_len, frame_split_indices=None, ground_frame_indices=None, **kw):
