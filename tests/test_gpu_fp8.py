@@ -136,9 +136,9 @@ def test_fp8_then_merge_lora_equals_merge_then_fp8():
             m.enable_fp8_linear(("qkv", "ffn"))
         outs[order] = m(lat, t, ctx, 420, **kw)
         if order == "fp8_then_merge":
-            assert rel_l2(outs[order], plain.cpu()) > 1e-3                   # the merge reached the fp8 projections
+            assert rel_l2(outs[order].cpu(), plain.cpu()) > 1e-3                   # the merge reached the fp8 projections
             unmerge_lora(pipe, None, 1.5, state_dict=lora)
-            assert rel_l2(m(lat, t, ctx, 420, **kw), plain.cpu()) < 3e-2    # back (up to the bf16 rounding of the merged weights)
+            assert rel_l2(m(lat, t, ctx, 420, **kw).cpu(), plain.cpu()) < 3e-2    # back (up to the bf16 rounding of the merged weights)
     assert torch.equal(outs["fp8_then_merge"], outs["merge_then_fp8"])
 
 
