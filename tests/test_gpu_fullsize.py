@@ -100,6 +100,32 @@ def test_14b_width_block_at_the_headline_cof_shape():
     assert float(per_row) < 5e-2, float(per_row)            # no single token row is off (e.g. a masked / ragged-tile row)
 
 
+def test_1p3b_width_block_at_l_32760():
+    """configs[1]'s width composed (not kernel by kernel): C = 1536 / 12 heads / ffn 8 960 -- K = 1536 and 8 960 GEMM dispatch
+    (the 8-wave 256^2 kernel below K = 4096), 12 local heads (no XCD pinning: 12 % 8 != 0) -- at L = 32 760 tokens, the CoF
+    grid (21, 30, 52) with one grounding frame."""
+    grid, fs, gr = (21, 30, 52), 10, (10, 11)
+    L, C = math.prod(grid), 1536
+    assert L == 32760
+    w13 = dict(dim=1536, ffn_dim=8960, num_heads=12)
+    m = WanTransformer3DModel(num_layers=1, **w13)
+    m.load_state_dict(random_dit_state_dict(DEV, seed=9, exercise_epilogues=True, dim=1536, ffn_dim=8960, num_layers=1), device=DEV)
+    cfg = O.DiTConfig(num_layers=1, **w13)
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(1, L, C, device=DEV, generator=g)
+    e = torch.randn(1, 6, C, device=DEV, generator=g) * 0.3
+    ctx = torch.randn(1, 512, C, device=DEV, generator=g).bfloat16().float()
+    out = m.block_forward(x, e, ctx, grid, 0, [fs], [gr])[0]
+    m.release_workspaces()
+    ref = O.block_forward(x[0], e[0], ctx[0], oracle_sd(m), 0, cfg, grid, O.rope_angles(128), fs, gr, L)
+    upd, upd_ref = out - x[0], ref - x[0]
+    r_all, u_all = rel_l2(out, ref), rel_l2(upd, upd_ref)
+    print(f"1.3B block @ L={L}: stream rel-L2 {r_all:.2e}, update rel-L2 {u_all:.2e}, cos {cosine(upd, upd_ref):.6f}")
+    assert r_all < 1e-2 and u_all < 3e-2 and cosine(upd, upd_ref) > 0.9995
+    per_row = ((out - ref).double().norm(dim=1) / ref.double().norm(dim=1)).max()
+    assert float(per_row) < 5e-2, float(per_row)
+
+
 def test_config3_shape_batch2_two_prompts():
     """configs[3]'s call shape (inference.py: guidance 5 -> B = 2 [uncond, cond]; 81f@720p -> grid (21,45,80),
     L = 75 600; T2V positions) with two layers at 14B width: the whole forward (patch embedding, time / text

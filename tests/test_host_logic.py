@@ -202,3 +202,23 @@ def test_teacache_host_logic():
     assert tc.cnt == 0 and tc.previous_modulated_input is None                               # reset after num_steps
     with pytest.raises(TypeError):
         TeaCache([1.0, 0.0], num_steps=3, rel_l1_thresh=0.1).decide(e)
+
+
+def test_transformer_surface_the_reference_pipeline_touches():
+    """the attributes and the call keywords the REFERENCE's WanPipeline uses on its transformer
+    (pipeline_wan.py:634, 689, 692, 695, 721-728) exist on the drop-in with the types the reference expects.  (The reference
+    pipeline itself cannot be imported here -- it needs the real diffusers -- so this pins the surface, not the composition.)"""
+    import inspect
+    from videocof_amd import WanTransformer3DModel
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64)
+    assert m.config.in_channels == 16 and tuple(m.config.patch_size) == (1, 2, 2)
+    m.num_inference_steps = 4
+    m.current_steps = 2
+    assert (m.num_inference_steps, m.current_steps) == (4, 2)
+    params = inspect.signature(m.forward).parameters
+    for kw in ("x", "context", "t", "seq_len", "frame_split_indices", "ground_frame_indices"):
+        assert kw in params, kw
+    assert m.dtype == torch.bfloat16 and m.freqs.shape == (1024, 64)
+    for name in ("enable_teacache", "disable_teacache", "share_teacache", "enable_cfg_skip", "disable_cfg_skip",
+                 "enable_multi_gpus_inference", "load_state_dict", "state_dict", "from_pretrained"):
+        assert callable(getattr(m, name)), name

@@ -45,13 +45,13 @@ def get_teacache_coefficients(model_name: str) -> Optional[List[float]]:
 class TeaCache:
     def __init__(self, coefficients: List[float], num_steps: int, rel_l1_thresh: float = 0.0,
                  num_skip_start_steps: int = 0, offload: bool = True):
+        # the same three argument checks as the reference's constructor (cache_utils.py:37-46: ValueError each), own wording
         if num_steps < 1:
-            raise ValueError(f"`num_steps` must be greater than 0 but is {num_steps}.")
+            raise ValueError(f"TeaCache: num_steps={num_steps}; a denoise loop has at least one step")
         if rel_l1_thresh < 0:
-            raise ValueError(f"`rel_l1_thresh` must be greater than or equal to 0 but is {rel_l1_thresh}.")
-        if num_skip_start_steps < 0 or num_skip_start_steps > num_steps:
-            raise ValueError("`num_skip_start_steps` must be great than or equal to 0 and "
-                             f"less than or equal to `num_steps={num_steps}` but is {num_skip_start_steps}.")
+            raise ValueError(f"TeaCache: rel_l1_thresh={rel_l1_thresh}; the accumulated-distance threshold cannot be negative")
+        if not 0 <= num_skip_start_steps <= num_steps:
+            raise ValueError(f"TeaCache: num_skip_start_steps={num_skip_start_steps} lies outside [0, num_steps={num_steps}]")
         self.coefficients = list(coefficients)
         self.num_steps = num_steps
         self.rel_l1_thresh = rel_l1_thresh
