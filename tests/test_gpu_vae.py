@@ -133,6 +133,26 @@ def test_g10_decode(golden, vae):
     assert outb.dtype == torch.bfloat16 and rel_l2(outb.float(), g["out"]) < 4e-2
 
 
+def test_decode_chunking_is_bit_identical(vae):
+    """The reference decodes one latent frame per call (wan_vae.py:561-573).  Frame 0 stays alone (the 'Rep' chunk); every
+    temporal operator after it is causal with a 2-frame history, so chunks of 2, 4 or 5 latent frames (incl. a ragged last
+    chunk: 1 + 4 + 4 + 2) give the SAME BITS as the per-frame loop -- and the oracle's result."""
+    z = det_uniform("vae.chunk.z", (1, 16, 11, 6, 10), 1.5).to(DEV)
+    outs = {}
+    old = vae.decode_chunk
+    try:
+        for n in (1, 2, 4, 5, 16):
+            vae.decode_chunk = n
+            outs[n] = vae.decode(z).sample
+    finally:
+        vae.decode_chunk = old
+    assert outs[1].shape == (1, 3, 41, 48, 80)
+    for n in (2, 4, 5, 16):
+        assert torch.equal(outs[n], outs[1]), n
+    orc = WanVAEOracle(deterministic_vae_state_dict())
+    assert rel_l2(outs[4][0], orc.decode(z[0].cpu())) < 3e-2
+
+
 def test_vae_vs_oracle_other_shape(vae):
     """Non-square, T = 5 (chunks 1,4): HIP encode->mode vs oracle, then HIP decode vs oracle."""
     orc = WanVAEOracle(deterministic_vae_state_dict())

@@ -29,6 +29,8 @@ def main():
     dev = torch.device("cuda:0")
     vae = AutoencoderKLWan()
     vae.load_state_dict(random_vae_state_dict(dev), device=dev)
+    if os.environ.get("WAN_VAE_DECODE_CHUNK"):            # A/B of the decoder's temporal chunking (1 = the reference's per-frame loop)
+        vae.decode_chunk = int(os.environ["WAN_VAE_DECODE_CHUNK"])
     g = torch.Generator(device=dev).manual_seed(0)
     video = (torch.rand(1, 3, args.frames, args.height, args.width, device=dev, generator=g) * 2 - 1).bfloat16()
     tl = (args.frames - 1) // 4 + 1
@@ -55,7 +57,7 @@ def main():
         "sec_per_encode": round(t_enc, 3), "encode_tflops_per_s": round(enc_tf / t_enc, 1),
         "sec_per_decode": round(t_dec, 3), "decode_tflops_per_s": round(dec_tf / t_dec, 1),
         "sec_per_decode_1_latent_frame": round(t_dec1, 4),
-        "latent_shape": list(lat.shape), "video_shape": list(vid.shape)}))
+        "decode_chunk": vae.decode_chunk, "latent_shape": list(lat.shape), "video_shape": list(vid.shape)}))
 
 
 if __name__ == "__main__":

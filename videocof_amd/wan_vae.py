@@ -10,10 +10,14 @@ Every convolution runs in ``wan_conv_cl`` (implicit GEMM on the matrix cores) on
 bf16 activations ``[T, H, W, C]``; RMS_norm+SiLU, the attention softmax and the layout changes at
 the boundary are HIP kernels too; the middle AttentionBlock's two products use ``wan_gemm_bf16``.
 
-Temporal chunking is the reference's: encode 1,4,4,... frames (:527-539), decode one latent
-frame per call (:561-573).  Each cached CausalConv3d owns a 2-frame history buffer; a missing
-history frame is the zero padding the reference applies (:32-38).  'Rep' (first upsample3d chunk
-skips time_conv, :108-112) and the downsample3d seeding (:148-152) are kept literally.
+Temporal chunking: encode 1,4,4,... frames as the reference does (:527-539).  The reference decodes one latent
+frame per call (:561-573); here latent frame 0 goes alone (it is the 'Rep' chunk whose upsample3d skips time_conv,
+:108-112) and the following frames in chunks of ``decode_chunk`` (default 4): every temporal operator of the decoder is
+causal with a 2-frame history, so a chunk of n frames is the same arithmetic on the same operands as n chunks of one --
+the results are bit-identical (``tests/test_gpu_vae.py::test_decode_chunking_is_bit_identical``) -- while the 60 x 104
+latent-resolution stage gets 4x the workgroups (it filled half the chip) and the launch count drops from 2 072 to ~600.
+Each cached CausalConv3d owns a 2-frame history buffer; a missing history frame is the zero padding the reference applies
+(:32-38).  'Rep' and the downsample3d seeding (:148-152) are kept literally.
 """
 from __future__ import annotations
 
@@ -88,6 +92,7 @@ class AutoencoderKLWan(nn.Module):
         self._seen: Dict[str, bool] = {}
         self._device = torch.device("cpu")
         self._dtype = torch.bfloat16
+        self.decode_chunk = 4                            # latent frames per decoder call after the first (1 = the reference's loop)
 
     @property
     def dtype(self):
@@ -296,7 +301,9 @@ class AutoencoderKLWan(nn.Module):
         std = self.std.to(z.device).view(-1, 1, 1, 1)
         zc = (z.float() * std + mean).permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
         x = self._causal(zc, "conv2")
-        outs = [self._decoder_chunk(x[i:i + 1].contiguous()) for i in range(x.shape[0])]
+        n = max(1, int(self.decode_chunk))
+        outs = [self._decoder_chunk(x[:1].contiguous())]
+        outs += [self._decoder_chunk(x[i:i + n].contiguous()) for i in range(1, x.shape[0], n)]
         self.clear_cache()
         return ops.cl_to_video(torch.cat(outs), 3, out_dtype, True)
 
