@@ -274,3 +274,34 @@ def test_lds_patch_conv_vs_torch_and_vs_gather_kernel(cin, cout, T, H, W, nh, re
     assert got.shape == ref.shape
     assert rel_l2_dev(got.float(), ref) < 4e-3 and rel_l2_dev(gather.float(), ref) < 4e-3
     assert rel_l2_dev(got.float(), gather.float()) < 3e-3
+
+
+@pytest.mark.parametrize("cin,T,H,W,nh", [(96, 1, 8, 32, 0), (96, 3, 13, 37, 1), (32, 2, 21, 70, 2), (96, 5, 9, 65, 2)])
+def test_head_conv_direct_kernel_vs_torch_and_vs_gather_kernel(cin, T, H, W, nh):
+    """The direct (vector-ALU) kernel of the causal 3x3x3 convolution with <= 4 output channels (conv3_head_kernel: the decoder
+    head 96 -> 3): exact tile, ragged tiles along H and W, 0 / 1 / 2 history frames, tile counts that are not a multiple of the 8
+    XCDs -- against torch's fp32 conv3d on the same bf16 inputs (<= 4e-3: one bf16 rounding at the store) and against the
+    implicit-GEMM gather kernel (tuning conv_head = 0); pad output channel 3 carries only its (zero) bias."""
+    g = torch.Generator(device=DEV).manual_seed(cin + H + W)
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).bfloat16()
+    hist = torch.randn(nh, H, W, cin, device=DEV, generator=g).bfloat16() if nh else None
+    K = 27 * cin
+    wt = (torch.randn(3, cin, 3, 3, 3, device=DEV, generator=g) * (1.0 / K ** 0.5)).bfloat16()
+    w = torch.zeros(4, ops.round_up(K, 64), device=DEV, dtype=torch.bfloat16)
+    w[:3, :K] = wt.permute(0, 2, 3, 4, 1).reshape(3, K)
+    b = torch.zeros(4, device=DEV)
+    b[:3] = torch.randn(3, device=DEV, generator=g)
+    run = lambda: ops.conv_cl(x, w, b, 4, (3, 3, 3), pad=(2, 1, 1), out_thw=(T, H, W), hist=hist)
+    try:
+        ops.set_tuning("conv_head", 1)
+        got = run()
+        assert torch.equal(run(), got)
+        ops.set_tuning("conv_head", 0)
+        gather = run()
+    finally:
+        ops.set_tuning("conv_head", 1)
+    frames = torch.cat([torch.zeros(2 - nh, H, W, cin, device=DEV, dtype=torch.bfloat16)] + ([hist] if nh else []) + [x])
+    ref = torch.nn.functional.conv3d(frames.float().permute(3, 0, 1, 2)[None], wt.float(), b[:3], padding=(0, 1, 1))[0].permute(1, 2, 3, 0)
+    assert got.shape == (T, H, W, 4) and float(got[..., 3].abs().max()) == 0.0
+    assert rel_l2_dev(got[..., :3].float(), ref) < 4e-3 and rel_l2_dev(gather[..., :3].float(), ref) < 4e-3
+    assert rel_l2_dev(got[..., :3].float(), gather[..., :3].float()) < 4e-3

@@ -57,6 +57,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"conv_fast", "WAN_CONV_FAST", 1},          // wan_conv_cl gather addresses on the branch-free 24-bit multiply path (0 = general 64-bit path)
     {"conv_patch", "WAN_CONV_PATCH", 1},        // causal 3x3x3 stride-1 convs with Cout % 96 == 0 on the LDS-patch kernel (0 = the gather kernel)
     {"attn_ref", "WAN_ATTN_REF", 1},            // lazy softmax reference of the 4-wave kernel: 1 = -m splat in the accumulator, 2 = packed subtract
+    {"conv_head", "WAN_CONV_HEAD", 1},          // causal 3x3x3 convs with <= 4 output channels on the direct (vector-ALU) kernel (0 = the gather kernel)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

@@ -670,6 +670,125 @@ wan_status_t launch_conv3_patch(ConvArgs g, hipStream_t s) {
     return WAN_OK;
 }
 
+// ------------------------------------------------------------------ causal 3x3x3, stride 1, <= 4 output channels: the decoder head
+// decoder.head.2 maps 96 channels to 3 at FULL resolution (wan_vae.py:476): as an implicit GEMM it fills 3 of the 32 columns of
+// the narrowest matrix tile and pays the whole per-chunk gather arithmetic of conv_cl_kernel (0.56 ms per output frame, 13 % of a
+// decode).  With so few outputs the matrix cores have nothing to offer; this kernel is a direct convolution on the vector ALUs:
+// a workgroup owns 8 x 32 output pixels of one frame (one pixel per thread), stages their (3 frames) x 10 x 34 input patch in
+// LDS 32 channels at a time (the same pixel-major, XOR-swizzled 64-byte records as conv3_patch_kernel), and every thread walks
+// the 27 taps of its own pixel: 4 x ds_read_b128, then 2 x 16 x COUT fp32 FMAs against weights that are wave-uniform (scalar
+// loads, SGPR operands).  fp32 accumulation, one bf16 rounding at the store.  Workgroup w runs on XCD w & 7 and the frames of
+// one spatial tile are consecutive on ONE XCD, so the 3x temporal re-read of every input plane is served by that XCD's L2.
+constexpr int HD_H = 8, HD_W = 32, HD_PH = HD_H + 2, HD_PW = HD_W + 2, HD_FR = HD_PH * HD_PW, HD_PX = 3 * HD_FR;   // 1020
+constexpr int kHeadLds = 1024 * 64;
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3_head_kernel(ConvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int ntile = g.pth * g.ptw;
+    int tile, frame;
+    {
+        const int w = blockIdx.x;
+        if ((ntile & 7) == 0 || true) {
+            // XCD x walks tiles x, x + 8, ...: all frames of one tile back to back on one XCD
+            const int xcd = w & 7, s = w >> 3;
+            const int per = (ntile + 7) >> 3;                   // tiles per XCD (the last ones may be missing)
+            const int ti = s / g.T_out;
+            frame = s - ti * g.T_out;
+            tile = ti * 8 + xcd;
+            if (ti >= per || tile >= ntile) return;
+        }
+    }
+    const int thi = tile / g.ptw, twi = tile - thi * g.ptw;
+    const int h0 = thi * HD_H, w0 = twi * HD_W;
+    const int hf = g.hist_frames;
+    const int H = g.H_in, W = g.W_in, Cin = g.Cin;
+    // ---- staging plan (chunk-independent): thread i-th piece = patch pixel pp, 16-byte slot q
+    int src_off[16];            // element offset of (pixel, 8-channel piece) inside x or hist, -1 = zero fill
+    bool from_hist[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + i * 256;                          // 0 .. 4095 (>= 4080: unused tail)
+        const int pp = idx >> 2, q = idx & 3;
+        const int f = pp / HD_FR, rem = pp - f * HD_FR;
+        const int pr = rem / HD_PW, pc = rem - pr * HD_PW;
+        const int t = frame - 2 + f, hh = h0 - 1 + pr, ww = w0 - 1 + pc;
+        const bool ok = pp < HD_PX && hh >= 0 && hh < H && ww >= 0 && ww < W && t >= -hf;
+        from_hist[i] = t < 0;
+        const int tt = t < 0 ? t + hf : t;
+        src_off[i] = ok ? ((tt * H + hh) * W + ww) * Cin + q * 8 : -1;
+    }
+    const int r = tid >> 5, c = tid & 31;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = g.bias ? g.bias[co] : 0.f;
+    const int nch = Cin >> 5;
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                                        // the previous chunk's reads are done
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + i * 256;
+            const int pp = idx >> 2, q = idx & 3;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (src_off[i] >= 0) v = *reinterpret_cast<const u32x4*>((from_hist[i] ? g.hist : g.x) + src_off[i] + ch * 32);
+            if (idx < 4 * 1024) *reinterpret_cast<u32x4*>(smem + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4)) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 27; ++tap) {                    // rolled: 64 weight dwords per tap are all the SGPRs there are
+            const int kt = tap / 9, kh = (tap - kt * 9) / 3, kw = tap - kt * 9 - kh * 3;
+            const int pp = (kt * HD_PH + r + kh) * HD_PW + c + kw;
+            const char* rec = smem + pp * 64;
+            const int sw = (pp >> 2) & 3;
+            // weights of this tap and chunk: wave-uniform -> scalar loads, used as SGPR operands of the dot products
+            const unsigned* wq = reinterpret_cast<const unsigned*>(g.w + tap * Cin + ch * 32);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // (read as eight bf16 and paired by element: hipcc folds bit_cast<bf16x2>(u32x4[j]) to element 0 for every j)
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(rec + ((q ^ sw) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x2 xp = {xv[2 * j], xv[2 * j + 1]};
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        // two exact bf16 products added to the fp32 accumulator (v_dot2c_f32_bf16)
+                        const bf16x2 wp = __builtin_bit_cast(bf16x2, wq[co * (int)(g.ldw >> 1) + q * 4 + j]);
+                        acc[co] = __builtin_amdgcn_fdot2_f32_bf16(xp, wp, acc[co], false);
+                    }
+                }
+            }
+        }
+    }
+    const int ho = h0 + r, wo = w0 + c;
+    if (ho < g.H_out && wo < g.W_out) {
+        bf16_t* op = g.out + ((int64_t)(frame * g.H_out + ho) * g.W_out + wo) * g.ldo;
+        if constexpr (COUT == 4) {
+            u32x2 w = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+            *reinterpret_cast<u32x2*>(op) = w;
+        } else {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) op[co] = (bf16_t)acc[co];
+        }
+    }
+}
+
+wan_status_t launch_conv3_head(ConvArgs& g, hipStream_t s) {
+    static std::atomic<uint64_t> done{0};
+    const wan_status_t st = wan_once_per_device(done, +[]() -> wan_status_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_head_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kHeadLds);
+        if (e != hipSuccess) { wan_set_error("wan_conv_cl: cannot reserve LDS: %s", hipGetErrorString(e)); return WAN_ERR_LAUNCH; }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
+    g.pth = (g.H_out + HD_H - 1) / HD_H; g.ptw = (g.W_out + HD_W - 1) / HD_W;
+    const int ntile = g.pth * g.ptw, per = (ntile + 7) / 8;
+    const int64_t nwg = (int64_t)per * 8 * g.T_out;
+    hipLaunchKernelGGL(conv3_head_kernel<4>, dim3((unsigned)nwg), dim3(256), kHeadLds, s, g);
+    WAN_CHECK_LAUNCH("wan_conv_cl (head)");
+    return WAN_OK;
+}
+
 // ------------------------------------------------------------------ per-pixel RMS_norm (+SiLU)
 // F.normalize(x, dim=channel) * sqrt(C) * gamma  (wan_vae.py:43-58), optional SiLU.  A pixel's C channels are
 // C/8 16-byte chunks; LPP = 8/16/32/64 lanes share a pixel (the next power of two >= C/8), so a wave normalises
@@ -813,7 +932,15 @@ extern "C" wan_status_t wan_conv_cl(const void* x, const void* hist, int hist_fr
                               ((uintptr_t)out & 15) == 0 && ((uintptr_t)resid & 15) == 0;          // 16-byte output stores
         if (mode && shape_ok) return launch_conv3_patch(g, s);      // also with fewer tiles than CUs (1 latent frame: 544 vs 285 TFLOP/s)
     }
-    if (p->Cout <= 32) { g.tiles_n = 1; return launch_conv<1>(g, s); }      // decoder head (3), latent convs (16 / 32)
+    {   // causal 3x3x3 / stride 1 with <= 4 output channels (the decoder head): direct convolution on the vector ALUs
+        const int64_t px = (int64_t)(p->T_in + hist_frames) * p->H_in * p->W_in;
+        const bool shape_ok = ntaps == 27 && p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 2 && p->ph == 1 && p->pw == 1 &&
+                              !p->upsample2x && !p->time_interleave && p->Cin % 32 == 0 && p->Cout == 4 && resid == nullptr &&
+                              p->T_out == p->T_in && p->H_out == p->H_in && p->W_out == p->W_in && px * p->Cin < (1LL << 31) &&
+                              ldw % 2 == 0 && ((uintptr_t)out & 7) == 0 && ldo % 4 == 0;
+        if (wan_tune(WAN_TUNE_CONV_HEAD) != 0 && shape_ok) return launch_conv3_head(g, s);
+    }
+    if (p->Cout <= 32) { g.tiles_n = 1; return launch_conv<1>(g, s); }      // latent convs (16 / 32), the head when the switch is off
     if (p->Cout <= 96) { g.tiles_n = (p->Cout + 95) / 96; return launch_conv<3>(g, s); }
     if (p->Cout % 192 == 0) { g.tiles_n = p->Cout / 192; return launch_conv<6>(g, s); }
     g.tiles_n = (p->Cout + 127) / 128;
