@@ -671,58 +671,64 @@ wan_status_t launch_conv3_patch(ConvArgs g, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ causal 3x3x3, stride 1, <= 4 output channels: the decoder head
-// decoder.head.2 maps 96 channels to 3 at FULL resolution (wan_vae.py:476): as an implicit GEMM it fills 3 of the 32 columns of
-// the narrowest matrix tile and pays the whole per-chunk gather arithmetic of conv_cl_kernel (0.56 ms per output frame, 13 % of a
-// decode).  With so few outputs the matrix cores have nothing to offer; this kernel is a direct convolution on the vector ALUs:
-// a workgroup owns 8 x 32 output pixels of one frame (one pixel per thread), stages their (3 frames) x 10 x 34 input patch in
-// LDS 32 channels at a time (the same pixel-major, XOR-swizzled 64-byte records as conv3_patch_kernel), and every thread walks
-// the 27 taps of its own pixel: 4 x ds_read_b128, then 2 x 16 x COUT fp32 FMAs against weights that are wave-uniform (scalar
-// loads, SGPR operands).  fp32 accumulation, one bf16 rounding at the store.  Workgroup w runs on XCD w & 7 and the frames of
-// one spatial tile are consecutive on ONE XCD, so the 3x temporal re-read of every input plane is served by that XCD's L2.
+// decoder.head.2 maps 96 channels to 3 at FULL resolution (wan_vae.py:476): in conv_cl_kernel it fills 3 of the 32 columns of the
+// narrowest tile and pays the whole per-chunk gather arithmetic (0.56 ms per output frame, 13 % of a decode).  Here a workgroup
+// owns 8 x 32 output pixels of one frame, stages their (3 frames) x 10 x 34 input patch in LDS 32 channels at a time (the same
+// pixel-major, XOR-swizzled 64-byte records as conv3_patch_kernel) together with the chunk's 27 x COUT weight rows: with
+// v_mfma_f32_16x16x32_bf16 a weight fragment is 16 output channels (COUT real, the rest one shared zero row) x 32 input channels
+// = 16 bytes per lane, so one tap of 64 pixels is ONE weight ds_read_b128, four pixel ds_read_b128 and four MFMAs -- no global
+// address arithmetic and no weight traffic in the loop.
+// (A vector-ALU form -- one pixel per thread, v_dot2c_f32_bf16 against scalar-loaded weights -- was measured first and LOST to
+// the gather kernel, 0.337 vs 0.328 s per decode: 100 scalar instructions and an exposed s_load round trip per tap.)
+// Workgroup w runs on XCD w & 7 and the frames of one spatial tile are consecutive on ONE XCD, so the 3x temporal re-read of
+// every input plane is served by that XCD's L2.
 constexpr int HD_H = 8, HD_W = 32, HD_PH = HD_H + 2, HD_PW = HD_W + 2, HD_FR = HD_PH * HD_PW, HD_PX = 3 * HD_FR;   // 1020
-constexpr int kHeadLds = 1024 * 64;
+constexpr int kHeadLds = 1024 * 64 + 27 * 4 * 64 + 64;
 
 template <int COUT>
-__global__ __launch_bounds__(256) void conv3_head_kernel(ConvArgs g) {
+__global__ __launch_bounds__(256, 2) void conv3_head_kernel(ConvArgs g) {
+    static_assert(COUT <= 16, "one 16-column MFMA tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = g.pth * g.ptw;
     int tile, frame;
     {
-        const int w = blockIdx.x;
-        if ((ntile & 7) == 0 || true) {
-            // XCD x walks tiles x, x + 8, ...: all frames of one tile back to back on one XCD
-            const int xcd = w & 7, s = w >> 3;
-            const int per = (ntile + 7) >> 3;                   // tiles per XCD (the last ones may be missing)
-            const int ti = s / g.T_out;
-            frame = s - ti * g.T_out;
-            tile = ti * 8 + xcd;
-            if (ti >= per || tile >= ntile) return;
-        }
+        // XCD x walks tiles x, x + 8, ...: all frames of one tile back to back on one XCD
+        const int w = blockIdx.x, xcd = w & 7, sq = w >> 3;
+        const int ti = sq / g.T_out;
+        frame = sq - ti * g.T_out;
+        tile = ti * 8 + xcd;
+        if (tile >= ntile) return;
     }
     const int thi = tile / g.ptw, twi = tile - thi * g.ptw;
     const int h0 = thi * HD_H, w0 = twi * HD_W;
     const int hf = g.hist_frames;
     const int H = g.H_in, W = g.W_in, Cin = g.Cin;
-    // ---- staging plan (chunk-independent): thread i-th piece = patch pixel pp, 16-byte slot q
+    // ---- staging plan (chunk-independent): this thread's i-th piece = patch pixel pp, 16-byte slot q
     int src_off[16];            // element offset of (pixel, 8-channel piece) inside x or hist, -1 = zero fill
-    bool from_hist[16];
+    unsigned hist_mask = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int idx = tid + i * 256;                          // 0 .. 4095 (>= 4080: unused tail)
+        const int idx = tid + i * 256;                          // 0 .. 4095 (>= 4080: zero tail)
         const int pp = idx >> 2, q = idx & 3;
         const int f = pp / HD_FR, rem = pp - f * HD_FR;
         const int pr = rem / HD_PW, pc = rem - pr * HD_PW;
         const int t = frame - 2 + f, hh = h0 - 1 + pr, ww = w0 - 1 + pc;
         const bool ok = pp < HD_PX && hh >= 0 && hh < H && ww >= 0 && ww < W && t >= -hf;
-        from_hist[i] = t < 0;
+        if (t < 0) hist_mask |= 1u << i;
         const int tt = t < 0 ? t + hf : t;
         src_off[i] = ok ? ((tt * H + hh) * W + ww) * Cin + q * 8 : -1;
     }
-    const int r = tid >> 5, c = tid & 31;
-    float acc[COUT];
+    // ---- MFMA roles: A = 16 pixels x 32 channels (lane: pixel lane & 15, channels 8 * (lane >> 4) ..), B = 32 channels x 16
+    // output channels (lane: output channel lane & 15, same channel octet).  Wave `wid` owns tile rows 2 wid, 2 wid + 1 as four
+    // 16-pixel blocks mb: row 2 wid + (mb >> 1), columns 16 (mb & 1) ..
+    const int m = lane & 15, kq = lane >> 4;
+    char* const wlds = smem + 1024 * 64;
+    const int wrd = (m < COUT ? m * 64 : 27 * COUT * 64) + kq * 16;      // this lane's row of a tap's weight record (or the zero row)
+    f32x4 acc[4];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = g.bias ? g.bias[co] : 0.f;
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nch = Cin >> 5;
     for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();                                        // the previous chunk's reads are done
@@ -731,44 +737,47 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(ConvArgs g) {
             const int idx = tid + i * 256;
             const int pp = idx >> 2, q = idx & 3;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (src_off[i] >= 0) v = *reinterpret_cast<const u32x4*>((from_hist[i] ? g.hist : g.x) + src_off[i] + ch * 32);
-            if (idx < 4 * 1024) *reinterpret_cast<u32x4*>(smem + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4)) = v;
+            if (src_off[i] >= 0) {
+                if ((hist_mask >> i) & 1) v = *reinterpret_cast<const u32x4*>(g.hist + (src_off[i] + ch * 32));
+                else v = *reinterpret_cast<const u32x4*>(g.x + (src_off[i] + ch * 32));
+            }
+            *reinterpret_cast<u32x4*>(smem + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4)) = v;
         }
+        // the chunk's weights: 27 taps x COUT rows x 32 channels (64 B per row) behind the patch; one 64-byte zero row serves the
+        // 16 - COUT padding columns of the MFMA tile
+        for (int i = tid; i < 27 * COUT * 4; i += 256) {
+            const int tap = i / (COUT * 4), rem = i - tap * (COUT * 4), co = rem >> 2, q = rem & 3;
+            *reinterpret_cast<u32x4*>(wlds + i * 16) = *reinterpret_cast<const u32x4*>(g.w + (co * (int)g.ldw + tap * Cin + ch * 32 + q * 8));
+        }
+        if (tid < 4) *reinterpret_cast<u32x4*>(wlds + 27 * COUT * 64 + tid * 16) = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
-#pragma unroll 1
-        for (int tap = 0; tap < 27; ++tap) {                    // rolled: 64 weight dwords per tap are all the SGPRs there are
-            const int kt = tap / 9, kh = (tap - kt * 9) / 3, kw = tap - kt * 9 - kh * 3;
-            const int pp = (kt * HD_PH + r + kh) * HD_PW + c + kw;
-            const char* rec = smem + pp * 64;
-            const int sw = (pp >> 2) & 3;
-            // weights of this tap and chunk: wave-uniform -> scalar loads, used as SGPR operands of the dot products
-            const unsigned* wq = reinterpret_cast<const unsigned*>(g.w + tap * Cin + ch * 32);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // (read as eight bf16 and paired by element: hipcc folds bit_cast<bf16x2>(u32x4[j]) to element 0 for every j)
-                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(rec + ((q ^ sw) << 4));
+        for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x2 xp = {xv[2 * j], xv[2 * j + 1]};
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co) {
-                        // two exact bf16 products added to the fp32 accumulator (v_dot2c_f32_bf16)
-                        const bf16x2 wp = __builtin_bit_cast(bf16x2, wq[co * (int)(g.ldw >> 1) + q * 4 + j]);
-                        acc[co] = __builtin_amdgcn_fdot2_f32_bf16(xp, wp, acc[co], false);
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bf16x8 wfrag = *reinterpret_cast<const bf16x8*>(wlds + wrd + ((kt * 3 + kh) * 3 + kw) * (m < COUT ? COUT * 64 : 0));
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const int pp = (kt * HD_PH + 2 * wid + (mb >> 1) + kh) * HD_PW + 16 * (mb & 1) + m + kw;
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + pp * 64 + ((kq ^ ((pp >> 2) & 3)) << 4));
+                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wfrag, acc[mb], 0, 0, 0);
                     }
                 }
-            }
-        }
     }
-    const int ho = h0 + r, wo = w0 + c;
-    if (ho < g.H_out && wo < g.W_out) {
-        bf16_t* op = g.out + ((int64_t)(frame * g.H_out + ho) * g.W_out + wo) * g.ldo;
-        if constexpr (COUT == 4) {
-            u32x2 w = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
-            *reinterpret_cast<u32x2*>(op) = w;
-        } else {
+    // ---- D: lane holds output channel lane & 15 of pixels 4 * (lane >> 4) .. + 3 of each block
+    if (m < COUT) {
+        const float bv = g.bias ? g.bias[m] : 0.f;
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) op[co] = (bf16_t)acc[co];
+        for (int mb = 0; mb < 4; ++mb) {
+            const int ho = h0 + 2 * wid + (mb >> 1);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int wo = w0 + 16 * (mb & 1) + 4 * kq + r4;
+                if (ho < g.H_out && wo < g.W_out)
+                    g.out[((int64_t)(frame * g.H_out + ho) * g.W_out + wo) * g.ldo + m] = (bf16_t)(acc[mb][r4] + bv);
+            }
         }
     }
 }
