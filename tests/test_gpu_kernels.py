@@ -356,7 +356,7 @@ def test_attention_max_free_attempt_and_lazy_reference_fixup():
     site = ops.AttentionWorkspace()        # this call site's scratch (flags + sticky word + statistics)
 
     def run(qf, fast):
-        ops.set_tuning("attn_fast", 1 if fast else 0)
+        ops.set_tuning("attn_fast", 2 if fast else 0)               # 2: the attempt even on this short launch (1 = long launches only)
         try:
             if site.buf is not None:
                 site.buf[8:12].zero_()                               # repair-event counter
@@ -421,17 +421,24 @@ def test_attention_max_free_attempt_and_lazy_reference_fixup():
     # (iv) the sticky switch: 1 of 6 workgroups redone (> 1/8) turns the attempt off for later calls on this scratch;
     #      they then run the lazy-reference kernel for every workgroup
     assert _hdr(site)[0] == 0
-    out_a = ops.attention_fwd((q3 * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)
-    assert _hdr(site)[:2] == [1, 1] and torch.equal(out_a, fast3)   # this call itself was still an attempt
-    k = k_saved
-    out_b = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)   # harmless input, switch still on
-    assert _hdr(site)[:2] == [1, 6] and torch.equal(out_b, lazy)
-    # (v) the switch belongs to the call site: another site (another layer type, another model) still makes the attempt
-    other = ops.AttentionWorkspace()
-    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=other), fast)
-    assert _hdr(other)[:2] == [0, 0]
-    site.reset()
-    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site), fast)
+    ops.set_tuning("attn_fast", 2)
+    try:
+        out_a = ops.attention_fwd((q3 * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)
+        assert _hdr(site)[:2] == [1, 1] and torch.equal(out_a, fast3)   # this call itself was still an attempt
+        k = k_saved
+        out_b = ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site)   # harmless input, switch still on
+        assert _hdr(site)[:2] == [1, 6] and torch.equal(out_b, lazy)
+        # (v) the switch belongs to the call site: another site (another layer type, another model) still makes the attempt
+        other = ops.AttentionWorkspace()
+        assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=other), fast)
+        assert _hdr(other)[:2] == [0, 0]
+        site.reset()
+        assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site), fast)
+    finally:
+        ops.set_tuning("attn_fast", 1)
+    # (vi) the default policy: a launch this short (6 workgroups) is not worth a second launch -- one lazy-reference launch
+    assert torch.equal(ops.attention_fwd((q * c).bfloat16(), k, vt, H, q_prescaled=True, workspace=site), lazy)
+    assert ops.get_tuning("last_attn_variant") & 15 == 1
 
 
 @pytest.mark.parametrize("pre", [True, False])

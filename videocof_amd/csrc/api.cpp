@@ -44,7 +44,7 @@ namespace {
 struct TuningKey { const char* key; const char* env; int def; };
 const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"attn_tail", "WAN_ATTN_TAIL", 1},          // split-KV tail round of wan_attention_fwd
-    {"attn_fast", "WAN_ATTN_FAST", 1},          // max-free first attempt (+ checked lazy-reference fix-up) for pre-scaled q with scratch
+    {"attn_fast", "WAN_ATTN_FAST", 1},          // max-free first attempt (+ checked lazy-reference fix-up): 1 = long self-attention launches with scratch, 2 = whenever there is scratch, 0 = never
     {"attn_xcd_map", "WAN_ATTN_XCD_MAP", 1},    // heads pinned to XCDs (one head's K/V per XCD L2 at a time)
     {"gemm_gm", "WAN_GEMM_GM", 0},              // M tiles per rasterisation group of the 256^2 GEMM (0 = by shape)
     {"gemm_phases", "WAN_GEMM_PHASES", 0},      // K-loop phasing of the 256^2 GEMM (0 = default)

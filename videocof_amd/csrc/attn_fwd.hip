@@ -1175,7 +1175,12 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
         const int64_t fb = flag_bytes(batch, Lq, num_heads);
         if (workspace_bytes >= fb) {
-            fast = pre && wan_tune(WAN_TUNE_ATTN_FAST) != 0 && wan_tune(WAN_TUNE_ATTN_W4) != 0;
+            // the attempt is worth its second launch (~5-15 us of workgroups that exit at once) only on long launches: self-attention
+            // over >= 4 rounds of workgroups; short launches (cross-attention's 8 KV tiles, small grids) take the one-launch lazy form.
+            // attn_fast = 2 forces the attempt whenever there is scratch (tests)
+            const int fast_mode = wan_tune(WAN_TUNE_ATTN_FAST);
+            const bool long_launch = self && (int64_t)nqb_all * num_heads * batch >= 4LL * wan_cu_count();
+            fast = pre && wan_tune(WAN_TUNE_ATTN_W4) != 0 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
             a.flags = (int*)workspace + 4;
             ws_tail = (char*)workspace + fb;
             tp = plan_tail(batch, Lq, Lk, num_heads);
