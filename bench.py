@@ -81,7 +81,8 @@ def pmc_traffic(workload, shards):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench14b_pmc_summary.json")), reverse=True):
         try:
             with open(path) as f:
-                d = next(v for k, v in json.load(f).items() if "attn_fwd" in k and "<0" in k)
+                cands = {k: v for k, v in json.load(f).items() if "attn_fwd" in k and "<0" in k and "fetch" in v and "write" in v}
+            d = max(cands.values(), key=lambda v: v["fetch"]["avg_ms"])        # the self-attention MAIN launch (not tail / fix-up)
             fetch, write = d["fetch"]["avg_counter"] * 1024 * 2, d["write"]["avg_counter"] * 1024
             return fetch + write, {"fetch_bytes_x2_corrected": fetch, "write_bytes": write, "algorithmic_bytes": alg,
                                    "note": "L2->fabric requests; includes Infinity-Cache hits",

@@ -132,6 +132,11 @@ typedef enum {
 wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                            void* out, int64_t ldo, int M, int N, int K, int epilogue,
                            const float* gate, int64_t rows_per_batch, void* stream);
+/* Host arithmetic only: the kernel family wan_gemm_bf16 dispatches an [M, K] x [N, K]^T product to. */
+int wan_gemm_plan(int M, int N, int K);
+#define WAN_GEMM_VARIANT_128 0      /* gemm_bf16_kernel: 128 x 128 x 64 tile, 4 waves, two workgroups per CU (small / under-filled shapes) */
+#define WAN_GEMM_VARIANT_256_W8 1   /* gemm256_kernel: 256 x 256 x 64 tile, 8 waves, phased K loop */
+#define WAN_GEMM_VARIANT_256_W4 2   /* gemm_w4_kernel: the same tile, 4 waves of 128 x 128 outputs (K >= 4096 by default) */
 
 /* ---------------------------------------------------------------------------
  * 8f-4  FP8 (OCP e4m3) projections -- an explicit, lossy option of the host model (`enable_fp8_linear`); never the default.
@@ -189,6 +194,10 @@ wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
  * over the key range so that it fills the chip (matters when few heads are local, e.g. the 5 heads per GPU of an 8-way
  * Ulysses shard: +15 %).  workspace = NULL is always valid (one lazy-reference launch). */
 int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim);
+/* Host arithmetic only (no GPU needed): what wan_attention_fwd will launch for this shape, flags and scratch size, as
+ * WAN_ATTN_VARIANT_* bits (the value wan_get_tuning("last_attn_variant") reports after the call); 0 for an unsupported shape.
+ * Lets a benchmark / test state the dispatched kernels without launching them.  No reference counterpart. */
+int wan_attention_plan(int batch, int Lq, int Lk, int num_heads, int head_dim, int flags, int64_t workspace_bytes);
 #define WAN_ATTN_Q_PRESCALED 1
 #define WAN_ATTN_QSCALE(softmax_scale) ((softmax_scale) * 1.4426950408889634f)
 

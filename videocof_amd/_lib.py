@@ -21,6 +21,7 @@ ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax refe
                       2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free attempt) + attn_fwd_w4_kernel<.,false,1,true> (lazy-reference fix-up of flagged workgroups)",
                       3: "attn_fwd_v2_kernel (8-wave, running max)"}
 ATTN_VARIANT_XCD_PINNED, ATTN_VARIANT_SPLIT_TAIL = 16, 32
+GEMM_VARIANT_KERNELS = {0: "gemm_bf16_kernel", 1: "gemm256_kernel", 2: "gemm_w4_kernel"}      # wan_gemm_plan (WAN_GEMM_VARIANT_*)
 
 
 def attn_variant_name(code: int) -> str:
@@ -108,6 +109,8 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
     "wan_attention_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "wan_attention_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64]),
+    "wan_gemm_plan": (c_int, [c_int, c_int, c_int]),
     "wan_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "wan_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_void_p]),

@@ -1097,6 +1097,43 @@ int64_t flag_bytes(int batch, int Lq, int num_heads) {
 }
 }  // namespace
 
+namespace {
+// The dispatch decision of wan_attention_fwd as host arithmetic (shared by the launcher and wan_attention_plan).
+struct AttnPlan { TailPlan tail; bool fast = false, w4 = true, ref2 = false, xcd = false; int variant = 0; };
+
+AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int64_t workspace_bytes) {
+    AttnPlan p;
+    const bool self = Lk > 1024;
+    const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
+    p.w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0;
+    // plain q always takes the packed-shift form (it applies softmax_scale exactly, in the same fma); pre-scaled q the
+    // accumulator form unless the developer switch asks for the other
+    p.ref2 = !pre || wan_tune(WAN_TUNE_ATTN_REF) == 2;
+    const int64_t fb = flag_bytes(batch, Lq, num_heads);
+    if (workspace_bytes >= fb) {
+        // the attempt is worth its second launch (~5-15 us of workgroups that exit at once) only on long launches: self-attention
+        // over >= 4 rounds of workgroups; short launches (cross-attention's 8 KV tiles, small grids) take the one-launch lazy form.
+        // attn_fast = 2 forces the attempt whenever there is scratch (tests)
+        const int fast_mode = wan_tune(WAN_TUNE_ATTN_FAST);
+        const bool long_launch = self && (int64_t)nqb_all * num_heads * batch >= 4LL * wan_cu_count();
+        p.fast = pre && p.w4 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
+        p.tail = plan_tail(batch, Lq, Lk, num_heads);
+        if (p.tail.tq > 0 && workspace_bytes - fb < p.tail.ws_bytes) p.tail = TailPlan();
+    }
+    // heads pinned to XCDs: only worth it (and only balanced) when the (batch, head) pairs split evenly over the 8 XCDs
+    p.xcd = wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && (num_heads * batch) % 8 == 0;
+    p.variant = !p.w4 ? WAN_ATTN_VARIANT_W8_RUNNING_MAX : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY);
+    if (p.xcd) p.variant |= WAN_ATTN_VARIANT_XCD_PINNED;
+    if (p.tail.tq > 0) p.variant |= WAN_ATTN_VARIANT_SPLIT_TAIL;
+    return p;
+}
+}  // namespace
+
+extern "C" int wan_attention_plan(int batch, int Lq, int Lk, int num_heads, int head_dim, int flags, int64_t workspace_bytes) {
+    if (batch <= 0 || Lq <= 0 || Lk <= 0 || num_heads <= 0 || head_dim != kD) return 0;
+    return plan_attention(batch, Lq, Lk, num_heads, (flags & WAN_ATTN_Q_PRESCALED) != 0, workspace_bytes).variant;
+}
+
 extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim) {
     if (batch <= 0 || Lq <= 0 || Lk <= 0 || num_heads <= 0 || head_dim != kD) return 0;
     return flag_bytes(batch, Lq, num_heads) + plan_tail(batch, Lq, Lk, num_heads).ws_bytes;
@@ -1168,35 +1205,27 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     // on the flagged workgroups only; (2) the last partial round of a long launch is split over the keys (plan_tail).
     // Without scratch (or attn_fast = 0): ONE launch of the lazy-reference form.
     // attn_fast / attn_tail (wan_set_tuning, or WAN_ATTN_FAST / WAN_ATTN_TAIL read once at load) are developer A/B switches.
-    TailPlan tp;
-    bool fast = false;
     char* ws_tail = nullptr;
+    int64_t ws_usable = 0;
     if (workspace != nullptr) {
         WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_attention_fwd: workspace must be 16-byte aligned");
         const int64_t fb = flag_bytes(batch, Lq, num_heads);
         if (workspace_bytes >= fb) {
-            // the attempt is worth its second launch (~5-15 us of workgroups that exit at once) only on long launches: self-attention
-            // over >= 4 rounds of workgroups; short launches (cross-attention's 8 KV tiles, small grids) take the one-launch lazy form.
-            // attn_fast = 2 forces the attempt whenever there is scratch (tests)
-            const int fast_mode = wan_tune(WAN_TUNE_ATTN_FAST);
-            const bool long_launch = self && (int64_t)nqb_all * num_heads * batch >= 4LL * wan_cu_count();
-            fast = pre && wan_tune(WAN_TUNE_ATTN_W4) != 0 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
+            ws_usable = workspace_bytes;
             a.flags = (int*)workspace + 4;
             ws_tail = (char*)workspace + fb;
-            tp = plan_tail(batch, Lq, Lk, num_heads);
-            if (tp.tq > 0 && workspace_bytes - fb < tp.ws_bytes) tp = TailPlan();
         }
     }
+    const AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable);
+    const TailPlan& tp = plan.tail;
+    const bool fast = plan.fast;
     a.nqb = tp.tq > 0 ? tp.main_qb : nqb_all;
     a.nbh = num_heads * batch;
-    // heads pinned to XCDs: only worth it (and only balanced) when the (batch, head) pairs split evenly over the 8 XCDs
-    a.xcd_map = (wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && a.nbh % 8 == 0) ? 1 : 0;
+    a.xcd_map = plan.xcd ? 1 : 0;
     const int64_t nwg = (int64_t)a.nqb * a.nbh;
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     dim3 grid((unsigned)nwg);
-    // plain q always takes the packed-shift form (it applies softmax_scale exactly, in the same fma); pre-scaled q the
-    // accumulator form unless the developer switch asks for the other
-    const bool w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0, ref2 = !pre || wan_tune(WAN_TUNE_ATTN_REF) == 2;
+    const bool w4 = plan.w4, ref2 = plan.ref2;
     const dim3 block4(kW4Threads);
     int variant;
     if (w4 && !fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path

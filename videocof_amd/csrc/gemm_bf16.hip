@@ -259,6 +259,20 @@ wan_status_t launch(const GemmArgs& g, hipStream_t s, int batch = 1) {
 
 }  // namespace
 
+bool wan_gemm256_uses_w4(int K);        // gemm_bf16_256.hip
+
+// Which kernel family wan_gemm_bf16 dispatches a shape to (host arithmetic, no GPU needed).  Large shapes -> the 256^2 tile
+// (one workgroup per CU: 8-wave phased kernel, or its 4-wave form for deep K), unless its tiles would leave more than half of
+// the CUs idle (M ~ 1e3: the text encoder, the VAE's attention block): four times as many 128^2 tiles at two per CU fill the
+// chip better.  gemm_variant = 1|2 is a developer A/B switch (wan_set_tuning), not a product option.
+extern "C" int wan_gemm_plan(int M, int N, int K) {
+    const int variant = wan_tune(WAN_TUNE_GEMM_VARIANT);
+    const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = M >= 1024 && N >= 256 && 2 * tiles256 > wan_cu_count();
+    if (!(variant == 2 || (variant == 0 && big))) return WAN_GEMM_VARIANT_128;
+    return wan_gemm256_uses_w4(K) ? WAN_GEMM_VARIANT_256_W4 : WAN_GEMM_VARIANT_256_W8;
+}
+
 extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                       void* out, int64_t ldo, int M, int N, int K, int epilogue,
                                       const float* gate, int64_t rows_per_batch, void* stream) {
@@ -275,16 +289,8 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
     WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
                 "wan_gemm_bf16: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
     if (M == 0) return WAN_OK;
-    {   // Large shapes -> 256^2 phased kernel (one workgroup per CU), unless its tiles would leave more than half of
-        // the CUs idle (M ~ 1e3: the text encoder, the VAE's attention block): four times as many 128^2 tiles at two
-        // per CU fill the chip better.  gemm_variant = 1|2 is a developer A/B switch (wan_set_tuning), not a product option.
-        const int variant = wan_tune(WAN_TUNE_GEMM_VARIANT);
-        const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-        const bool big = M >= 1024 && N >= 256 && 2 * tiles256 > wan_cu_count();
-        if (variant == 2 || (variant == 0 && big))
-            return wan_gemm_bf16_256(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch,
-                                     (hipStream_t)stream);
-    }
+    if (wan_gemm_plan(M, N, K) != WAN_GEMM_VARIANT_128)
+        return wan_gemm_bf16_256(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, (hipStream_t)stream);
     GemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;

@@ -747,6 +747,12 @@ extern "C" wan_status_t wan_gemm_fp8(const void* A_fp8, int64_t lda, const float
     }
 }
 
+// the 4-wave form of the 256^2 tile for this K?  (host arithmetic; also behind wan_gemm_plan)
+bool wan_gemm256_uses_w4(int K) {
+    const int w4mode = wan_tune(WAN_TUNE_GEMM_W4);
+    return K % (2 * BK) == 0 && ((w4mode == 1 && K >= 4096) || (w4mode == 2 && K >= 8192) || w4mode == 3);
+}
+
 // called by wan_gemm_bf16 (gemm_bf16.hip) for large shapes; arguments already validated there
 wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                void* out, int64_t ldo, int M, int N, int K, int epilogue,
@@ -765,8 +771,7 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     // batched epilogues the 4-wave kernel is ahead on every 14B shape in process (o/q 2.675 vs 2.686 ms, q|k 5.43 vs 5.46, ffn.0
     // 7.33 vs 7.68, ffn.2 7.72 vs 7.98; 8-way shards +3..7 %) and by 0.45 % of a whole step in situ
     // (profiles/r02/gemm_epilogue_ab.txt); at K = 1536 it loses 10-15 % (profiles/r02/gemm_w4_ab.log).
-    const int w4mode = wan_tune(WAN_TUNE_GEMM_W4);
-    const bool w4 = K % (2 * BK) == 0 && ((w4mode == 1 && K >= 4096) || (w4mode == 2 && K >= 8192) || w4mode == 3);
+    const bool w4 = wan_gemm256_uses_w4(K);
 #define WAN_G256(E) (w4 ? launch_w4<E>(g, s) : phases == 4 ? launch256<E, 4>(g, s) : launch256<E, 2>(g, s))
     switch (epilogue) {
         case WAN_EPI_BF16: return WAN_G256(WAN_EPI_BF16);
