@@ -176,6 +176,42 @@ def test_graph_replay_is_bit_identical(golden, model):
     assert model.mask_source_frames == 0 and model._ctx_cache is None          # the pipeline restored the model
 
 
+def test_whole_loop_graph_is_bit_identical(golden, model):
+    """capture_graph='loop': every step's forward, the CFG combine, the CoF mask and the UniPC update of the whole denoise loop
+    (pipeline_wan.py:694-740) recorded as ONE hipGraph.  Call 1 of a signature is eager, call 2 captures + replays, later calls
+    replay -- with another prompt (other length: the embeddings live zero-padded in a static buffer), other latents, and with
+    CFG (its own signature).  All of them give the SAME BITS as the eager loop."""
+    from videocof_amd import GraphedLoop
+    g = golden("dit_g8_cof_loop")
+    lat = torch.cat([torch.from_numpy(g["src"]), torch.from_numpy(g["noise"])], dim=2).to(DEV)
+    lat2 = lat.clone()
+    lat2[:, :, 3:] = lat[:, :, 3:].flip(-1)
+    ctx_a = torch.from_numpy(g["ctx"]).to(DEV)
+    ctx_b = (ctx_a[:5] * 0.7).contiguous()                       # another prompt, another token count
+    kw = dict(source_frames=9, reasoning_frames=4, num_inference_steps=4, shift=3, repeat_rope=True, cot=True,
+              output_type="latent", weight_dtype=torch.float32)
+
+    def run(pipe, latents, ctx, graph, scale=1.0):
+        return pipe(latents=latents, prompt_embeds=[ctx], negative_prompt_embeds=[ctx_a * 0.5] if scale > 1 else None,
+                    guidance_scale=scale, capture_graph=graph, **kw).latents
+
+    eager = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    looped = WanPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+    want = [run(eager, lat, ctx_a, False), run(eager, lat, ctx_a, False), run(eager, lat2, ctx_b, False)]
+    want_cfg = run(eager, lat, ctx_a, False, 3.0)
+    got = [run(looped, lat, ctx_a, "loop"), run(looped, lat, ctx_a, "loop"), run(looped, lat2, ctx_b, "loop")]
+    assert isinstance(looped._graphed_loop, GraphedLoop) and looped._graphed_loop.replays == 2      # eager, capture + replay, replay
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[0], got[2])
+    got_cfg = [run(looped, lat, ctx_a, "loop", 3.0) for _ in range(3)]
+    assert looped._graphed_loop.replays == 4 and all(torch.equal(x, want_cfg) for x in got_cfg)
+    assert torch.equal(run(looped, lat, ctx_a, "loop"), want[0])                                    # back to the first signature
+    assert model.mask_source_frames == 0 and model._ctx_cache is None
+    with pytest.raises(NotImplementedError, match="callback"):
+        looped(latents=lat, prompt_embeds=[ctx_a], guidance_scale=1.0, capture_graph="loop", callback_on_step_end=lambda *a: None, **kw)
+
+
 def test_graph_entries_pin_their_buffers_and_follow_the_model(model):
     """A captured graph replays raw device addresses.  (i) Two call shapes A, B, A: shape B (and an eager call of yet another
     shape) must not free or reuse the workspaces graph A was captured with -- A's replay still equals the eager result, bitwise;

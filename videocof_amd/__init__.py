@@ -17,7 +17,7 @@ Device arithmetic lives in ``libwan_hip.so`` (csrc/, C ABI in include/wan_hip.h)
 from .fm_solvers_unipc import FlowUniPCMultistepScheduler  # noqa: F401
 from .pipeline_wan import WanPipeline, WanPipelineOutput  # noqa: F401
 from .wan_transformer3d import WanTransformer3DModel  # noqa: F401
-from .graph import GraphedForward  # noqa: F401
+from .graph import GraphedForward, GraphedLoop  # noqa: F401
 from .cache_utils import TeaCache, get_teacache_coefficients  # noqa: F401
 from .attention_utils import attention, flash_attention  # noqa: F401
 from .wan_vae import AutoencoderKLWan  # noqa: F401

@@ -27,7 +27,7 @@ from typing import Dict, Optional
 
 import torch
 
-__all__ = ["GraphedForward"]
+__all__ = ["GraphedForward", "GraphedLoop"]
 
 
 class _Entry:
@@ -121,3 +121,91 @@ class GraphedForward:
             return ent.out.clone()
         finally:
             m.cache_context = prev
+
+
+class _LoopEntry:
+    __slots__ = ("x", "ctx", "graph", "out", "calls", "epoch", "bufs", "attn_bufs", "keep")
+
+
+class GraphedLoop:
+    """The WHOLE denoise loop of ``WanPipeline.__call__`` (pipeline_wan.py:694-740: every step's forward, the CFG combine, the CoF
+    mask and the UniPC update) as ONE hipGraph per call signature.  ``GraphedForward`` replays one forward and leaves the
+    scheduler update and the CFG arithmetic eager between replays -- ~10 % of a step at launch-bound shapes; here a video is one
+    graph launch.
+
+    What makes it capturable: the sampler's coefficients are host float64 scalars that depend only on (steps, shift) -- they are
+    baked into the captured ``wan_lincomb`` launches; the timesteps are device tensors kept alive by the entry; the latents and the
+    prompt embeddings (zero-padded to ``text_len`` rows, which is what the text embedding does with them anyway) live in static
+    buffers refreshed before each replay; the text K/V are computed INSIDE the graph by the first forward and reused by the later
+    steps.  Call 1 of a signature runs eagerly (it allocates the workspaces and returns the result), call 2 captures and replays,
+    later calls replay.  Entries pin their workspaces and follow the model's ``_graph_epoch`` exactly like ``GraphedForward``'s."""
+
+    def __init__(self, model):
+        if model.sp_world_size != 1:
+            raise NotImplementedError("graph capture covers the single-device forward (collectives stay eager)")
+        self.model = model
+        self._entries: Dict[tuple, _LoopEntry] = {}
+        self.replays = 0
+
+    def reset(self) -> None:
+        for ent in self._entries.values():
+            if ent.bufs is not None:
+                ent.bufs.pinned = False
+        self._entries.clear()
+
+    def __del__(self):
+        try:
+            self.reset()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def __call__(self, key: tuple, latents: torch.Tensor, context, loop_fn, keep=()):
+        """``loop_fn(latents, context) -> final latents`` runs the loop (eagerly or under capture); ``keep``: objects whose device
+        memory the captured launches read (the scheduler's timestep tensor) -- held by the entry."""
+        m = self.model
+        if m.teacache is not None:
+            raise NotImplementedError("TeaCache decides per step on the host whether the blocks run: not capturable")
+        T, D = m.text_len, m.text_dim
+        key = key + (tuple(latents.shape), latents.dtype, len(context), torch.cuda.current_device(), tuple(m._fp8),
+                     bool(m.use_block_composite), bool(m.use_forward_composite), int(m.skip_source_frames), int(m.mask_source_frames))
+        epoch = m._graph_epoch
+        for k in [k for k, e in self._entries.items() if e.epoch != epoch]:
+            stale = self._entries.pop(k)
+            if stale.bufs is not None:
+                stale.bufs.pinned = False
+        ent = self._entries.get(key)
+        if ent is None:
+            ent = self._entries[key] = _LoopEntry()
+            ent.x, ent.ctx, ent.graph, ent.out, ent.calls, ent.epoch = None, None, None, None, 0, epoch
+            ent.bufs, ent.attn_bufs, ent.keep = None, None, None
+        ent.calls += 1
+        if ent.calls == 1:
+            return loop_fn(latents, context)                 # eager: the result of this call, and the warm-up of the capture
+        if ent.graph is None:
+            ent.x = torch.empty_like(latents)
+            ent.ctx = [torch.zeros(T, D, device=latents.device, dtype=u.dtype) for u in context]
+            ent.keep = tuple(keep)
+        ent.x.copy_(latents)
+        for buf, u in zip(ent.ctx, context):
+            if u.shape[0] > T or u.shape[1] != D:
+                raise ValueError(f"context has shape {tuple(u.shape)}; expected [<= {T}, {D}]")
+            buf[:u.shape[0]].copy_(u)
+            buf[u.shape[0]:].zero_()
+        if ent.graph is None:
+            m._ctx_cache = None                              # the text K/V are recorded as part of the graph
+            events, m._attn_events = m._attn_events, None
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    ent.out = loop_fn(ent.x, ent.ctx)
+            finally:
+                m._attn_events = events
+            ent.graph = graph
+            ent.bufs = m._bufs[m._bufs_last]
+            ent.bufs.pinned = True
+            ent.attn_bufs = [ws.buf for ws in (m._ws_self, m._ws_cross, m._ws_self_sfx, m._ws_cross_sfx)]
+        ent.graph.replay()
+        self.replays += 1
+        return ent.out.clone()

@@ -52,6 +52,7 @@ class WanPipeline:
         self._num_timesteps = 0
         self._interrupt = False
         self._graphed = None
+        self._graphed_loop = None
 
     guidance_scale = property(lambda self: self._guidance_scale)
     num_timesteps = property(lambda self: self._num_timesteps)
@@ -160,7 +161,7 @@ class WanPipeline:
                  # extensions of this package (keyword-only in spirit; the names above are the reference's, :516-548)
                  source_latents: Optional[torch.Tensor] = None, device=None,
                  weight_dtype: torch.dtype = torch.bfloat16, cache_context: bool = True,
-                 skip_source_prediction: bool = True, capture_graph: bool = False):
+                 skip_source_prediction: bool = True, capture_graph=False):
         if timesteps is not None:
             raise NotImplementedError("custom `timesteps` are not supported (the reference's CLIs never pass them)")
         if num_videos_per_prompt != 1:
@@ -210,7 +211,9 @@ class WanPipeline:
         if prev_mask is not None:
             self.transformer.mask_source_frames = condition_count
         forward = self.transformer
-        if capture_graph:
+        if capture_graph not in (False, True, "step", "loop"):
+            raise ValueError(f"capture_graph={capture_graph!r}: False, True / 'step' (one hipGraph per forward) or 'loop' (the whole loop)")
+        if capture_graph in (True, "step"):
             # one hipGraph per call shape, kept across calls (videocof_amd/graph.py): step 0 of the first call runs
             # eagerly, step 1 is captured, every later step (and call) is a replay -- bit-identical latents
             if self._graphed is None or self._graphed.model is not self.transformer:
@@ -218,7 +221,10 @@ class WanPipeline:
                 self._graphed = GraphedForward(self.transformer)
             forward = self._graphed
 
-        try:
+        use_rope_map = repeat_rope and (video is not None or source_latents is not None or latents is not None)
+
+        def denoise(latents, embeds):
+            """The loop of :694-740 on `latents` with the prompt embeddings `embeds`; eager, or recorded into a hipGraph."""
             for i, t in enumerate(timesteps):                                                   # :694
                 self.transformer.current_steps = i
                 if self._interrupt:
@@ -234,11 +240,11 @@ class WanPipeline:
                 # or `source_latents` (extension) carry the encoded source: such calls are treated like the reference
                 # treats the same call WITH its video; a call with none of the three has no source segment and keeps
                 # plain T2V positions.  Documented in INTEGRATION.md section B.
-                if repeat_rope and (video is not None or source_latents is not None or latents is not None):
+                if use_rope_map:
                     fsi = [condition_count] * nb                                                # :713
                     if cot:
                         gfi = [(condition_count, condition_count + ground_latent_count)] * nb  # :716-718
-                noise_pred = forward(x=latent_model_input, context=in_prompt_embeds, t=timestep,
+                noise_pred = forward(x=latent_model_input, context=embeds, t=timestep,
                                      seq_len=seq_len, frame_split_indices=fsi,
                                      ground_frame_indices=gfi)                                  # :721-728
                 if do_cfg:
@@ -252,6 +258,30 @@ class WanPipeline:
                     out = callback_on_step_end(self, i, t, {"latents": latents})
                     if out:
                         latents = out.pop("latents", latents)
+            return latents
+
+        try:
+            if capture_graph == "loop":
+                # the whole loop as ONE hipGraph (videocof_amd.GraphedLoop): first call of a signature eager, second captures
+                if callback_on_step_end is not None:
+                    raise NotImplementedError("capture_graph='loop' replays all steps in one launch: no per-step callback")
+                if not getattr(self.transformer, "cache_context", False):
+                    raise NotImplementedError("capture_graph='loop' needs cache_context (the text K/V are part of the graph)")
+                if self._graphed_loop is None or self._graphed_loop.model is not self.transformer:
+                    from .graph import GraphedLoop
+                    self._graphed_loop = GraphedLoop(self.transformer)
+                self.scheduler.set_begin_index(0)       # no device round trip (index_for_timestep) inside a capture
+                key = (int(num_inference_steps), float(shift), bool(do_cfg), float(guidance_scale) if do_cfg else 0.0,
+                       int(condition_count), int(ground_latent_count), bool(cot), bool(use_rope_map), int(seq_len),
+                       int(self.scheduler.config.solver_order), bool(self.scheduler.config.lower_order_final))
+
+                def loop_fn(lat, embeds):
+                    self.scheduler._reset()
+                    self.scheduler.set_begin_index(0)
+                    return denoise(lat, embeds)
+                latents = self._graphed_loop(key, latents, in_prompt_embeds, loop_fn, keep=(timesteps, self.scheduler.sigmas))
+            else:
+                latents = denoise(latents, in_prompt_embeds)
         finally:
             if hasattr(self.transformer, "cache_context"):
                 self.transformer.cache_context = prev_cache
