@@ -300,6 +300,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward + CoF mask from a hipGraph (videocof_amd.GraphedForward; text K/V hoisted out of "
                          "the step as WanPipeline does).  For launch-bound small shapes; never the headline line.")
+    ap.add_argument("--graph-loop", action="store_true",
+                    help="replay the WHOLE K-step loop (forwards, CoF mask, UniPC updates) from ONE hipGraph "
+                         "(videocof_amd.GraphedLoop = WanPipeline(capture_graph='loop')).  For launch-bound small shapes.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -377,16 +380,33 @@ def main():
         model.mask_source_frames = Fs                # the CoF mask inside the captured unpatchify kernel
         prof = model._attn_events = None             # HIP events cannot be recorded inside a replayed graph
 
+    gloop = None
+    if args.graph_loop:
+        if sp or args.graph:
+            raise SystemExit("--graph-loop covers the single-device forward and excludes --graph")
+        from videocof_amd import GraphedLoop
+        gloop = GraphedLoop(model)
+        model.cache_context = True                   # the text K/V are computed once per loop, inside the graph
+        model.mask_source_frames = Fs
+        prof = model._attn_events = None
+
     def run(n_steps):
         nonlocal latents
         sched.set_timesteps(max(n_steps, 1), device=dev, shift=3)
-        lat = latents
-        for t in sched.timesteps[:n_steps]:
-            v = fwd(lat, t.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
-            if cof and not args.graph:
-                v[:, :, :Fs] = 0
-            lat = sched.step(v, t, lat, return_dict=False)[0]
-        return lat
+
+        def loop(lat, c):
+            if gloop is not None:
+                sched._reset()
+                sched.set_begin_index(0)             # no device round trip inside a capture
+            for t in sched.timesteps[:n_steps]:
+                v = fwd(lat, t.expand(1), c, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+                if cof and not args.graph and gloop is None:
+                    v[:, :, :Fs] = 0
+                lat = sched.step(v, t, lat, return_dict=False)[0]
+            return lat
+        if gloop is not None:
+            return gloop((n_steps,), latents, ctx, loop, keep=(sched.timesteps,))
+        return loop(latents, ctx)
 
     def fence():
         torch.cuda.synchronize()
@@ -394,7 +414,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.warmup > 0:
+    if args.graph_loop:
+        run(args.steps)                              # eager call of this signature
+        run(args.steps)                              # capture + first replay
+    elif args.warmup > 0:
         run(max(args.warmup, 2) if args.graph else args.warmup)      # graph: one eager call + the capture
     if prof is not None:
         prof.clear()
@@ -415,7 +438,7 @@ def main():
 
     # ---------------- parity of this run's own forward (untimed): probe the last block, compare with the oracle
     parity = None
-    if not args.no_verify and not sp and rank == 0:
+    if not args.no_verify and not sp and rank == 0 and not args.graph_loop:
         model._attn_events = None
         model.mask_source_frames = 0
         model._probe_layer = wl["num_layers"] - 1
@@ -490,7 +513,7 @@ def main():
             "what": "HIP events on the compute stream around (i) wait_k / wait_v / V^T unpack / wait_q before attention and "
                     "(ii) the inverse (o) exchange; the k and V^T exchanges themselves run under the V and q projections"},
         "parity": parity,
-        "graph": bool(args.graph),
+        "graph": "loop" if args.graph_loop else bool(args.graph),
         "attn_stress": bool(args.attn_stress),
     }
     if rank == 0:
