@@ -245,6 +245,36 @@ wan_status_t wan_sp_pack_heads(const void* x_bf16, int64_t ldx, void* wire, int 
 wan_status_t wan_sp_unpack_heads(const void* wire, void* x_bf16, int64_t ldx, int P, int T, int B, int Cl, void* stream);
 wan_status_t wan_sp_unpack_vt(const void* wire, void* vt_bf16, int64_t ldvt, int P, int B, int Cl, int T, void* stream);
 
+/* a21' The collective itself, owned by the library (for a host without torch.distributed; the Python host may use either):
+ *      one communicator = one RCCL comm + ONE side HIP stream + two events.
+ *      replaces: set_multi_gpus_devices / init_distributed_environment (dist/fuser.py:35-54) and the head all-to-all inside
+ *                xFuserLongContextAttention (dist/wan_xfuser.py:68-111).
+ *      wan_sp_unique_id: rank 0 creates the 128-byte rendezvous token; the host distributes it (MPI, a file, torchrun's store).
+ *      wan_sp_init: collective over all ranks (ncclCommInitRank) on the CURRENT HIP device; wan_sp_init_from_comm adopts an
+ *                existing ncclComm_t (not destroyed by wan_sp_destroy).
+ *      wan_sp_a2a_scatter_heads / wan_sp_a2a_gather_heads: the same operation on the wire layouts above -- slab d of `send_wire`
+ *                (bytes_total / world_size bytes) goes to rank d, slab s of `recv_wire` arrives from rank s; the first name is
+ *                for q / k / V^T (token shards -> head shards), the second for o (back).  ASYNCHRONOUS: enqueued on the side
+ *                stream behind everything already enqueued on `compute_stream`; the caller goes on enqueueing the next
+ *                projection and calls
+ *      wan_sp_wait before the kernel that reads the receive buffers: `compute_stream` then waits (on the device) for every
+ *                exchange started so far.  The host is never synchronised.  send / receive buffers must be distinct and stay
+ *                untouched between start and wait (persistent pairs, as videocof_amd/wan_transformer3d.py keeps them).
+ *      wan_sp_all_gather: recv[r] <- send of rank r (the head output, wan_transformer3d.py:1085-1086); also asynchronous.
+ *      RCCL is bound at run time (dlopen "librccl.so.1"): WAN_ERR_UNSUPPORTED if it cannot be loaded. */
+typedef struct wan_sp_comm wan_sp_comm;
+#define WAN_SP_UNIQUE_ID_BYTES 128
+wan_status_t wan_sp_unique_id(void* id128);
+wan_status_t wan_sp_init(wan_sp_comm** comm, const void* id128, int rank, int world_size);
+wan_status_t wan_sp_init_from_comm(wan_sp_comm** comm, void* nccl_comm, int rank, int world_size);
+int wan_sp_rank(const wan_sp_comm* comm);
+int wan_sp_world_size(const wan_sp_comm* comm);
+wan_status_t wan_sp_a2a_scatter_heads(wan_sp_comm* comm, const void* send_wire, void* recv_wire, int64_t bytes_total, void* compute_stream);
+wan_status_t wan_sp_a2a_gather_heads(wan_sp_comm* comm, const void* send_wire, void* recv_wire, int64_t bytes_total, void* compute_stream);
+wan_status_t wan_sp_all_gather(wan_sp_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* compute_stream);
+wan_status_t wan_sp_wait(wan_sp_comm* comm, void* compute_stream);
+wan_status_t wan_sp_destroy(wan_sp_comm* comm);
+
 /* ---------------------------------------------------------------------------
  * a11  One WanAttentionBlock as a single call (WanAttentionBlock.forward, wan_transformer3d.py:464-515) -- the
  *      composite a non-Python host drives: LN-modulate -> q|k GEMM -> RMSNorm+RoPE (q pre-scaled) -> V^T GEMM ->

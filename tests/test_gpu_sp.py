@@ -181,6 +181,62 @@ def test_sp_async_path_over_rccl_on_one_gpu():
     print(f"rccl world_size=1: rel={rel:.2e} bitwise_vs_single={bitwise_single} exposed_comm={ms:.2f} ms over {n_ev} windows")
 
 
+def _library_comm_worker(q_out):
+    """The Ulysses branch over the communicator the LIBRARY owns (wan_sp_*: RCCL bound by dlopen, one side stream, two events),
+    one rank, no torch.distributed at all."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    from videocof_amd import WanTransformer3DModel
+    from videocof_amd import dist as vdist
+    from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+    heads, layers = 4, 4
+    cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=layers, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=layers, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+    lat = det_uniform("sp.lat", (2, 16, 7, 12, 20), 1.0).cuda()
+    ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda(), det_uniform("sp.c1", (5, 64), 1.0).cuda()]
+    t = torch.tensor([749, 749], device="cuda:0")
+    kw = dict(frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
+    single = m(lat, t, ctx, 420, **kw)
+    comm = vdist.init_sequence_parallel(backend="library", rank=0, world_size=1)
+    assert isinstance(comm, vdist.LibraryComm) and comm.world_size == 1 and not torch.distributed.is_initialized()
+    m.enable_multi_gpus_inference()
+    m.force_ulysses = True
+    outs = [m(lat, t, ctx, 420, **kw) for _ in range(3)]
+    # the raw calls: an exchange of a known pattern on a side stream behind a compute-stream producer, and the error paths
+    a = torch.arange(1 << 20, device="cuda:0", dtype=torch.int32)
+    send = a * 3                                             # producer on the compute stream, right before the exchange
+    recv = torch.zeros_like(send)
+    wait = comm.exchange(recv, send, async_op=True)
+    wait()
+    ok_raw = bool(torch.equal(recv, a * 3))
+    gathered = comm.all_gather_tokens(torch.ones(2, 5, 3, device="cuda:0"))
+    try:
+        comm.exchange(send, send)
+        inplace_error = ""
+    except ValueError as e:
+        inplace_error = str(e)
+    torch.cuda.synchronize()
+    vdist.destroy_sequence_parallel()
+    q_out.put((float((outs[0] - single).norm() / single.norm()), all(bool(torch.equal(o, outs[0])) for o in outs[1:]), ok_raw,
+               tuple(gathered.shape), inplace_error))
+
+
+def test_sp_over_the_library_owned_communicator():
+    """`wan_sp_init`, `wan_sp_a2a_*`, one library-owned side stream + events.  One rank (RCCL refuses two ranks on one
+    device), so the exchanges are identities -- what is exercised is the whole path: dlopen of RCCL, communicator set-up, the
+    compute-stream -> side-stream -> compute-stream event chain around every exchange of every layer, teardown."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_library_comm_worker, args=(q,))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    rel, repeat, ok_raw, gshape, inplace_error = q.get(timeout=5)
+    assert rel < 2e-3 and repeat and ok_raw and gshape == (2, 5, 3)
+    assert "in-place" in inplace_error
+
+
 def _shard_shape_worker(rank, world, port, q_out):
     """14B width (40 heads -> 5 per rank at P = 8: no XCD pinning, split-KV tail round on), L = 16 384."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"

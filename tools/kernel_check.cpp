@@ -422,6 +422,29 @@ int main(int argc, char** argv) {
     }
     if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
     if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
+    if (mode == "sp") {           // the library-owned communicator from a C host: one rank, a pattern through both collectives
+        unsigned char uid[WAN_SP_UNIQUE_ID_BYTES];
+        WAN(wan_sp_unique_id(uid));
+        wan_sp_comm* comm = nullptr;
+        WAN(wan_sp_init(&comm, uid, 0, 1));
+        const size_t n = 1 << 22;
+        std::vector<bf16> h(n); for (size_t i = 0; i < n; ++i) h[i] = (bf16)(i * 2654435761u >> 16);
+        Dev<bf16> send(h), recv(n), gath(n);
+        recv.zero();
+        hipStream_t cs; HIP(hipStreamCreate(&cs));
+        WAN(wan_sp_a2a_scatter_heads(comm, send.p, recv.p, (int64_t)n * 2, cs));
+        WAN(wan_sp_all_gather(comm, send.p, gath.p, (int64_t)n * 2, cs));
+        WAN(wan_sp_wait(comm, cs));
+        HIP(hipStreamSynchronize(cs));
+        report("wan_sp_a2a_scatter_heads (1 rank: identity)", recv.host() == h ? 0.0 : 1.0, 0.0, "mismatch");
+        report("wan_sp_all_gather (1 rank: identity)", gath.host() == h ? 0.0 : 1.0, 0.0, "mismatch");
+        report("rank / world", (wan_sp_rank(comm) == 0 && wan_sp_world_size(comm) == 1) ? 0.0 : 1.0, 0.0, "mismatch");
+        const bool rejects = wan_sp_a2a_gather_heads(comm, send.p, send.p, 64, cs) == WAN_ERR_INVALID;
+        report("in-place exchange rejected", rejects ? 0.0 : 1.0, 0.0, "mismatch");
+        WAN(wan_sp_destroy(comm));
+        HIP(hipStreamDestroy(cs));
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+    }
     if (mode == "attnarms") {     // check_attn under every dispatch arm of wan_attention_fwd
         struct Arm { const char* name; int w4, fast, ref; };
         for (Arm arm : {Arm{"w4 lazy, reference in the accumulator", 1, 0, 1}, Arm{"w4 lazy, packed shift", 1, 0, 2},

@@ -109,6 +109,16 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
     "wan_attention_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "wan_sp_unique_id": (c_int, [c_void_p]),
+    "wan_sp_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "wan_sp_init_from_comm": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "wan_sp_rank": (c_int, [c_void_p]),
+    "wan_sp_world_size": (c_int, [c_void_p]),
+    "wan_sp_a2a_scatter_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_sp_a2a_gather_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_sp_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_sp_wait": (c_int, [c_void_p, c_void_p]),
+    "wan_sp_destroy": (c_int, [c_void_p]),
     "wan_attention_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "wan_gemm_plan": (c_int, [c_int, c_int, c_int]),
     "wan_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),

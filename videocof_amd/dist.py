@@ -148,6 +148,69 @@ class SequenceParallelGroup:
         return torch.cat(parts, dim=1)
 
 
+class LibraryComm:
+    """The same exchange interface on the communicator libwan_hip.so owns (``wan_sp_*``, include/wan_hip.h a21'): an RCCL comm, one
+    side HIP stream and two events inside the library -- what a host without torch.distributed drives.  Here it is an alternative
+    transport for the Python host (``init_sequence_parallel(backend="library")``): the rendezvous token travels through an existing
+    torch.distributed group (any backend; gloo is enough) or is not needed at all for a single rank."""
+
+    def __init__(self, rank: Optional[int] = None, world_size: Optional[int] = None, group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        lib = _lib.load()
+        if world_size is None:
+            world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = (ctypes.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(lib.wan_sp_unique_id(uid), "wan_sp_unique_id")
+        if world_size > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        self._comm = ctypes.c_void_p()
+        _lib.check(lib.wan_sp_init(ctypes.byref(self._comm), uid, int(rank), int(world_size)), "wan_sp_init")
+        self.rank, self.world_size, self.group = int(rank), int(world_size), group
+        self._host_staged = False
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def exchange(self, recv: torch.Tensor, send: torch.Tensor, async_op: bool = False):
+        if send.numel() != recv.numel() or send.numel() % self.world_size or not (send.is_contiguous() and recv.is_contiguous()):
+            raise ValueError("exchange: send / recv must be contiguous, of equal size, divisible by the group size")
+        lib, vp = self._lib.load(), self._ct.c_void_p
+        self._lib.check(lib.wan_sp_a2a_scatter_heads(self._comm, vp(send.data_ptr()), vp(recv.data_ptr()),
+                                                     send.numel() * send.element_size(), self._stream()), "wan_sp_a2a_scatter_heads")
+        wait = lambda: self._lib.check(lib.wan_sp_wait(self._comm, self._stream()), "wan_sp_wait")
+        if async_op:
+            return wait
+        wait()
+        return None
+
+    def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
+        P = self.world_size
+        y = y.contiguous()
+        recv = torch.empty((P,) + tuple(y.shape), device=y.device, dtype=y.dtype)
+        lib, vp = self._lib.load(), self._ct.c_void_p
+        self._lib.check(lib.wan_sp_all_gather(self._comm, vp(y.data_ptr()), vp(recv.data_ptr()), y.numel() * y.element_size(),
+                                              self._stream()), "wan_sp_all_gather")
+        self._lib.check(lib.wan_sp_wait(self._comm, self._stream()), "wan_sp_wait")
+        return torch.cat(list(recv), dim=1)
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.load().wan_sp_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def get_sp_group() -> Optional[SequenceParallelGroup]:
     return _SP
 
@@ -160,15 +223,23 @@ def get_sequence_parallel_rank() -> int:
     return _SP.rank if _SP is not None else 0
 
 
-def init_sequence_parallel(group=None) -> SequenceParallelGroup:
-    """Use an already initialised process group (or WORLD) as the Ulysses group."""
+def init_sequence_parallel(group=None, backend: str = "torch", rank: Optional[int] = None, world_size: Optional[int] = None):
+    """Use an already initialised process group (or WORLD) as the Ulysses group.  ``backend="library"``: the collectives run on
+    the communicator libwan_hip.so owns (``LibraryComm``); the torch group, if any, only carries the rendezvous token."""
     global _SP
-    _SP = SequenceParallelGroup(group)
+    if backend == "library":
+        _SP = LibraryComm(rank, world_size, group)
+    elif backend == "torch":
+        _SP = SequenceParallelGroup(group)
+    else:
+        raise ValueError(f"init_sequence_parallel: backend {backend!r} (\"torch\" or \"library\")")
     return _SP
 
 
 def destroy_sequence_parallel() -> None:
     global _SP
+    if isinstance(_SP, LibraryComm):
+        _SP.close()
     _SP = None
 
 
