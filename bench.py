@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of the last block")
+    ap.add_argument("--fp8-layers", default="qkv,ffn",
+                    help="with --fp8: comma-separated subset of qkv,ffn,o,cross (all four = every per-token Linear of a block)")
     ap.add_argument("--fp8", action="store_true",
                     help="run the q|k, v, ffn.0 and ffn.2 projections in OCP e4m3 (WanTransformer3DModel.enable_fp8_linear): a "
                          "LOSSY option with its own error statement; the line says so in `dtype` and is never the headline")
@@ -350,7 +352,7 @@ def main():
     if args.fp8:
         if sp:
             raise SystemExit("--fp8 covers the single-device forward")
-        model.enable_fp8_linear(("qkv", "ffn"))
+        model.enable_fp8_linear(tuple(args.fp8_layers.split(",")))
     if sp:
         vdist.init_sequence_parallel()
         model.enable_multi_gpus_inference()
@@ -492,7 +494,7 @@ def main():
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "strong" if sp or world == 1 else "weak", "vs_baseline": None,
-        "dtype": "fp8-e4m3 (q|k, v, ffn.0, ffn.2 projections) + bf16 (attention, o, cross-attention); LOSSY option, not the headline"
+        "dtype": f"fp8-e4m3 projections ({args.fp8_layers}) + bf16 (attention, the rest); LOSSY option, not the headline"
                  if args.fp8 else "bf16",
         "data": "synthetic (random-init weights, N(0,1) latents + text embeddings)",
         "config": {"workload": wl["desc"], "layout": "VideoCoF (src|ground|tgt)" if cof else "T2V",

@@ -160,14 +160,18 @@ def test_fp8_mode_14b_width_block_error_statement():
     f8 = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
     m.enable_fp8_linear(("ffn",))
     f8_ffn = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
+    m.enable_fp8_linear(("qkv", "ffn", "o", "cross"))            # every per-token Linear of the block (fp8_optimization.py:19-57)
+    f8_all = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
     m.disable_fp8_linear()
     osd = {k: v.detach().float() for k, v in m.state_dict().items()}
     ref = O.block_forward(x[0], e[0], ctx[0], osd, 0, cfg, grid, O.rope_angles(128), 4, (4, 5), L)
     m.release_workspaces()
     u_ref = ref - x[0]
-    res = {name: (rel_l2(out, ref), rel_l2(out - x[0], u_ref)) for name, out in (("bf16", bf), ("fp8 ffn", f8_ffn), ("fp8 qkv+ffn", f8))}
+    res = {name: (rel_l2(out, ref), rel_l2(out - x[0], u_ref)) for name, out in (("bf16", bf), ("fp8 ffn", f8_ffn), ("fp8 qkv+ffn", f8),
+                                                                                 ("fp8 all", f8_all))}
     for name, (s_, u_) in res.items():
         print(f"14B-width block, L=8192, {name:12s}: residual stream rel-L2 {s_:.2e}, block update rel-L2 {u_:.2e}")
     assert res["bf16"][1] < 3e-2
     assert res["fp8 ffn"][1] < 8e-2 and res["fp8 qkv+ffn"][1] < 1.2e-1
     assert res["fp8 qkv+ffn"][0] < 5e-2
+    assert res["fp8 all"][1] < 1.5e-1 and res["fp8 all"][0] < 6e-2 and not torch.equal(f8_all, f8)

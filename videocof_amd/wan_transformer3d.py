@@ -334,12 +334,16 @@ class WanTransformer3DModel(nn.Module):
         "model_cpu_offload_and_qfloat8"``) stores weights as e4m3 and up-casts them to bf16 for every matmul; here the named
         projections run on the fp8 matrix pipe: weights e4m3 with one scale per output channel (quantised once, now),
         activations e4m3 with one scale per token row (quantised inside the LN-modulate kernel, or by a row kernel for the
-        GELU output), fp32 accumulation.  ``layers``: "qkv" (self-attention q | k and v), "ffn" (ffn.0 and ffn.2).
+        GELU output), fp32 accumulation.  ``layers``: "qkv" (self-attention q | k and v), "ffn" (ffn.0 and ffn.2), "o" (the self- and
+        cross-attention output projections: their bf16 input, the attention kernel's output, takes one row-quantising pass) and
+        "cross" (the cross-attention query projection, fed by the quantising form of the norm3 kernel) -- all four together cover
+        every per-token Linear of a block, as the reference's fp8 mode does (fp8_optimization.py:19-57); the step-invariant text
+        K / V projections stay bf16.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
-        if not set(layers) <= {"qkv", "ffn"} or not layers:
-            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn'), got {layers}")
+        if not set(layers) <= {"qkv", "ffn", "o", "cross"} or not layers:
+            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn', 'o', 'cross'), got {layers}")
         if self.dim % 128 or self.ffn_dim % 128:
             raise NotImplementedError("fp8 projections need dim and ffn_dim to be multiples of 128")
         for blk in self.blocks:
@@ -348,6 +352,10 @@ class WanTransformer3DModel(nn.Module):
                 blk.f8["qk"], blk.f8["v"] = ops.quantize_weight_fp8(blk.w_qk), ops.quantize_weight_fp8(blk.w_v)
             if "ffn" in layers:
                 blk.f8["w1"], blk.f8["w2"] = ops.quantize_weight_fp8(blk.w1), ops.quantize_weight_fp8(blk.w2)
+            if "o" in layers:
+                blk.f8["o"], blk.f8["co"] = ops.quantize_weight_fp8(blk.w_o), ops.quantize_weight_fp8(blk.w_co)
+            if "cross" in layers:
+                blk.f8["cq"] = ops.quantize_weight_fp8(blk.w_cq)
         self._fp8 = layers
         self._bufs, self._bufs_last = {}, None
         self._graph_epoch += 1              # new e4m3 tensors: a graph captured before must not replay the old ones
@@ -539,6 +547,9 @@ class WanTransformer3DModel(nn.Module):
             if "ffn" in self._fp8:
                 b.ffq = torch.empty(M, self.ffn_dim, device=dev, dtype=ops.FP8)
                 b.ffs = torch.empty(M, device=dev, dtype=torch.float32)
+            if "o" in self._fp8:
+                b.attq = torch.empty(M, C, device=dev, dtype=ops.FP8)
+                b.atts = torch.empty(M, device=dev, dtype=torch.float32)
         b.pinned = False
         self._bufs[key] = b
         self._bufs_last = key
@@ -625,14 +636,26 @@ class WanTransformer3DModel(nn.Module):
             self._comm_done(cev)
             ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B)
             o_in = att
-        ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
+        if "o" in f8:
+            ops.quantize_rows_fp8(o_in, out=bufs.attq, out_scale=bufs.atts)
+            ops.gemm_fp8(bufs.attq, bufs.atts, *f8["o"], blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
+        else:
+            ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
         # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
-        ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
-        ops.gemm(h, blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq)
+        if "cq" in f8:
+            ops.ln_modulate_fp8(xs, blk.n3w, blk.n3b, False, M, self.eps, out=bufs.hq, out_scale=bufs.rs)
+            ops.gemm_fp8(bufs.hq, bufs.rs, *f8["cq"], blk.b_cq, ops.EPI_BF16, out=cq)
+        else:
+            ops.ln_modulate(xs, blk.n3w, blk.n3b, False, M, self.eps, out=h)
+            ops.gemm(h, blk.w_cq, blk.b_cq, ops.EPI_BF16, out=cq)
         ops.rmsnorm_rope_(cq, blk.ncq, None, None, self.d, self.eps, x0_scale=self._qs)
         ck, cvt = ctx_kv
         ops.attention_fwd(cq.view(B, Ll, C), ck, cvt, H, out=att.view(B, Ll, C), q_prescaled=True, workspace=self._ws_cross)
-        ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
+        if "co" in f8:
+            ops.quantize_rows_fp8(att, out=bufs.attq, out_scale=bufs.atts)
+            ops.gemm_fp8(bufs.attq, bufs.atts, *f8["co"], blk.b_co, ops.EPI_RESID_F32, out=xs)
+        else:
+            ops.gemm(att, blk.w_co, blk.b_co, ops.EPI_RESID_F32, out=xs)
         # ---- FFN (:507-511)
         if "w1" in f8:
             ops.ln_modulate_fp8(xs, em[4], em[3], True, Ll, self.eps, out=bufs.hq, out_scale=bufs.rs)
