@@ -252,7 +252,7 @@ def _shard_shape_worker(rank, world, port, q_out):
         m = WanTransformer3DModel(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1)
         m.load_state_dict(random_dit_state_dict(dev, seed=3, exercise_epilogues=True, **shapes), device=dev)
         g = torch.Generator(device=dev).manual_seed(5)
-        lat = torch.randn(1, 16, 16, 64, 64, device=dev, generator=g).bfloat16()          # grid (16, 32, 32) = 16 384 tokens
+        lat = torch.randn(1, 16, 16, 64, 64, device=dev, generator=g)                     # grid (16, 32, 32) = 16 384 tokens; fp32 in -> fp32 out
         ctx = [torch.randn(37, 4096, device=dev, generator=g).bfloat16()]
         t = torch.tensor([500], device=dev)
         kw = dict(frame_split_indices=[7], ground_frame_indices=[(7, 8)])
