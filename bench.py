@@ -325,10 +325,21 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        # the collective libraries print connection banners on fd 1 ("[Gloo] Rank 0 is connected to ..."): keep stdout for the
+        # ONE JSON line and send whatever they print during set-up to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     wl = WORKLOADS[args.workload]
     sp = world > 1 and args.mode == "sp"
     if sp and wl["num_heads"] % world:
