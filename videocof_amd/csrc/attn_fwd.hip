@@ -59,7 +59,8 @@ struct AttnArgs {
     // (head, z) pair bh = 8 * ((w >> 3) / nqb) + (w & 7) pins every head to one XCD, whose 32 CUs walk that head's query
     // blocks together: one head's K / V^T (34 MB at L = 67 080) streams through ONE 4 MB L2 instead of all eight.
     int nqb, nbh, xcd_map;
-    int tile_mask;        // developer experiment (attn_exp): staging reads tile (t & tile_mask); 0x7fffffff in product
+    int tile_mask;        // developer experiment (attn_exp & 1): staging reads tile (t & tile_mask); 0x7fffffff in product
+    int exp_nocheck;      // developer experiment (attn_exp & 2), TIMING ONLY: the lazy form skips its per-tile window check
 };
 
 // VARIANT (template parameter of the kernel below) only names the instantiation so profiles separate the two
@@ -796,7 +797,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define QK(qb, kt, ks, f, w) do { if constexpr (MAXFREE) { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } \
                                   else { W4_LGKM(w); if ((ks) == 0) { if constexpr (SPLAT) W4A_MFMA_C(sn[qb][kt], fr[(f) & 3], qf[qb][0], negm[qb]); else W4A_MFMA0(sn[qb][kt], fr[(f) & 3], qf[qb][0]); } \
                                          else W4A_MFMA_S(sn[qb][kt], fr[(f) & 3], qf[qb][ks]); } SB(); } while (0)
-#define MIDCHECK() do { if constexpr (!MAXFREE) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } while (0)
+#define MIDCHECK() do { if constexpr (!MAXFREE) { if (a.exp_nocheck == 0) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } } while (0)
 #define PV(qb, dt, tt, f, w) do { if constexpr (MAXFREE) { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } \
                                   else { W4_LGKM(w); if ((tt) < 2) W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pc[qb][(tt) & 1]); else W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pf23[qb][(tt) & 1]); } SB(); } while (0)
 #define G(j) do { if ((j) < 4) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 4); } while (0)
@@ -1197,6 +1198,7 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     hipStream_t st = (hipStream_t)stream;
     const bool self = Lk > 1024;
     a.tile_mask = (wan_tune(WAN_TUNE_ATTN_EXP) & 1) ? 15 : 0x7fffffff;
+    a.exp_nocheck = (wan_tune(WAN_TUNE_ATTN_EXP) & 2) ? 1 : 0;
     if (wan_tune(WAN_TUNE_DEBUG_CHECKS) != 0) {       // synchronising contract check, developer builds / bring-up only
         const wan_status_t cs = check_vt_padding(a, batch, lk_pad, st);
         if (cs != WAN_OK) return cs;
