@@ -44,7 +44,7 @@ const char* wan_last_error(void);
 /* Developer switches (A/B harnesses, bring-up).  The matching environment variables (WAN_ATTN_TAIL, WAN_ATTN_FAST,
  * WAN_ATTN_XCD_MAP, WAN_ATTN_W4, WAN_ATTN_REF, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
  * read ONCE, at the first call into the library; the launch paths never call getenv().  Keys: "attn_tail",
- * "attn_fast", "attn_xcd_map", "attn_w4", "attn_ref", "conv_head", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
+ * "attn_fast", "attn_xcd_map", "attn_w4", "attn_ref", "conv_head", "gemm_exp", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
  * "debug_checks" = 1 turns on SYNCHRONISING contract checks (V^T pad columns of wan_attention_fwd are finite).
  * wan_set_tuning is an atomic store: safe against concurrent launches, which see the old or the new value.
  * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code).

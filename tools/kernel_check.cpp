@@ -422,6 +422,27 @@ int main(int argc, char** argv) {
     }
     if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
     if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
+    if (mode == "gemmx") {        // timing attribution of the 4-wave GEMM's main loop: with / without its LDS-DMA instructions
+        const int M = 67080;
+        struct S { int N, K, epi; const char* what; };
+        for (S sh : {S{10240, 5120, WAN_EPI_BF16, "qk proj"}, S{5120, 13824, WAN_EPI_RESID_F32, "ffn.2+resid"}}) {
+            auto hA = to_bf(randn((size_t)4096 * 64));
+            Dev<bf16> A((size_t)M * sh.K), W((size_t)sh.N * sh.K);
+            for (size_t off = 0; off < A.n; off += hA.size()) HIP(hipMemcpy(A.p + off, hA.data(), std::min(hA.size(), A.n - off) * 2, hipMemcpyHostToDevice));
+            for (size_t off = 0; off < W.n; off += hA.size()) HIP(hipMemcpy(W.p + off, hA.data(), std::min(hA.size(), W.n - off) * 2, hipMemcpyHostToDevice));
+            Dev<float> bias(sh.N), gate(sh.N); bias.zero(); gate.zero();
+            Dev<char> out((size_t)M * sh.N * 4); out.zero();
+            for (int round = 0; round < 2; ++round)
+                for (int e : {0, 1, 3}) {
+                    WAN(wan_set_tuning("gemm_exp", e));
+                    double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, sh.K, W.p, sh.K, bias.p, out.p, sh.N, M, sh.N, sh.K, sh.epi,
+                                                                sh.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, M, nullptr)); }, 3, 1);
+                    printf("  gemmx[%-12s gemm_exp=%d (%s)] %.3f ms  %.0f TFLOP/s\n", sh.what, e, e == 0 ? "product" : e == 1 ? "no W DMA" : "no DMA at all",
+                           ms, 2.0 * M * sh.N * sh.K / ms / 1e9);
+                }
+            WAN(wan_set_tuning("gemm_exp", 0));
+        }
+    }
     if (mode == "sp") {           // the library-owned communicator from a C host: one rank, a pattern through both collectives
         unsigned char uid[WAN_SP_UNIQUE_ID_BYTES];
         WAN(wan_sp_unique_id(uid));

@@ -54,6 +54,7 @@ struct GemmArgs {
     // FP8 instantiation (wan_gemm_fp8): A / W point at e4m3 bytes, lda / ldw count bytes = elements; the product of the
     // quantised operands is scaled by sa[m] * sw[n] (per-token, per-output-channel) before bias and epilogue
     const float* sa; const float* sw;
+    int exp;              // developer experiment (gemm_exp), TIMING ONLY: bit 0 / bit 1 = the 4-wave kernel's main loop skips its W / A tile DMA
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)min(kt, nk - 1) * BK * 2), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
+        if (g.exp & (operand ? 1 : 2)) return;          // timing experiment: what the DMA instructions cost the lone wave of a SIMD
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
             operand ? w_voff[j & 1] : a_voff[j & 1], (int)((j >> 1) * 16 * ld * 2), 0, 0);
@@ -733,7 +735,7 @@ extern "C" wan_status_t wan_gemm_fp8(const void* A_fp8, int64_t lda, const float
     GemmArgs g;
     g.A = (const bf16_t*)A_fp8; g.lda = lda; g.W = (const bf16_t*)W_fp8; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-    g.M = M; g.N = N; g.K = K; g.sa = a_row_scale; g.sw = w_row_scale;
+    g.M = M; g.N = N; g.K = K; g.sa = a_row_scale; g.sw = w_row_scale; g.exp = 0;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.gm = g.tiles_n >= 40 ? 2 : 3;
     hipStream_t s = (hipStream_t)stream;
@@ -760,7 +762,7 @@ wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_
     GemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-    g.M = M; g.N = N; g.K = K; g.sa = nullptr; g.sw = nullptr;
+    g.M = M; g.N = N; g.K = K; g.sa = nullptr; g.sw = nullptr; g.exp = wan_tune(WAN_TUNE_GEMM_EXP);
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     // M tiles per rasterisation group, measured at M = 67 080 (profiles/r01/gemm_raster_group_ab.log): 2 for wide N
     // (qk projection +5 %, ffn.0 +2 % over the former 4), 3 otherwise (+2 %); 8 and 16 lose 10-15 %.
