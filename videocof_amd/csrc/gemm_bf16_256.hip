@@ -54,7 +54,7 @@ struct GemmArgs {
     // FP8 instantiation (wan_gemm_fp8): A / W point at e4m3 bytes, lda / ldw count bytes = elements; the product of the
     // quantised operands is scaled by sa[m] * sw[n] (per-token, per-output-channel) before bias and epilogue
     const float* sa; const float* sw;
-    int exp;              // developer experiment (gemm_exp), TIMING ONLY: bit 0 / bit 1 = the 4-wave kernel's main loop skips its W / A tile DMA
+    int exp;              // developer experiment (gemm_exp), TIMING ONLY: bit 0 / bit 1 = the 4-wave kernel's main loop skips its W / A tile DMA, bit 2 = every DMA reads K tile 0 / 1 (cache hits)
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -454,7 +454,8 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     const int64_t w_bytes = ((int64_t)(min(g.N - n0, BN) - 1) * g.ldw + g.K) * 2;
     auto rsrc = [&](const char* tile, int64_t bytes, int kt) {
         const int64_t left = kt < nk ? bytes - (int64_t)kt * BK * 2 : 0;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)min(kt, nk - 1) * BK * 2), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
+        const int ke = (g.exp & 4) ? (min(kt, nk - 1) & 1) : min(kt, nk - 1);      // timing experiment: every request hits K tiles 0 / 1 (cache-resident)
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)ke * BK * 2), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
         if (g.exp & (operand ? 1 : 2)) return;          // timing experiment: what the DMA instructions cost the lone wave of a SIMD
