@@ -54,7 +54,7 @@ struct GemmArgs {
     // FP8 instantiation (wan_gemm_fp8): A / W point at e4m3 bytes, lda / ldw count bytes = elements; the product of the
     // quantised operands is scaled by sa[m] * sw[n] (per-token, per-output-channel) before bias and epilogue
     const float* sa; const float* sw;
-    int exp;              // developer experiment (gemm_exp), TIMING ONLY: bit 0 / bit 1 = the 4-wave kernel's main loop skips its W / A tile DMA, bit 2 = every DMA reads K tile 0 / 1 (cache hits)
+    int exp;              // developer experiment (gemm_exp), TIMING ONLY: bit 0 / bit 1 = the 4-wave kernel's main loop skips its W / A tile DMA, bit 2 = every DMA reads K tile 0 / 1 (cache hits), bit 3 (with bit 0) = the W bytes are fetched by plain register loads instead
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -458,7 +458,13 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)ke * BK * 2), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
-        if (g.exp & (operand ? 1 : 2)) return;          // timing experiment: what the DMA instructions cost the lone wave of a SIMD
+        if (g.exp & (operand ? 1 : 2)) {                // timing experiment: what the DMA instructions cost the lone wave of a SIMD
+            if ((g.exp & 8) && operand) {               // ... and what the same bytes cost as plain register loads (results discarded)
+                u32x4 sink;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(sink) : "v"(w_voff[j & 1]), "s"(r), "s"((int)((j >> 1) * 16 * ld * 2)));
+            }
+            return;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
             operand ? w_voff[j & 1] : a_voff[j & 1], (int)((j >> 1) * 16 * ld * 2), 0, 0);
