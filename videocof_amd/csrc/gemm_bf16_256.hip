@@ -487,6 +487,7 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     u32x4 af[2][4], wf[2][4];                // [k-step parity][block]
+    const bool early_w = (g.exp & 16) != 0;
 
 #define GW4_SB() __builtin_amdgcn_sched_barrier(0)
 // 12 of the 16 accumulator tiles (192 registers) are pinned to AGPRs, the last M block (4 tiles, 64 registers) to VGPRs:
@@ -496,8 +497,8 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
 #define GW4_MFMA(ACC, X, Y) do { if (i < 3) GW4_MFMA_A(ACC, X, Y); else GW4_MFMA_V(ACC, X, Y); } while (0)
     // k-step S of the K tile in LDS buffer `buf`: 16 MFMAs; the even slots fetch the fragments of the NEXT k-step (from
     // `nbuf`, k-step NS), the odd slots of the steps that carry DMA issue one piece each.
-    auto kstep = [&](auto S_, int buf, int nbuf, auto NS_, auto DMA_, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int dbuf)
-                     __attribute__((always_inline)) {
+    auto kstep = [&](auto S_, int buf, int nbuf, auto NS_, auto DMA_, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int dbuf,
+                     __amdgpu_buffer_rsrc_t rw2) __attribute__((always_inline)) {
         constexpr int S = decltype(S_)::value, NS = decltype(NS_)::value, DMA = decltype(DMA_)::value;   // DMA: 0 none, 1 pieces 0..7 (A), 2 pieces 8..15 (W)
         (void)buf;
 #pragma unroll
@@ -512,10 +513,12 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
                     const int f = slot / 2;
                     if (f < 4) af[NS & 1][f] = lds16(smem + a_base + f * 32 * 128 + koff[nbuf][NS]);
                     else wf[NS & 1][f - 4] = lds16(smem + w_base + (f - 4) * 32 * 128 + koff[nbuf][NS]);
+                    // experiment (gemm_exp & 16): the W pieces of tile kt+2 leave in k-step 3 of tile kt as well (one k-step more flight time)
+                    if (DMA == 1 && early_w) stage_piece(rw2, dbuf, 1, slot / 2, g.ldw);
                 } else if (DMA != 0) {
                     const int pj = slot / 2;
                     if (DMA == 1) stage_piece(ra, dbuf, 0, pj, g.lda);
-                    else stage_piece(rw, dbuf, 1, pj, g.ldw);
+                    else if (!early_w) stage_piece(rw, dbuf, 1, pj, g.ldw);
                 }
                 GW4_SB();
             }
@@ -533,6 +536,11 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         const __amdgpu_buffer_rsrc_t ra1 = rsrc(a_tile, a_bytes, 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage_piece(ra1, 1, 0, j, g.lda);       // its W half goes out in k-step 0 of tile 0
+        if (early_w) {
+            const __amdgpu_buffer_rsrc_t rw1 = rsrc(w_tile, w_bytes, 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage_piece(rw1, 1, 1, j, g.ldw);
+        }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             af[0][f] = lds16(smem + a_base + f * 32 * 128 + koff[0][0]);
@@ -545,13 +553,14 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     auto ktile = [&](int kt, int b) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rw_prev = rsrc(w_tile, w_bytes, kt + 1);      // W of tile kt+1 -> buffer 1-b (its A went out in tile kt-1)
         const __amdgpu_buffer_rsrc_t ra_next = rsrc(a_tile, a_bytes, kt + 2);      // A of tile kt+2 -> buffer b, after the barrier
-        kstep(I0{}, b, b, I1{}, I2{}, ra_next, rw_prev, 1 - b);
-        kstep(I1{}, b, b, I2{}, I0{}, ra_next, rw_prev, b);
-        kstep(I2{}, b, b, I3{}, I0{}, ra_next, rw_prev, b);
+        const __amdgpu_buffer_rsrc_t rw_next = rsrc(w_tile, w_bytes, kt + 2);      // experiment: W of tile kt+2 together with its A
+        kstep(I0{}, b, b, I1{}, I2{}, ra_next, rw_prev, 1 - b, rw_next);
+        kstep(I1{}, b, b, I2{}, I0{}, ra_next, rw_prev, b, rw_next);
+        kstep(I2{}, b, b, I3{}, I0{}, ra_next, rw_prev, b, rw_next);
         __builtin_amdgcn_s_waitcnt(0x0F70);      // my pieces of tile kt+1 have landed ...
         __builtin_amdgcn_s_barrier();            // ... everybody's have, and every wave has read the last fragment of tile kt
         GW4_SB();
-        kstep(I3{}, b, 1 - b, I0{}, I1{}, ra_next, rw_prev, b);
+        kstep(I3{}, b, 1 - b, I0{}, I1{}, ra_next, rw_prev, b, rw_next);
     };
     for (int kt = 0; kt < nk; kt += 2) {          // nk is even (the dispatcher sends K % 128 != 0 to the 8-wave kernel)
         ktile(kt, 0);
