@@ -8,7 +8,9 @@ LIB   := videocof_amd/libwan_hip.so
 OBJD  := build/obj
 OBJS  := $(patsubst $(CSRC)/%,$(OBJD)/%.o,$(SRCS))
 # -fno-honor-nans: lets fmaxf/fminf lower to one v_max/v_min (no canonicalising v_max on MFMA outputs)
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fno-honor-nans -Iinclude
+# EXPERIMENTS=1 compiles the timing-only variants behind the gemm_exp switch into the kernels (tools/kernel_check gemmx)
+EXPERIMENTS ?= 0
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fno-honor-nans -Iinclude -DWAN_DEV_EXPERIMENTS=$(EXPERIMENTS)
 # attn_fwd.hip only: keep adjacent scalar f32 adds single-instruction -- under plain -O3 the SLP vectoriser packs the
 # row-sum adds of the two query blocks into v_pk_add_f32, which beside MFMAs costs more than it saves (CDNA4 guide,
 # per-instruction cycle constants).  The GEMM / norm epilogues keep their packed math.

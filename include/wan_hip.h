@@ -50,7 +50,8 @@ const char* wan_last_error(void);
  * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code).
  * Read-only key "last_attn_variant": what the most recent wan_attention_fwd call of this process launched, as
  * WAN_ATTN_VARIANT_* (kernel family | WAN_ATTN_VARIANT_XCD_PINNED | WAN_ATTN_VARIANT_SPLIT_TAIL) -- so that a benchmark
- * reports the kernel the dispatcher picked instead of a literal. */
+ * reports the kernel the dispatcher picked instead of a literal.  Read-only key "dev_experiments": 1 if the library was built with
+ * `make EXPERIMENTS=1` (timing-only kernel variants behind "gemm_exp" compiled in; never in the product build). */
 wan_status_t wan_set_tuning(const char* key, int value);
 int wan_get_tuning(const char* key);
 #define WAN_ATTN_VARIANT_W4_LAZY 1          /* attn_fwd_w4_kernel<.,.,1|2>: 4 waves, lazy softmax reference, one launch */

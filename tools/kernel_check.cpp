@@ -423,6 +423,7 @@ int main(int argc, char** argv) {
     if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
     if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
     if (mode == "gemmx") {        // timing attribution of the 4-wave GEMM's main loop: with / without its LDS-DMA instructions
+        if (wan_get_tuning("dev_experiments") != 1) printf("  NOTE: libwan_hip.so was built without the experiment variants (make clean; make EXPERIMENTS=1): every arm below is the product kernel\n");
         const int M = 67080;
         struct S { int N, K, epi; const char* what; };
         for (S sh : {S{10240, 5120, WAN_EPI_BF16, "qk proj"}, S{5120, 13824, WAN_EPI_RESID_F32, "ffn.2+resid"}}) {

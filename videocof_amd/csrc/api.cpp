@@ -11,6 +11,10 @@
 
 #include "common.hpp"
 
+#ifndef WAN_DEV_EXPERIMENTS
+#define WAN_DEV_EXPERIMENTS 0
+#endif
+
 static thread_local char g_err[512] = "";
 
 void wan_set_error(const char* fmt, ...) {
@@ -93,6 +97,7 @@ extern "C" wan_status_t wan_set_tuning(const char* key, int value) {
 
 extern "C" int wan_get_tuning(const char* key) {
     if (key && !strcmp(key, "last_attn_variant")) return g_last_attn_variant.load(std::memory_order_relaxed);
+    if (key && !strcmp(key, "dev_experiments")) return WAN_DEV_EXPERIMENTS;      // 1: built with `make EXPERIMENTS=1` (gemm_exp variants compiled in)
     if (key)
         for (int i = 0; i < WAN_TUNE_COUNT; ++i)
             if (!strcmp(key, kTuningKeys[i].key)) return wan_tune(i);

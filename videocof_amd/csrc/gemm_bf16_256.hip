@@ -32,6 +32,10 @@
 
 #include "common.hpp"
 
+#ifndef WAN_DEV_EXPERIMENTS
+#define WAN_DEV_EXPERIMENTS 0
+#endif
+
 namespace {
 
 constexpr int kDefaultPhases = 2;
@@ -454,17 +458,23 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     const int64_t w_bytes = ((int64_t)(min(g.N - n0, BN) - 1) * g.ldw + g.K) * 2;
     auto rsrc = [&](const char* tile, int64_t bytes, int kt) {
         const int64_t left = kt < nk ? bytes - (int64_t)kt * BK * 2 : 0;
-        const int ke = (g.exp & 4) ? (min(kt, nk - 1) & 1) : min(kt, nk - 1);      // timing experiment: every request hits K tiles 0 / 1 (cache-resident)
+#if WAN_DEV_EXPERIMENTS
+        const int ke = (g.exp & 4) ? (min(kt, nk - 1) & 1) : min(kt, nk - 1);      // every request hits K tiles 0 / 1 (cache-resident)
+#else
+        const int ke = min(kt, nk - 1);
+#endif
         return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)ke * BK * 2), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
-        if (g.exp & (operand ? 1 : 2)) {                // timing experiment: what the DMA instructions cost the lone wave of a SIMD
+#if WAN_DEV_EXPERIMENTS     // `make EXPERIMENTS=1`: timing-only variants behind gemm_exp (tools/kernel_check gemmx); not in the product build
+        if (g.exp & (operand ? 1 : 2)) {                // what the DMA instructions cost the lone wave of a SIMD
             if ((g.exp & 8) && operand) {               // ... and what the same bytes cost as plain register loads (results discarded)
                 u32x4 sink;
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(sink) : "v"(w_voff[j & 1]), "s"(r), "s"((int)((j >> 1) * 16 * ld * 2)));
             }
             return;
         }
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
             operand ? w_voff[j & 1] : a_voff[j & 1], (int)((j >> 1) * 16 * ld * 2), 0, 0);
@@ -487,7 +497,11 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     u32x4 af[2][4], wf[2][4];                // [k-step parity][block]
-    const bool early_w = (g.exp & 16) != 0;
+#if WAN_DEV_EXPERIMENTS
+    const bool early_w = (g.exp & 16) != 0;        // the W pieces of tile kt+2 leave in k-step 3 of tile kt as well (measured: no gain)
+#else
+    constexpr bool early_w = false;
+#endif
 
 #define GW4_SB() __builtin_amdgcn_sched_barrier(0)
 // 12 of the 16 accumulator tiles (192 registers) are pinned to AGPRs, the last M block (4 tiles, 64 registers) to VGPRs:
