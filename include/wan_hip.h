@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 3
+#define WAN_ABI_VERSION 4
 
 typedef enum {
     WAN_OK = 0,
