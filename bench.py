@@ -290,7 +290,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of the last block")
     ap.add_argument("--fp8-layers", default="qkv,ffn",
-                    help="with --fp8: comma-separated subset of qkv,ffn,o,cross (all four = every per-token Linear of a block)")
+                    help="with --fp8: comma-separated subset of qkv,ffn,o,cross (all four = every per-token Linear of a block) and attn "
+                         "(self-attention QK^T on the fp8 matrix pipe, P.V stays bf16)")
     ap.add_argument("--fp8", action="store_true",
                     help="run the q|k, v, ffn.0 and ffn.2 projections in OCP e4m3 (WanTransformer3DModel.enable_fp8_linear): a "
                          "LOSSY option with its own error statement; the line says so in `dtype` and is never the headline")
@@ -495,6 +496,10 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
+        if (vcode & 15) == 4:       # fp8 QK^T: half of the flops run at the fp8 rate (2 x bf16), half (P.V) at the bf16 rate
+            peak = 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS)
+            roof.update(peak=round(peak, 1), frac=round(ach / peak, 4),
+                        dtype_peak="harmonic mix: QK^T at the dense fp8 MFMA rate (2 x bf16), P.V at the dense bf16 rate")
 
     units = world if (world > 1 and not sp) else 1            # dp: every rank denoises its own video
     tokens = units * L * args.steps
@@ -505,8 +510,8 @@ def main():
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "strong" if sp or world == 1 else "weak", "vs_baseline": None,
-        "dtype": f"fp8-e4m3 projections ({args.fp8_layers}) + bf16 (attention, the rest); LOSSY option, not the headline"
-                 if args.fp8 else "bf16",
+        "dtype": (f"fp8-e4m3 ({args.fp8_layers}; 'attn' = the QK^T product of self-attention) + bf16 (softmax, P.V, the rest); "
+                  "LOSSY option, not the headline") if args.fp8 else "bf16",
         "data": "synthetic (random-init weights, N(0,1) latents + text embeddings)",
         "config": {"workload": wl["desc"], "layout": "VideoCoF (src|ground|tgt)" if cof else "T2V",
                    "latent": [1, 16, Ftot, wl["h"], wl["w"]], "grid": [Ftot, wl["h"] // 2, wl["w"] // 2],

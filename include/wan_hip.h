@@ -57,6 +57,7 @@ int wan_get_tuning(const char* key);
 #define WAN_ATTN_VARIANT_W4_LAZY 1          /* attn_fwd_w4_kernel<.,.,1|2>: 4 waves, lazy softmax reference, one launch */
 #define WAN_ATTN_VARIANT_W4_MAXFREE 2       /* attn_fwd_w4_kernel<.,false,0> + its checked fix-up launch attn_fwd_w4_kernel<.,false,1,true> */
 #define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* attn_fwd_v2_kernel, 8 waves, running max per tile ("attn_w4" = 0: developer A/B partner) */
+#define WAN_ATTN_VARIANT_W4_LAZY_QK8 4      /* attn_fwd_w4_kernel<0,.,1,false,true>: the lazy form with QK^T on the fp8 matrix pipe (wan_attention_fwd_qk8) */
 #define WAN_ATTN_VARIANT_FAMILY_MASK 15
 #define WAN_ATTN_VARIANT_XCD_PINNED 16      /* every (batch, head) pinned to one XCD */
 #define WAN_ATTN_VARIANT_SPLIT_TAIL 32      /* the last partial round ran split over the keys (+ merge kernel) */
@@ -200,7 +201,32 @@ int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, 
  * Lets a benchmark / test state the dispatched kernels without launching them.  No reference counterpart. */
 int wan_attention_plan(int batch, int Lq, int Lk, int num_heads, int head_dim, int flags, int64_t workspace_bytes);
 #define WAN_ATTN_Q_PRESCALED 1
+#define WAN_ATTN_QK_FP8 2                   /* wan_attention_plan only: plan for wan_attention_fwd_qk8 */
 #define WAN_ATTN_QSCALE(softmax_scale) ((softmax_scale) * 1.4426950408889634f)
+
+/* a9' Self-attention with the QK^T product on the fp8 matrix pipe (LOSSY, opt-in; the role of the reference's
+ *     `sageattn` branch, attention_utils.py:152-211 with attention_type = "SAGE_ATTENTION": 8-bit QK^T, 16-bit P.V).
+ *       q8  e4m3 [B][Lq][H*128] = e4m3( q * softmax_scale * log2(e) * 2^q_exp )      (strides in BYTES, rows 16-byte aligned)
+ *       k8  e4m3 [B][Lk][H*128] = e4m3( k * 2^k_exp )
+ *     both written by wan_rmsnorm_rope_fp8 (below); the power-of-two factors move typical post-RMSNorm magnitudes into e4m3's
+ *     normal range (2^-6 .. 448) and are undone exactly by the MFMA's E8M0 operand scales, so the fp32 scores differ from the
+ *     bf16 kernel's only by the 3-bit mantissas of q8 / k8 (a relative error of <= 2^-4 per element; |q| * 2^q_exp or
+ *     |k| * 2^k_exp above 448 saturates).  Everything behind the scores -- lazy softmax reference, bf16 P, P.V, fp32 sums,
+ *     split tail, XCD pinning, the scratch layout -- is wan_attention_fwd's lazy-reference form; vt / out as there.
+ *     Measured error and speed: tests/test_gpu_fp8.py, DESIGN.md section 13. */
+wan_status_t wan_attention_fwd_qk8(const void* q8, int64_t ldq8, int64_t q8_bstride, int q_exp,
+                                   const void* k8, int64_t ldk8, int64_t k8_bstride, int k_exp,
+                                   const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                   void* out, int64_t ldo, int64_t o_bstride,
+                                   int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
+/* wan_rmsnorm_rope that leaves x0 / x1 untouched and writes e4m3 copies of the results, dense [rows][dim] bytes:
+ * out0 = e4m3(bf16(result0 * x0_scale)), out1 = e4m3(bf16(result1 * x1_scale)) -- the bf16 rounding first, so that with
+ * power-of-two extra factors the e4m3 value is a quantisation of exactly the number the bf16 path would have used. */
+wan_status_t wan_rmsnorm_rope_fp8(const void* x0_bf16, const float* w0, const void* x1_bf16, const float* w1,
+                                  int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                  const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                  float x0_scale, float x1_scale, void* out0_fp8, void* out1_fp8, void* stream);
 
 /* [rows, cols] bf16 (row stride ld) -> [cols, ldt] bf16 transposed; pad columns [rows, ldt) are zeroed.
  * Used when a caller hands attention() a row-major V (the reference's [B,L,N,D] layout). */

@@ -162,16 +162,105 @@ def test_fp8_mode_14b_width_block_error_statement():
     f8_ffn = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
     m.enable_fp8_linear(("qkv", "ffn", "o", "cross"))            # every per-token Linear of the block (fp8_optimization.py:19-57)
     f8_all = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
+    m.enable_fp8_linear(("attn",))                               # only the self-attention QK^T product in e4m3
+    f8_attn = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
+    m.enable_fp8_linear(("qkv", "ffn", "o", "cross", "attn"))
+    f8_all_attn = m.block_forward(x, e, ctx, grid, 0, [4], [(4, 5)])[0]
     m.disable_fp8_linear()
     osd = {k: v.detach().float() for k, v in m.state_dict().items()}
     ref = O.block_forward(x[0], e[0], ctx[0], osd, 0, cfg, grid, O.rope_angles(128), 4, (4, 5), L)
     m.release_workspaces()
     u_ref = ref - x[0]
     res = {name: (rel_l2(out, ref), rel_l2(out - x[0], u_ref)) for name, out in (("bf16", bf), ("fp8 ffn", f8_ffn), ("fp8 qkv+ffn", f8),
-                                                                                 ("fp8 all", f8_all))}
+                                                                                 ("fp8 all", f8_all), ("fp8 attn", f8_attn),
+                                                                                 ("fp8 all+attn", f8_all_attn))}
     for name, (s_, u_) in res.items():
         print(f"14B-width block, L=8192, {name:12s}: residual stream rel-L2 {s_:.2e}, block update rel-L2 {u_:.2e}")
     assert res["bf16"][1] < 3e-2
     assert res["fp8 ffn"][1] < 8e-2 and res["fp8 qkv+ffn"][1] < 1.2e-1
     assert res["fp8 qkv+ffn"][0] < 5e-2
     assert res["fp8 all"][1] < 1.5e-1 and res["fp8 all"][0] < 6e-2 and not torch.equal(f8_all, f8)
+    assert res["fp8 attn"][1] < 8e-2 and not torch.equal(f8_attn, bf)
+    assert res["fp8 all+attn"][1] < 1.8e-1 and res["fp8 all+attn"][0] < 7e-2 and not torch.equal(f8_all_attn, f8_all)
+
+
+def _attention_ref_log2(qs, k, v, L):
+    """softmax_2(qs k^T) v in fp64 on the GPU; qs already carries softmax_scale * log2(e).  [Lq, H, 128] operands."""
+    s_ = torch.einsum("qhd,khd->hqk", qs.double(), k[:L].double())
+    p = torch.softmax(s_ * math.log(2.0), dim=-1)
+    return torch.einsum("hqk,khd->qhd", p, v[:L].double())
+
+
+def test_rmsnorm_rope_fp8_is_the_e4m3_cast_of_the_bf16_result():
+    """wan_rmsnorm_rope_fp8 = the bf16 kernel's result times a power of two, cast like torch casts to float8_e4m3fn; inputs untouched."""
+    from videocof_amd._lib import RopeParams
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rows, H = 3 * 4 * 6 + 5, 3                            # 5 rows past the (3, 4, 6) grid pass through un-rotated
+    C = H * 128
+    qk = (torch.randn(rows, 2 * C, device=DEV, generator=g) * 2).bfloat16()
+    nq, nk = torch.rand(C, device=DEV, generator=g) + 0.5, torch.rand(C, device=DEV, generator=g) + 0.5
+    ang = O.rope_angles(128).to(DEV)
+    rope = (torch.cos(ang).float().contiguous(), torch.sin(ang).float().contiguous())
+    rp = RopeParams(3, 4, 6, 2, 1, 2, 0, rows, ang.shape[0])
+    qs = ops.q_prescale(128)
+    q8, k8 = torch.empty(rows, C, device=DEV, dtype=ops.FP8), torch.empty(rows, C, device=DEV, dtype=ops.FP8)
+    before = qk.clone()
+    ops.rmsnorm_rope_fp8(qk[:, :C], nq, qk[:, C:], nk, 128, 1e-6, rope, rp, q8, k8, x0_scale=qs * 32.0, x1_scale=4.0)
+    assert torch.equal(qk, before)
+    ops.rmsnorm_rope_(qk[:, :C], nq, qk[:, C:], nk, 128, 1e-6, rope, rp, x0_scale=qs)
+    want_q = (qk[:, :C].float() * 32.0).clamp(-448, 448).to(ops.FP8)
+    want_k = (qk[:, C:].float() * 4.0).clamp(-448, 448).to(ops.FP8)
+    assert torch.equal(q8.view(torch.uint8), want_q.view(torch.uint8))
+    assert torch.equal(k8.view(torch.uint8), want_k.view(torch.uint8))
+
+
+@pytest.mark.parametrize("Lq,Lk,H,qstd", [(300, 420, 2, 1.0), (64, 64, 1, 1.0), (257, 8, 3, 1.0), (520, 1500, 2, 1.0), (256, 4096, 1, 30.0),
+                                          (86 * 256 + 10, 1100, 3, 1.0)])
+def test_attention_qk8_is_exact_on_its_operands(Lq, Lk, H, qstd):
+    """KERNEL statement: wan_attention_fwd_qk8 computes softmax(q8 k8^T) v of the e4m3 operands it is handed to the accuracy of
+    the bf16 kernel (fp32 scores and sums, bf16 P) -- ragged last tile, keys past k_len masked, the split-KV tail round
+    (last shape), a softmax reference that has to be repaired (qstd = 30: scores of +-100 in log2 units).
+    MODE statement (printed, bounded): what e4m3 q / k cost against the bf16 operands."""
+    g = torch.Generator(device=DEV).manual_seed(Lq + Lk)
+    C, qe, ke = H * 128, 5, 2
+    qs_ = ops.q_prescale(128)
+    q = (torch.randn(Lq, C, device=DEV, generator=g) * qstd * qs_).bfloat16()              # as rmsnorm_rope(x0_scale) hands it over
+    kpad = ops.round_up(Lk, 64) + 64                                                          # rows past k_len hold garbage
+    k = torch.randn(kpad, C, device=DEV, generator=g).bfloat16()
+    v = (torch.randn(kpad, C, device=DEV, generator=g) + torch.linspace(-1, 1, C, device=DEV)).bfloat16()
+    q8 = (q.float() * 2.0 ** qe).clamp(-448, 448).to(ops.FP8)
+    k8 = (k.float() * 2.0 ** ke).clamp(-448, 448).to(ops.FP8)
+    vt = ops.transpose_pad(v[:Lk].contiguous())
+    out = ops.attention_fwd_qk8(q8[None], k8[None], vt[None], H, qe, ke, k_len=Lk)[0]
+    assert (ops.get_tuning("last_attn_variant") & 15) == 4
+    rows = torch.arange(Lq, device=DEV) if Lq <= 1024 else torch.cat([torch.arange(64, device=DEV), torch.arange(Lq - 600, Lq, device=DEV),
+                                                                       torch.arange(64, Lq - 600, 211, device=DEV)])
+    ref = _attention_ref_log2(q8.float()[rows].view(-1, H, 128) * 2.0 ** -qe, k8.float().view(-1, H, 128) * 2.0 ** -ke, v.view(-1, H, 128), Lk)
+    got = out[rows].view(-1, H, 128)
+    assert rel_l2(got, ref) < 6e-3
+    ref16 = _attention_ref_log2(q[rows].view(-1, H, 128), k.view(-1, H, 128), v.view(-1, H, 128), Lk)
+    out16 = ops.attention_fwd(q[None], k[None, :kpad], vt[None], H, k_len=Lk, q_prescaled=True)[0]
+    e8, e16 = rel_l2(got, ref16), rel_l2(out16[rows].view(-1, H, 128), ref16)
+    print(f"attention Lq={Lq} Lk={Lk} H={H} q std {qstd}: fp8 QK^T vs bf16 operands rel-L2 {e8:.2e} (bf16 kernel: {e16:.2e})")
+    if qstd == 1.0:
+        assert e16 < 6e-3 and e8 < 6e-2           # N(0,1) scores: an e4m3 rounding of q and k moves a score by ~4 % of its std
+
+
+def test_fp8_attention_small_model_follows_bf16():
+    """A small DiT with only the attention product in e4m3 stays within the fp8 mode's bound of the bf16 forward (and differs from
+    it: the qk8 kernel ran), and `disable_fp8_linear` restores the bf16 bits."""
+    tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**tiny), device=DEV)
+    lat = det_uniform("fp8.lat", (1, 16, 7, 12, 20), 1.0).to(DEV)
+    ctx = [det_uniform("fp8.ctx", (37, 64), 1.0).to(DEV)]
+    t = torch.tensor([899], device=DEV)
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    bf = m(lat, t, ctx, 420, **kw)
+    m.enable_fp8_linear(("attn",))
+    f8 = m(lat, t, ctx, 420, **kw)
+    e = rel_l2(f8, bf)
+    print(f"small DiT, fp8 QK^T only: output rel-L2 vs bf16 path {e:.2e}")
+    assert 0 < e < 5e-2
+    m.disable_fp8_linear()
+    assert torch.equal(m(lat, t, ctx, 420, **kw), bf)

@@ -493,6 +493,78 @@ int main(int argc, char** argv) {
         HIP(hipDeviceSynchronize());
         printf("attnprof done\n");
     }
+    if (mode == "attnq8") {       // wan_attention_fwd_qk8: exactness against its own (quantised) operands, error against the bf16 operands, speed
+        // usage: kernel_check attnq8 [q_exp k_exp]
+        const int qe = argc > 3 ? atoi(argv[2]) : 5, ke = argc > 3 ? atoi(argv[3]) : 2;
+        auto f2e4m3 = [](float x) -> uint8_t {             // OCP e4m3fn, round to nearest even, saturating at +-448
+            const uint8_t sgn = x < 0 ? 0x80 : 0; float ax = fabsf(x);
+            if (!(ax == ax)) return 0x7f;
+            if (ax >= 448.f) return sgn | 0x7e;
+            if (ax < 0.015625f) return sgn | (uint8_t)lrintf(ax * 512.f);              // subnormals: steps of 2^-9 (8 -> the first normal)
+            uint32_t u; memcpy(&u, &ax, 4);
+            u += 0x7ffffu + ((u >> 20) & 1); u &= ~0xfffffu;                            // keep 3 mantissa bits
+            const int e = (int)(u >> 23) - 127 + 7; const uint32_t m = (u >> 20) & 7;
+            return sgn | (uint8_t)((e << 3) | m);
+        };
+        auto e4m32f = [](uint8_t b) -> float {
+            const int e = (b >> 3) & 15, m = b & 7; const float v = e == 0 ? m * (1.f / 512.f) : ldexpf(1.f + m / 8.f, e - 7);
+            return (b & 0x80) ? -v : v;
+        };
+        const float scale = 1.f / sqrtf(128.f), cc = WAN_ATTN_QSCALE(scale);
+        struct Shape { int Lq, Lk, H; float qs; };
+        for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{33, 1000, 1, 6.f}, Shape{520, 1500, 2, 40.f},
+                         Shape{256, 4096, 1, 100.f}, Shape{86 * 256 + 10, 1100, 3, 1.f}}) {
+            const int Lq = sh.Lq, Lk = sh.Lk, H = sh.H, C = H * 128;
+            auto q = bf_round(randn((size_t)Lq * C, sh.qs)), k = bf_round(randn((size_t)Lk * C)), v = bf_round(randn((size_t)Lk * C));
+            for (int j = 0; j < Lk; ++j) for (int c = 0; c < C; ++c) v[(size_t)j * C + c] = bf2f(f2bf(v[(size_t)j * C + c] + 0.01f * (c % 128) - 0.003f * (j % 97)));
+            std::vector<uint8_t> q8(q.size()), k8(k.size());
+            std::vector<float> qd(q.size()), kd(k.size()), qb(q.size());
+            for (size_t i = 0; i < q.size(); ++i) {
+                qb[i] = bf2f(f2bf(q[i] * cc));                                           // what the bf16 kernel would be handed
+                q8[i] = f2e4m3(ldexpf(qb[i], qe)); qd[i] = ldexpf(e4m32f(q8[i]), -qe) / cc; qb[i] /= cc;
+            }
+            for (size_t i = 0; i < k.size(); ++i) { k8[i] = f2e4m3(ldexpf(k[i], ke)); kd[i] = ldexpf(e4m32f(k8[i]), -ke); }
+            const int64_t ldvt = (Lk + 63) / 64 * 64;
+            Dev<uint8_t> dq8(q8), dk8(k8);
+            Dev<bf16> dv(to_bf(v)), dvt((size_t)C * ldvt), dout((size_t)Lq * C);
+            WAN(wan_transpose_bf16(dv.p, C, dvt.p, ldvt, Lk, C, nullptr));
+            const int64_t wsb = wan_attention_workspace_bytes(1, Lq, Lk, H, 128);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            WAN(wan_attention_fwd_qk8(dq8.p, C, 0, qe, dk8.p, C, 0, ke, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, wsb ? ws.p : nullptr, wsb, nullptr));
+            HIP(hipDeviceSynchronize());
+            std::vector<int> rows;
+            for (int i = 0; i < Lq; ++i) if (Lq <= 1024 || i < 64 || i >= Lq - 600 || i % 211 == 0) rows.push_back(i);
+            std::vector<double> ref, ref16; attn_ref(qd, kd, v, Lq, Lk, H, scale, ref, rows); attn_ref(qb, k, v, Lq, Lk, H, scale, ref16, rows);
+            auto all = bf_to_f(dout.host());
+            std::vector<float> got(rows.size() * C);
+            for (size_t ri = 0; ri < rows.size(); ++ri) memcpy(&got[ri * C], &all[(size_t)rows[ri] * C], C * sizeof(float));
+            char nm[128]; snprintf(nm, sizeof nm, "qk8 Lq=%d Lk=%d H=%d qscale=%.0f (variant 0x%x): vs its own e4m3 operands", Lq, Lk, H, sh.qs, wan_get_tuning("last_attn_variant"));
+            report(nm, rel_l2(ref, got), 6e-3);
+            printf("       error against the bf16 operands (the cost of e4m3 q, k): rel_l2 %.3e\n", rel_l2(ref16, got));
+        }
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+        {   // speed at the bench shape, alternating with the bf16 dispatch in one process
+            const int L = 67080, H = 40, C = H * 128; const int64_t ldvt = (L + 63) / 64 * 64;
+            auto hf = randn((size_t)4096 * 128);
+            auto hq = to_bf(hf);
+            std::vector<uint8_t> h8q(hf.size()), h8k(hf.size());
+            for (size_t i = 0; i < hf.size(); ++i) { h8q[i] = f2e4m3(ldexpf(bf2f(f2bf(hf[i] * cc)), qe)); h8k[i] = f2e4m3(ldexpf(bf2f(hq[i]), ke)); }
+            Dev<bf16> q((size_t)L * C), k((size_t)L * C), vt((size_t)C * ldvt), o((size_t)L * C);
+            Dev<uint8_t> q8((size_t)L * C), k8((size_t)L * C);
+            auto fill = [&](auto& d, const auto& src) { for (size_t off = 0; off < d.n; off += src.size()) HIP(hipMemcpy(d.p + off, src.data(), std::min(src.size(), d.n - off) * sizeof(src[0]), hipMemcpyHostToDevice)); };
+            fill(k, hq); fill(vt, hq); fill(q8, h8q); fill(k8, h8k);
+            { std::vector<float> t = bf_to_f(hq); for (auto& x : t) x *= cc; fill(q, to_bf(t)); }
+            const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            for (int round = 0; round < 2; ++round) {
+                double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, scale, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr)); }, 4, 1);
+                printf("  bf16 dispatch   L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
+                ms = time_ms([&] { WAN(wan_attention_fwd_qk8(q8.p, C, 0, qe, k8.p, C, 0, ke, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, wsb ? ws.p : nullptr, wsb, nullptr)); }, 4, 1);
+                printf("  fp8 QK^T        L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
+                fflush(stdout);
+            }
+        }
+    }
     if (mode == "attnx") {        // in-process A/B of the self-attention launch at the bench shape: tuning key=value sets from argv
         // usage: kernel_check attnx [H] "k1=v1,k2=v2" "k1=v1" ...   (each quoted group is one arm; "" = defaults)
         const int L = 67080; int H = 40; int first = 2;

@@ -19,7 +19,8 @@ LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
 ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax reference)",
                       2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free attempt) + attn_fwd_w4_kernel<.,false,1,true> (lazy-reference fix-up of flagged workgroups)",
-                      3: "attn_fwd_v2_kernel (8-wave, running max)"}
+                      3: "attn_fwd_v2_kernel (8-wave, running max)",
+                      4: "attn_fwd_w4_kernel<0,.,1,false,true> (4-wave, lazy softmax reference, QK^T on the fp8 matrix pipe)"}
 ATTN_VARIANT_XCD_PINNED, ATTN_VARIANT_SPLIT_TAIL = 16, 32
 GEMM_VARIANT_KERNELS = {0: "gemm_bf16_kernel", 1: "gemm256_kernel", 2: "gemm_w4_kernel"}      # wan_gemm_plan (WAN_GEMM_VARIANT_*)
 
@@ -108,6 +109,12 @@ SIGNATURES = {
     "wan_attention_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_attention_fwd_qk8": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int,
+                                      c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                      c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_rmsnorm_rope_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                     c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_float, c_void_p, c_void_p,
+                                     c_void_p]),
     "wan_attention_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "wan_sp_unique_id": (c_int, [c_void_p]),
     "wan_sp_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),

@@ -33,6 +33,8 @@
 
 namespace {
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
 constexpr int kD = 128;          // head dim
 constexpr int kQPerWave = 32;
 constexpr int kWavesPerWG = 8;
@@ -59,6 +61,11 @@ struct AttnArgs {
     // (head, z) pair bh = 8 * ((w >> 3) / nqb) + (w & 7) pins every head to one XCD, whose 32 CUs walk that head's query
     // blocks together: one head's K / V^T (34 MB at L = 67 080) streams through ONE 4 MB L2 instead of all eight.
     int nqb, nbh, xcd_map;
+    // QK8 form (wan_attention_fwd_qk8): q, k as OCP e4m3 bytes [rows][H*128], pre-multiplied by powers of two; the MFMA
+    // applies the inverse (q8_scale / k8_scale: the E8M0 byte 127 - exponent, replicated into all four bytes)
+    const unsigned char* q8; int64_t ldq8, q8_bs;
+    const unsigned char* k8; int64_t ldk8, k8_bs;
+    unsigned q8_scale, k8_scale;
     int tile_mask;        // developer experiment (attn_exp & 1): staging reads tile (t & tile_mask); 0x7fffffff in product
     int exp_nocheck;      // developer experiment (attn_exp & 2), TIMING ONLY: the lazy form skips its per-tile window check
 };
@@ -513,10 +520,16 @@ constexpr float kW4Trigger = 0x1p40f;
 // REF: 0 = max-free, 1 = lazy reference riding in the accumulator (-m splats, 32 VGPRs, no extra VALU),
 //      2 = lazy reference subtracted from the scores two at a time (v_pk_add_f32: 4 VGPRs, +32 VALU per tile).
 // FIX: the launch right behind a max-free attempt on the same grid -- only flagged workgroups run (all others exit at once).
-template <int VARIANT, bool SPLIT, int REF, bool FIX = false>
+// QK8: S^T = K.Q^T on the fp8 matrix pipe (v_mfma_scale_f32_32x32x64_f8f6f4: 2 x the bf16 rate; 8 x 16-pass MFMAs per tile
+//      instead of 32 x 8-pass), from e4m3 copies of q and k that the RMSNorm+RoPE kernel writes (wan_rmsnorm_rope_fp8); softmax,
+//      P and the P.V product are the bf16 / fp32 ones of the REF = 1 form.  LOSSY (3 mantissa bits on q and k), opt-in.
+//      K tile image: [64 keys][128 B], chunk' = chunk ^ ((row >> 1) & 7) (the V^T image's swizzle), 2 DMA pieces per wave; a lane's
+//      A fragment (kt, dh) = 32 bytes d = 64 dh + 32 hi .. + 31 of key pi(lane & 31) + 32 kt, read as two ds_read_b128.
+template <int VARIANT, bool SPLIT, int REF, bool FIX = false, bool QK8 = false>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {
     constexpr bool MAXFREE = REF == 0, SPLAT = REF == 1, PKSUB = REF == 2;
+    static_assert(!QK8 || (SPLAT && !FIX && VARIANT == 0), "the fp8 QK^T form is the self-attention lazy-reference kernel");
     static_assert(!(SPLIT && MAXFREE), "the split tail round runs the lazy-reference form");
     static_assert(!FIX || (!SPLIT && !MAXFREE), "the fix-up launch is the unsplit lazy-reference form");
     const int wg_linear = blockIdx.x;
@@ -560,18 +573,29 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     const int Lk = SPLIT ? min(a.Lk - t0 * kKV, a.tiles_per_split * kKV) : a.Lk;
     const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
     const bf16_t* K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
+    const unsigned char* K8 = QK8 ? a.k8 + batch * a.k8_bs + head * kD + (int64_t)t0 * kKV * a.ldk8 : nullptr;
     const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt + t0 * kKV;
     bf16_t* O = a.o + batch * a.o_bs + head * kD;
 
     // ---- Q fragments of the wave's two query blocks (B operands of S^T = K.Q^T), kept in AGPRs by the "a" constraints
     int qrow[2];
     u32x4 qf[2][8];
+    i32x8 qf8[2][2];            // QK8: B operands, 32 e4m3 per lane and d half (d = 64 dh + 32 hi .. + 31)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         qrow[qb] = qblk * kQPerWG + wid * 64 + qb * 32 + l31;
-        const bf16_t* qp = Q + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq + hi * 8;
+        if constexpr (QK8) {
+            const unsigned char* qp = a.q8 + batch * a.q8_bs + head * kD + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq8 + hi * 32;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+            for (int dh = 0; dh < 2; ++dh) {
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(qp + dh * 64), up = *reinterpret_cast<const u32x4*>(qp + dh * 64 + 16);
+                qf8[qb][dh] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+            }
+        } else {
+            const bf16_t* qp = Q + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+        }
     }
     char* const kring = smem;
     // ---- staging: this wave copies pieces 4*wid .. 4*wid+3 (1 KiB each) of every K and V^T tile
@@ -584,24 +608,37 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     int k_voff[4], v_voff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int kr = wid * 16 + 4 * j + (lane >> 4);
-        k_voff[j] = (int)((kr * a.ldk + ((lane & 15) ^ (kr & 15)) * 8) * 2);
+        if constexpr (QK8) {        // 8 pieces of 8 rows x 128 B; this wave stages pieces 2 wid, 2 wid + 1 (j < 2)
+            const int kr = (wid * 2 + (j & 1)) * 8 + (lane >> 3);
+            k_voff[j] = (int)(kr * a.ldk8 + ((lane & 7) ^ ((kr >> 1) & 7)) * 16);
+        } else {
+            const int kr = wid * 16 + 4 * j + (lane >> 4);
+            k_voff[j] = (int)((kr * a.ldk + ((lane & 15) ^ (kr & 15)) * 8) * 2);
+        }
         const int vr = (wid * 4 + j) * 8 + (lane >> 3);
         v_voff[j] = (int)((vr * a.ldvt + ((lane & 7) ^ ((vr >> 1) & 7)) * 8) * 2);
     }
-    const int64_t k_tile_bytes = (int64_t)kKV * a.ldk * 2;
+    const int64_t k_row_bytes = QK8 ? a.ldk8 : a.ldk * 2;
+    const int64_t k_tile_bytes = (int64_t)kKV * k_row_bytes;
+    const char* const k_origin = QK8 ? (const char*)K8 : (const char*)K;
     auto k_rsrc = [&](int t) {          // tile min(t, nkv-1): a request past the end re-stages the last tile into a dead slot
         const int tc = min(t, nkv - 1);
-        const int64_t left = (int64_t)(Lk - tc * kKV) * a.ldk * 2;               // bytes from the tile origin to the end of row Lk-1
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)K + tc * k_tile_bytes), 0,
+        const int64_t left = (int64_t)(Lk - tc * kKV) * k_row_bytes;             // bytes from the tile origin to the end of row Lk-1
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(k_origin + tc * k_tile_bytes), 0,
                                                  (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto v_rsrc = [&](int t) {          // tile min(t, nkv-1) (t <= nkv - 1 on every call); V^T pad columns exist up to roundup(Lk, 64)
         return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)min(t, nkv - 1) * kKV * 2), 0, 0x7fffffff, 0x00020000);
     };
     auto stage_k_piece = [&](__amdgpu_buffer_rsrc_t r, int kslot, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kring + kslot * kKTileBytes + (wid * 4 + j) * 1024),
-                                                 16, k_voff[j], 0, 0, 0);
+        if constexpr (QK8) {
+            if (j < 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kring + kslot * kKTileBytes + (wid * 2 + j) * 1024),
+                                                         16, k_voff[j], 0, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kring + kslot * kKTileBytes + (wid * 4 + j) * 1024),
+                                                     16, k_voff[j], 0, 0, 0);
+        }
     };
     auto stage_v_piece = [&](__amdgpu_buffer_rsrc_t r, int vslot, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + 2 * kKTileBytes + vslot * kVTileBytes + (wid * 4 + j) * 1024),
@@ -615,6 +652,11 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     unsigned k_adr[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) k_adr[ks] = lds_base + k_rowoff + (((2 * ks + hi) ^ k_sw) << 4);
+    unsigned k8_adr[4];         // QK8: chunk 4 dh + 2 hi + x of row pi, x = 0, 1 (index 2 dh + x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k8_adr[i] = lds_base + pi * 128 + (((4 * (i >> 1) + 2 * hi + (i & 1)) ^ ((pi >> 1) & 7)) << 4);
+    unsigned sc_k, sc_q;        // the MFMA's E8M0 operand scales (VGPR operands; asm so that they are set once, not per MFMA)
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(sc_k), "=v"(sc_q) : "s"(a.k8_scale), "s"(a.q8_scale));
     const int v_rowoff = l31 * 128, v_sw = (l31 >> 1) & 7;
     unsigned v_adr[4];          // carries the V ring base
 #pragma unroll
@@ -656,19 +698,46 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define W4A_MFMA_O(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "a"(A), "v"(B))
 #define W4_MFMA_S(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "a"(B))
 #define W4_MFMA_O(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B))
+// QK8: one 16-pass fp8 MFMA = 64 of the 128 d; the E8M0 scale bytes undo the power-of-two pre-scaling of q8 / k8
+#define W8_MFMA0(D, A, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(D) : "v"(A), "a"(B), "v"(sc_k), "v"(sc_q))
+#define W8_MFMA_SV(D, A, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(D) : "v"(A), "a"(B), "v"(sc_k), "v"(sc_q))
+// The loop's K fragments live in FIXED registers a[224 + 8 f .. 231 + 8 f] (f = 2 dh + kt): an 8-register MFMA operand filled by
+// two ds_read_b128 has no expression as asm operands (no sub-register syntax; built from two 4-register operands hipcc copies the
+// halves through VGPRs -- and does so before the untracked LDS data has arrived).  Every statement that touches them names all
+// 32 as clobbered, so hipcc keeps its own AGPR values (O, Q, the V^T ring) out of that range.
+#define W8_KCLOB "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+                 "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define W8K_MFMA_C(D, F, B, C) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%5:%6], %1, %2, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(D) : "a"(B), "v"(C), "v"(sc_k), "v"(sc_q), "i"(224 + 8 * (F)), "i"(231 + 8 * (F)) : W8_KCLOB)
+#define W8K_MFMA_S(D, F, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%4:%5], %1, %0, %2, %3 op_sel_hi:[0,0,0]" : "+v"(D) : "a"(B), "v"(sc_k), "v"(sc_q), "i"(224 + 8 * (F)), "i"(231 + 8 * (F)) : W8_KCLOB)
+    if constexpr (QK8) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+        for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const u32x4 kf0 = lds_read16_at(k_adr[ks] + kt * 32 * 256);
+            for (int kt = 0; kt < 2; ++kt) {
+                const u32x4 lo = lds_read16_at(k8_adr[2 * dh] + kt * 32 * 128), up = lds_read16_at(k8_adr[2 * dh + 1] + kt * 32 * 128);
+                const i32x8 kf0 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                if (ks == 0) W4_MFMA0(s0[qb][kt], kf0, qf[qb][0]);
-                else W4_MFMA_S(s0[qb][kt], kf0, qf[qb][ks]);
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (dh == 0) W8_MFMA0(s0[qb][kt], kf0, qf8[qb][0]);
+                    else W8_MFMA_SV(s0[qb][kt], kf0, qf8[qb][1]);
+                }
             }
-        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const u32x4 kf0 = lds_read16_at(k_adr[ks] + kt * 32 * 256);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (ks == 0) W4_MFMA0(s0[qb][kt], kf0, qf[qb][0]);
+                    else W4_MFMA_S(s0[qb][kt], kf0, qf[qb][ks]);
+                }
+            }
+    }
     __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // S(0) is read by VALU code below: cover the MFMA -> VALU wait states
+    if constexpr (QK8) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // ... of a 16-pass MFMA
 
     // ---- lazy reference (see the kernel header): -m of each query block as a 16-register splat = the C operand that starts
     // every S chain.  It starts as the exact row max of tile 0 (of its valid keys when tile 0 is also the last tile).
@@ -728,6 +797,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         // straight-line and cut into small steps by sched_barriers: at this point ~225 VGPRs are live, and a scheduler that
         // overlaps the steps for latency (as it would by default) spills
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // sn's accumulate chains ended in the last MFMA slots
+        if constexpr (QK8) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // (16-pass MFMAs there)
         if (a.flags != nullptr && lane == 0) atomicAdd(a.flags - 2, 1);       // scratch header word [2]: repair events (statistics)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -797,6 +867,12 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define QK(qb, kt, ks, f, w) do { if constexpr (MAXFREE) { if ((ks) == 0) W4_MFMA0(sn[qb][kt], kfr[(f) & 3], qf[qb][0]); else W4_MFMA_S(sn[qb][kt], kfr[(f) & 3], qf[qb][ks]); } \
                                   else { W4_LGKM(w); if ((ks) == 0) { if constexpr (SPLAT) W4A_MFMA_C(sn[qb][kt], fr[(f) & 3], qf[qb][0], negm[qb]); else W4A_MFMA0(sn[qb][kt], fr[(f) & 3], qf[qb][0]); } \
                                          else W4A_MFMA_S(sn[qb][kt], fr[(f) & 3], qf[qb][ks]); } SB(); } while (0)
+// QK8: fragment f = 2 dh + kt
+#define RDK8(f) asm volatile("ds_read_b128 a[%2:%3], %0 offset:%6\n\tds_read_b128 a[%4:%5], %1 offset:%6" \
+                             :: "v"(k8_adr[2 * ((f) >> 1)]), "v"(k8_adr[2 * ((f) >> 1) + 1]), "i"(224 + 8 * (f)), "i"(227 + 8 * (f)), "i"(228 + 8 * (f)), \
+                                "i"(231 + 8 * (f)), "i"(kslot_next * kKTileBytes + ((f) & 1) * 32 * 128) : W8_KCLOB)
+#define QK8(qb, kt, dh, f, w) do { W4_LGKM(w); if ((dh) == 0) W8K_MFMA_C(sn[qb][kt], f, qf8[qb][0], negm[qb]); else W8K_MFMA_S(sn[qb][kt], f, qf8[qb][1]); SB(); } while (0)
+#define G8(j) do { if ((j) < 2) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 2); } while (0)
 #define MIDCHECK() do { if constexpr (!MAXFREE) { if (a.exp_nocheck == 0) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } } while (0)
 #define PV(qb, dt, tt, f, w) do { if constexpr (MAXFREE) { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } \
                                   else { W4_LGKM(w); if ((tt) < 2) W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pc[qb][(tt) & 1]); else W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pf23[qb][(tt) & 1]); } SB(); } while (0)
@@ -811,12 +887,17 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define C(w) do { const unsigned pk_ = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1]); \
                   if (((w) >> 3) & 1) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; \
                   else pn[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; } while (0)
-        if constexpr (PKSUB) {
+        if constexpr (QK8) {
+#include "attn_w4_sched_q8.inc"
+        } else if constexpr (PKSUB) {
 #include "attn_w4_sched_pk.inc"
         } else {
 #include "attn_w4_sched.inc"
         }
 #undef RDK
+#undef RDK8
+#undef QK8
+#undef G8
 #undef RDV
 #undef QK
 #undef MIDCHECK
@@ -917,6 +998,11 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' D -> the accumulator reads below
     }
 #undef SB
+#undef W8_MFMA0
+#undef W8_MFMA_SV
+#undef W8K_MFMA_C
+#undef W8K_MFMA_S
+#undef W8_KCLOB
 #undef W4_MFMA0
 #undef W4A_MFMA_C
 #undef W4_SCALE_ACC
@@ -1102,7 +1188,7 @@ namespace {
 // The dispatch decision of wan_attention_fwd as host arithmetic (shared by the launcher and wan_attention_plan).
 struct AttnPlan { TailPlan tail; bool fast = false, w4 = true, ref2 = false, xcd = false; int variant = 0; };
 
-AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int64_t workspace_bytes) {
+AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int64_t workspace_bytes, bool qk8 = false) {
     AttnPlan p;
     const bool self = Lk > 1024;
     const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
@@ -1117,13 +1203,15 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
         // attn_fast = 2 forces the attempt whenever there is scratch (tests)
         const int fast_mode = wan_tune(WAN_TUNE_ATTN_FAST);
         const bool long_launch = self && (int64_t)nqb_all * num_heads * batch >= 4LL * wan_cu_count();
-        p.fast = pre && p.w4 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
+        p.fast = pre && p.w4 && !qk8 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
         p.tail = plan_tail(batch, Lq, Lk, num_heads);
         if (p.tail.tq > 0 && workspace_bytes - fb < p.tail.ws_bytes) p.tail = TailPlan();
     }
     // heads pinned to XCDs: only worth it (and only balanced) when the (batch, head) pairs split evenly over the 8 XCDs
     p.xcd = wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && (num_heads * batch) % 8 == 0;
-    p.variant = !p.w4 ? WAN_ATTN_VARIANT_W8_RUNNING_MAX : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY);
+    if (qk8) p.ref2 = false;
+    p.variant = qk8 ? WAN_ATTN_VARIANT_W4_LAZY_QK8
+                    : (!p.w4 ? WAN_ATTN_VARIANT_W8_RUNNING_MAX : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY));
     if (p.xcd) p.variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (p.tail.tq > 0) p.variant |= WAN_ATTN_VARIANT_SPLIT_TAIL;
     return p;
@@ -1132,7 +1220,7 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
 
 extern "C" int wan_attention_plan(int batch, int Lq, int Lk, int num_heads, int head_dim, int flags, int64_t workspace_bytes) {
     if (batch <= 0 || Lq <= 0 || Lk <= 0 || num_heads <= 0 || head_dim != kD) return 0;
-    return plan_attention(batch, Lq, Lk, num_heads, (flags & WAN_ATTN_Q_PRESCALED) != 0, workspace_bytes).variant;
+    return plan_attention(batch, Lq, Lk, num_heads, (flags & WAN_ATTN_Q_PRESCALED) != 0, workspace_bytes, (flags & WAN_ATTN_QK_FP8) != 0).variant;
 }
 
 extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim) {
@@ -1140,13 +1228,18 @@ extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int 
     return flag_bytes(batch, Lq, num_heads) + plan_tail(batch, Lq, Lk, num_heads).ws_bytes;
 }
 
-extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
-                                          const void* k, int64_t ldk, int64_t k_bstride,
-                                          const void* vt, int64_t ldvt, int64_t vt_bstride,
-                                          void* out, int64_t ldo, int64_t o_bstride,
-                                          int batch, int Lq, int Lk, int num_heads, int head_dim,
-                                          float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
-                                          void* stream) {
+namespace {
+struct Qk8Operands { int q_exp, k_exp; };      // q8 = e4m3(q * softmax_scale * log2(e) * 2^q_exp), k8 = e4m3(k * 2^k_exp)
+}
+
+// q / k are bf16 tensors, or -- with `qk8` -- e4m3 tensors whose strides count BYTES
+static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bstride,
+                                       const void* k, int64_t ldk, int64_t k_bstride,
+                                       const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                       void* out, int64_t ldo, int64_t o_bstride,
+                                       int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                       float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
+                                       void* stream, const Qk8Operands* qk8) {
     WAN_REQUIRE(q && k && vt && out, WAN_ERR_INVALID, "wan_attention_fwd: null tensor");
     WAN_REQUIRE((flags & ~WAN_ATTN_Q_PRESCALED) == 0, WAN_ERR_INVALID, "wan_attention_fwd: unknown flags 0x%x", flags);
     WAN_REQUIRE(head_dim == kD, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: head_dim=%d (only 128 is built)", head_dim);
@@ -1156,6 +1249,13 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     WAN_REQUIRE(ldq >= C && ldk >= C && ldo >= C && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, WAN_ERR_INVALID,
                 "wan_attention_fwd: row strides (%lld,%lld,%lld) too small/misaligned for %d heads",
                 (long long)ldq, (long long)ldk, (long long)ldo, num_heads);
+    if (qk8) {
+        WAN_REQUIRE(ldq % 16 == 0 && ldk % 16 == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && q_bstride % 16 == 0 &&
+                        k_bstride % 16 == 0, WAN_ERR_INVALID, "wan_attention_fwd_qk8: e4m3 rows must be 16-byte aligned");
+        WAN_REQUIRE(qk8->q_exp >= -100 && qk8->q_exp <= 100 && qk8->k_exp >= -100 && qk8->k_exp <= 100, WAN_ERR_INVALID,
+                    "wan_attention_fwd_qk8: scale exponents (%d, %d) out of range", qk8->q_exp, qk8->k_exp);
+        WAN_REQUIRE(wan_tune(WAN_TUNE_ATTN_W4) != 0, WAN_ERR_UNSUPPORTED, "wan_attention_fwd_qk8: only the 4-wave kernel has an fp8 form");
+    }
     const int64_t lk_pad = ((int64_t)Lk + kKV - 1) / kKV * kKV;
     WAN_REQUIRE(ldvt >= lk_pad && ldvt % 8 == 0, WAN_ERR_INVALID,
                 "wan_attention_fwd: ldvt=%lld must be >= roundup(Lk,64)=%lld and a multiple of 8",
@@ -1171,7 +1271,9 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, true>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 2>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 2>),
-                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 2>)};
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 2>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, false, true>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1, false, true>)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
             if (e != hipSuccess) {
@@ -1185,6 +1287,13 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     AttnArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.q_bs = q_bstride;
     a.k = (const bf16_t*)k; a.ldk = ldk; a.k_bs = k_bstride;
+    a.q8 = nullptr; a.k8 = nullptr; a.ldq8 = a.ldk8 = a.q8_bs = a.k8_bs = 0; a.q8_scale = a.k8_scale = 0x7f7f7f7fu;
+    if (qk8) {
+        a.q8 = (const unsigned char*)q; a.ldq8 = ldq; a.q8_bs = q_bstride;
+        a.k8 = (const unsigned char*)k; a.ldk8 = ldk; a.k8_bs = k_bstride;
+        a.q8_scale = 0x01010101u * (unsigned)(127 - qk8->q_exp);
+        a.k8_scale = 0x01010101u * (unsigned)(127 - qk8->k_exp);
+    }
     a.vt = (const bf16_t*)vt; a.ldvt = ldvt; a.vt_bs = vt_bstride;
     a.o = (bf16_t*)out; a.ldo = ldo; a.o_bs = o_bstride;
     a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
@@ -1218,7 +1327,7 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
             ws_tail = (char*)workspace + fb;
         }
     }
-    const AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable);
+    const AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable, qk8 != nullptr);
     const TailPlan& tp = plan.tail;
     const bool fast = plan.fast;
     a.nqb = tp.tq > 0 ? tp.main_qb : nqb_all;
@@ -1230,7 +1339,10 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     const bool w4 = plan.w4, ref2 = plan.ref2;
     const dim3 block4(kW4Threads);
     int variant;
-    if (w4 && !fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
+    if (qk8) {                       // fp8 QK^T (opt-in, lossy): the lazy-reference kernel with its S product on the fp8 pipe
+        variant = WAN_ATTN_VARIANT_W4_LAZY_QK8;
+        hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, false, true>), grid, block4, kLdsBytesW4, st, a);
+    } else if (w4 && !fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
         variant = WAN_ATTN_VARIANT_W4_LAZY;
         if (ref2) {
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 2>), grid, block4, kLdsBytesW4, st, a);
@@ -1266,7 +1378,8 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
         a.ws_ml = a.ws_o + (int64_t)batch * tp.nsplit * num_heads * tp.rows_tail * kD;
         a.nqb = tp.tq; a.nbh = num_heads * batch * tp.nsplit; a.xcd_map = 0;
         dim3 tgrid((unsigned)((int64_t)a.nqb * a.nbh));
-        if (w4 && ref2) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 2>), tgrid, block4, kLdsBytesW4, st, a);
+        if (qk8) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 1, false, true>), tgrid, block4, kLdsBytesW4, st, a);
+        else if (w4 && ref2) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 2>), tgrid, block4, kLdsBytesW4, st, a);
         else if (w4) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 1>), tgrid, block4, kLdsBytesW4, st, a);
         else if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
@@ -1276,6 +1389,28 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
     wan_note_attn_variant(variant);
     WAN_CHECK_LAUNCH("wan_attention_fwd");
     return WAN_OK;
+}
+
+extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
+                                          const void* k, int64_t ldk, int64_t k_bstride,
+                                          const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                          void* out, int64_t ldo, int64_t o_bstride,
+                                          int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                          float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+    return attention_fwd_impl(q, ldq, q_bstride, k, ldk, k_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, batch, Lq, Lk, num_heads,
+                              head_dim, softmax_scale, flags, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" wan_status_t wan_attention_fwd_qk8(const void* q8, int64_t ldq8, int64_t q8_bstride, int q_exp,
+                                              const void* k8, int64_t ldk8, int64_t k8_bstride, int k_exp,
+                                              const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                              void* out, int64_t ldo, int64_t o_bstride,
+                                              int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                              void* workspace, int64_t workspace_bytes, void* stream) {
+    const Qk8Operands ops = {q_exp, k_exp};
+    return attention_fwd_impl(q8, ldq8, q8_bstride, k8, ldk8, k8_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, batch, Lq, Lk,
+                              num_heads, head_dim, 1.0f, WAN_ATTN_Q_PRESCALED, workspace, workspace_bytes, stream, &ops);
 }
 
 extern "C" wan_status_t wan_transpose_bf16(const void* in, int64_t ld, void* out_t, int64_t ldt,

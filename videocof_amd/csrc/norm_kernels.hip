@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ x0, const float* __restrict__ w0, bf16_t* __restrict__ x1,
     const float* __restrict__ w1, int64_t ld, int dim, int head_dim, float eps,
     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp, float x0_scale,
-    bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, int out_slabs, int out_batch) {
+    bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, int out_slabs, int out_batch, float x1_scale, int out_fp8) {
     __shared__ float red[kWaves];
     __shared__ __attribute__((aligned(16))) float2 cs[128];   // (cos, sin) of this token's head_dim/2 pairs
     const int64_t row = blockIdx.x;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
         }
     }
     const float rstd = rsqrtf(block_sum<kWaves>(ss, red) / (float)dim + eps)    // also orders cs[] writes
-                       * (blockIdx.y == 0 ? x0_scale : 1.f);
+                       * (blockIdx.y == 0 ? x0_scale : x1_scale);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * kThreads;
@@ -168,6 +168,12 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
             }
             if (ob == nullptr) {
                 xr[idx] = o;
+            } else if (out_fp8) {
+                // OCP e4m3 copy of the (scaled) row, dense [rows][dim] bytes: the QK^T operands of the fp8 attention variant.
+                // Re-derived from the bf16-rounded values so that it is a quantisation of exactly what the bf16 path would see.
+                u32x2 q8 = {pack_fp8x4(bf16lo_to_f32(o[0]), bf16hi_to_f32(o[0]), bf16lo_to_f32(o[1]), bf16hi_to_f32(o[1])),
+                            pack_fp8x4(bf16lo_to_f32(o[2]), bf16hi_to_f32(o[2]), bf16lo_to_f32(o[3]), bf16hi_to_f32(o[3]))};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(ob) + row * (int64_t)dim + (idx << 3)) = q8;
             } else {
                 // Ulysses send layout [slab][t][b][Cl] (layout_kernels.hip): the row's channels are split into `out_slabs` head
                 // groups, one per destination rank, so the all-to-all sends this buffer as it stands
@@ -263,13 +269,30 @@ extern "C" wan_status_t wan_quantize_rows_fp8(const void* x_bf16, int64_t ldx, v
     return WAN_OK;
 }
 
+static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, const float* w1,
+                                         int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                         const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                         float x0_scale, void* out0, void* out1, int out_slabs, int out_batch, void* stream,
+                                         float x1_scale, int out_fp8);
+
 static wan_status_t rmsnorm_rope_impl(void* x0, const float* w0, void* x1, const float* w1,
                                       int64_t ld, int64_t rows, int dim, int head_dim, float eps,
-                                      const float* rope_cos, const float* rope_sin,
-                                      const wan_rope_params* rp, float x0_scale, void* out0, void* out1, int out_slabs,
-                                      int out_batch, void* stream) {
+                                      const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                      float x0_scale, void* out0, void* out1, int out_slabs, int out_batch, void* stream) {
+    return rmsnorm_rope_impl_ex(x0, w0, x1, w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp, x0_scale, out0, out1, out_slabs,
+                                out_batch, stream, 1.0f, 0);
+}
+
+static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, const float* w1,
+                                         int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                         const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                         float x0_scale, void* out0, void* out1, int out_slabs, int out_batch, void* stream,
+                                         float x1_scale, int out_fp8) {
     WAN_REQUIRE(x0 && w0, WAN_ERR_INVALID, "wan_rmsnorm_rope: null tensor");
-    if (out0 || out1) {
+    if (out_fp8) {
+        WAN_REQUIRE(out0 != nullptr && (out1 != nullptr) == (x1 != nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope_fp8: one output per input tensor");
+        WAN_REQUIRE(x1_scale == x1_scale && x1_scale != 0.f, WAN_ERR_INVALID, "wan_rmsnorm_rope_fp8: x1_scale must be a non-zero number");
+    } else if (out0 || out1) {
         WAN_REQUIRE(rp != nullptr && rope_cos != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: needs rope tables and parameters");
         WAN_REQUIRE(out0 != nullptr && (out1 != nullptr) == (x1 != nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: one output per input tensor");
         WAN_REQUIRE(out_slabs > 0 && out_batch > 0 && dim % out_slabs == 0 && (dim / out_slabs) % 8 == 0 &&
@@ -302,7 +325,7 @@ static wan_status_t rmsnorm_rope_impl(void* x0, const float* w0, void* x1, const
     hipStream_t s = (hipStream_t)stream;
     const int nv = (dim / 8 + kThreads - 1) / kThreads;
     dim3 grid((unsigned)rows, x1 ? 2 : 1), block(kThreads);
-#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch); break;
+#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch, x1_scale, out_fp8); break;
     switch (nv) { RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) }
 #undef RR_CASE
     WAN_CHECK_LAUNCH("wan_rmsnorm_rope");
@@ -323,4 +346,13 @@ extern "C" wan_status_t wan_rmsnorm_rope_sp(const void* x0, const float* w0, con
     WAN_REQUIRE(wire0 != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: null wire buffer");
     return rmsnorm_rope_impl(const_cast<void*>(x0), w0, const_cast<void*>(x1), w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp,
                              x0_scale, wire0, wire1, slabs, batch, stream);
+}
+
+extern "C" wan_status_t wan_rmsnorm_rope_fp8(const void* x0, const float* w0, const void* x1, const float* w1,
+                                             int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                             const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                             float x0_scale, float x1_scale, void* out0_fp8, void* out1_fp8, void* stream) {
+    WAN_REQUIRE(out0_fp8 != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_fp8: null output");
+    return rmsnorm_rope_impl_ex(const_cast<void*>(x0), w0, const_cast<void*>(x1), w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp,
+                                x0_scale, out0_fp8, out1_fp8, 1, 1, stream, x1_scale, 1);
 }

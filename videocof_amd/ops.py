@@ -422,6 +422,74 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
 
 
 @_on_tensor_device
+def rmsnorm_rope_fp8(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor], w1: Optional[torch.Tensor], head_dim: int,
+                     eps: float, rope: Optional[Tuple[torch.Tensor, torch.Tensor]], rope_params: Optional[RopeParams],
+                     out0: torch.Tensor, out1: Optional[torch.Tensor], x0_scale: float = 1.0, x1_scale: float = 1.0) -> None:
+    """``rmsnorm_rope_`` that leaves x0 / x1 untouched and writes OCP e4m3 copies of the results (dense ``FP8`` [rows, dim]):
+    ``out = e4m3(bf16(result * scale))`` -- the operands of ``attention_fwd_qk8`` (include/wan_hip.h, a9')."""
+    _need(x0, torch.bfloat16, "rmsnorm_rope_fp8.x0")
+    _need(w0, torch.float32, "rmsnorm_rope_fp8.w0")
+    rows, dim = x0.shape
+    ld = x0.stride(0)
+    for nm, t in (("out0", out0), ("out1", out1)):
+        if t is not None:
+            _need(t, FP8, "rmsnorm_rope_fp8." + nm)
+            if not t.is_contiguous() or t.numel() < rows * dim:
+                raise ValueError(f"rmsnorm_rope_fp8.{nm} must be contiguous with >= rows * dim bytes")
+    if x1 is not None:
+        _need(x1, torch.bfloat16, "rmsnorm_rope_fp8.x1")
+        _need(w1, torch.float32, "rmsnorm_rope_fp8.w1")
+        if x1.shape != x0.shape or x1.stride(0) != ld or out1 is None:
+            raise ValueError("rmsnorm_rope_fp8: x0 / x1 must share shape and row stride, and x1 needs out1")
+    cos = sin = None
+    if rope is not None:
+        cos, sin = rope
+        if rope_params is None:
+            raise ValueError("rmsnorm_rope_fp8: rope tables given without rope_params")
+    lib = _lib.load()
+    _lib.check(lib.wan_rmsnorm_rope_fp8(_p(x0), _p(w0), _p(x1), _p(w1), ld, rows, dim, head_dim, float(eps), _p(cos), _p(sin),
+                                        ctypes.byref(rope_params) if rope_params is not None else None, float(x0_scale),
+                                        float(x1_scale), _p(out0), _p(out1), _stream()), "wan_rmsnorm_rope_fp8")
+
+
+@_on_tensor_device
+def attention_fwd_qk8(q8: torch.Tensor, k8: torch.Tensor, vt: torch.Tensor, num_heads: int, q_exp: int, k_exp: int,
+                      k_len: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                      workspace: Optional[AttentionWorkspace] = None) -> torch.Tensor:
+    """Self-attention with QK^T on the fp8 matrix pipe (LOSSY, opt-in; include/wan_hip.h a9').
+    q8 e4m3 [B,Lq,H*128] = e4m3(q * softmax_scale * log2(e) * 2^q_exp), k8 e4m3 [B,Lk,H*128] = e4m3(k * 2^k_exp)
+    (``rmsnorm_rope_fp8`` writes both), vt / out as ``attention_fwd``."""
+    for nm, t, dt in (("q8", q8, FP8), ("k8", k8, FP8), ("vt", vt, torch.bfloat16)):
+        _need(t, dt, "attention_qk8." + nm)
+        if t.dim() != 3:
+            raise ValueError(f"attention_qk8.{nm} must be 3-D [B, rows, cols]")
+    B, Lq, C = q8.shape
+    Lk = k8.shape[1] if k_len is None else int(k_len)
+    if Lk > k8.shape[1] or Lk <= 0:
+        raise ValueError(f"attention_qk8: k_len={Lk} outside (0, {k8.shape[1]}]")
+    head_dim = C // num_heads
+    if out is None:
+        out = torch.empty(B, Lq, C, device=q8.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "attention_qk8.out")
+    if vt.shape[1] != C or k8.shape[2] != C or k8.shape[0] != B or vt.shape[0] != B:
+        raise ValueError("attention_qk8: q8/k8/vt shapes disagree")
+    lib = _lib.load()
+    ws, ws_bytes = None, int(lib.wan_attention_workspace_bytes(B, Lq, Lk, num_heads, head_dim))
+    if ws_bytes > 0:
+        if workspace is None:
+            key = (q8.device, _stream())
+            workspace = _ATTN_WS.get(key)
+            if workspace is None:
+                workspace = _ATTN_WS[key] = AttentionWorkspace()
+        ws = workspace.get(q8.device, ws_bytes)
+    _lib.check(lib.wan_attention_fwd_qk8(_p(q8), q8.stride(1), q8.stride(0), int(q_exp), _p(k8), k8.stride(1), k8.stride(0), int(k_exp),
+                                         _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
+                                         B, Lq, Lk, num_heads, head_dim, _p(ws), ws_bytes if ws is not None else 0, _stream()),
+               "wan_attention_fwd_qk8")
+    return out
+
+
+@_on_tensor_device
 def transpose_pad(v: torch.Tensor, ldt: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 [rows, cols] -> [cols, ldt] (zero padded columns), ldt default roundup(rows, 64)."""
     _need(v, torch.bfloat16, "transpose.v")

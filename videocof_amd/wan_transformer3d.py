@@ -124,6 +124,7 @@ class WanTransformer3DModel(nn.Module):
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
         self._ctx_cache = None
         self._fp8 = ()                      # enable_fp8_linear: which projections run in e4m3 (lossy, opt-in)
+        self.fp8_attn_exponents = (5, 2)    # "attn": q8 = e4m3(q * scale * log2e * 2^5), k8 = e4m3(k * 2^2) (include/wan_hip.h a9')
         self.use_block_composite = True     # single-device blocks through wan_dit_block_forward (one C call per block)
         self.use_forward_composite = True   # ... and, when nothing hooks into the block loop, the whole token path through wan_dit_forward
         self._cdw = None                    # ctypes wan_dit_weights of the loaded blocks (built on first use)
@@ -338,12 +339,17 @@ class WanTransformer3DModel(nn.Module):
         cross-attention output projections: their bf16 input, the attention kernel's output, takes one row-quantising pass) and
         "cross" (the cross-attention query projection, fed by the quantising form of the norm3 kernel) -- all four together cover
         every per-token Linear of a block, as the reference's fp8 mode does (fp8_optimization.py:19-57); the step-invariant text
-        K / V projections stay bf16.
+        K / V projections stay bf16.  "attn" is not a Linear: it moves the self-attention QK^T product to the fp8 matrix pipe
+        (e4m3 q and k with static power-of-two scales ``fp8_attn_exponents``, written by the RMSNorm+RoPE kernel; softmax and
+        P.V stay bf16 / fp32) -- the role of the reference's ``sageattn`` branch (attention_utils.py:152-211,
+        ``attention_type = "SAGE_ATTENTION"``: 8-bit QK^T, 16-bit P.V); single-device path only.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
-        if not set(layers) <= {"qkv", "ffn", "o", "cross"} or not layers:
-            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn', 'o', 'cross'), got {layers}")
+        if not set(layers) <= {"qkv", "ffn", "o", "cross", "attn"} or not layers:
+            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn', 'o', 'cross', 'attn'), got {layers}")
+        if "attn" in layers and self.d != 128:
+            raise NotImplementedError("the fp8 QK^T attention kernel is built for head_dim 128")
         if self.dim % 128 or self.ffn_dim % 128:
             raise NotImplementedError("fp8 projections need dim and ffn_dim to be multiples of 128")
         for blk in self.blocks:
@@ -356,6 +362,8 @@ class WanTransformer3DModel(nn.Module):
                 blk.f8["o"], blk.f8["co"] = ops.quantize_weight_fp8(blk.w_o), ops.quantize_weight_fp8(blk.w_co)
             if "cross" in layers:
                 blk.f8["cq"] = ops.quantize_weight_fp8(blk.w_cq)
+            if "attn" in layers:
+                blk.f8["attn"] = True
         self._fp8 = layers
         self._bufs, self._bufs_last = {}, None
         self._graph_epoch += 1              # new e4m3 tensors: a graph captured before must not replay the old ones
@@ -550,6 +558,9 @@ class WanTransformer3DModel(nn.Module):
             if "o" in self._fp8:
                 b.attq = torch.empty(M, C, device=dev, dtype=ops.FP8)
                 b.atts = torch.empty(M, device=dev, dtype=torch.float32)
+            if "attn" in self._fp8:
+                b.q8 = torch.empty(M, C, device=dev, dtype=ops.FP8)
+                b.k8 = torch.empty(M, C, device=dev, dtype=ops.FP8)
         b.pinned = False
         self._bufs[key] = b
         self._bufs_last = key
@@ -584,21 +595,35 @@ class WanTransformer3DModel(nn.Module):
             ops.ln_modulate_fp8(xs, em[1], em[0], True, Ll, self.eps, out=bufs.hq, out_scale=bufs.rs)
         else:
             ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
+        a8 = "attn" in f8                 # QK^T on the fp8 matrix pipe: the norm+rope kernel writes e4m3 q / k instead of bf16
+        qe, ke = self.fp8_attn_exponents
+
+        def norm_rope():
+            if a8:
+                ops.rmsnorm_rope_fp8(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, bufs.q8, bufs.k8,
+                                     x0_scale=self._qs * 2.0 ** qe, x1_scale=2.0 ** ke)
+            else:
+                ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+
         if not usp and "qk" in f8:
             ops.gemm_fp8(bufs.hq, bufs.rs, *f8["qk"], blk.b_qk, ops.EPI_BF16, out=qk)
-            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+            norm_rope()
             for b in range(B):
                 ops.gemm_fp8(bufs.hq[b * Ll:(b + 1) * Ll][:L], bufs.rs[b * Ll:(b + 1) * Ll][:L], *f8["v"], blk.b_v,
                              ops.EPI_BF16_T, out=vt[b])
         elif not usp:
             ops.gemm(h, blk.w_qk, blk.b_qk, ops.EPI_BF16, out=qk)
-            ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+            norm_rope()
             for b in range(B):
                 ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
         if not usp:
             ev = self._event_pair()
-            ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True,
-                              workspace=self._ws_self)
+            if a8:
+                ops.attention_fwd_qk8(bufs.q8.view(B, Ll, C), bufs.k8.view(B, Ll, C), vt, H, qe, ke, k_len=L, out=att.view(B, Ll, C),
+                                      workspace=self._ws_self)
+            else:
+                ops.attention_fwd(qk3[:, :, :C], qk3[:, :, C:], vt, H, k_len=L, out=att.view(B, Ll, C), q_prescaled=True,
+                                  workspace=self._ws_self)
             self._event_done(ev, B * Ll)
             o_in = att
         else:
