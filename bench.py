@@ -498,7 +498,9 @@ def main():
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
         if (vcode & 15) == 4:       # fp8 QK^T: half of the flops run at the fp8 rate (2 x bf16), half (P.V) at the bf16 rate
             peak = 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS)
-            roof.update(peak=round(peak, 1), frac=round(ach / peak, 4),
+            roof.update(peak=round(peak, 1), frac=round(ach / peak, 4), traffic=None,
+                        traffic_detail={"note": "the committed PMC passes are of the bf16 kernel; none was taken for this lossy variant "
+                                                "(its K tiles are half the bytes)"},
                         dtype_peak="harmonic mix: QK^T at the dense fp8 MFMA rate (2 x bf16), P.V at the dense bf16 rate")
 
     units = world if (world > 1 and not sp) else 1            # dp: every rank denoises its own video
