@@ -45,11 +45,11 @@ def _main_loop_histogram(body):
     return hist
 
 
-@pytest.mark.parametrize("mangled,what", [("attn_fwd_w4_kernelILi0ELb0ELi0ELb0", "max-free"),
-                                           ("attn_fwd_w4_kernelILi0ELb0ELi1ELb0", "lazy reference in the accumulator"),
-                                           ("attn_fwd_w4_kernelILi0ELb0ELi1ELb1", "lazy reference, fix-up launch"),
-                                           ("attn_fwd_w4_kernelILi0ELb1ELi1ELb0", "lazy reference, split-KV tail"),
-                                           ("attn_fwd_w4_kernelILi0ELb0ELi2ELb0", "lazy reference, packed shift (plain q)")])
+@pytest.mark.parametrize("mangled,what", [("attn_fwd_w4_kernelILi0ELb0ELi0ELb0ELb0E", "max-free"),
+                                           ("attn_fwd_w4_kernelILi0ELb0ELi1ELb0ELb0E", "lazy reference in the accumulator"),
+                                           ("attn_fwd_w4_kernelILi0ELb0ELi1ELb1ELb0E", "lazy reference, fix-up launch"),
+                                           ("attn_fwd_w4_kernelILi0ELb1ELi1ELb0ELb0E", "lazy reference, split-KV tail"),
+                                           ("attn_fwd_w4_kernelILi0ELb0ELi2ELb0ELb0E", "lazy reference, packed shift (plain q)")])
 def test_attention_w4_main_loop_is_clean(attn_asm, mangled, what):
     body = _kernel(attn_asm, mangled)
     meta = "\n".join(attn_asm)
@@ -65,3 +65,23 @@ def test_attention_w4_main_loop_is_clean(attn_asm, mangled, what):
     packed = h.get("v_pk_fma_f32", 0)
     assert vector - packed <= 480, (what, vector)        # 128 MFMA + 2 x 167 others (+ the check) per two tiles
     assert packed == (64 if "packed" in what else 0)
+
+
+@pytest.mark.parametrize("mangled,what", [("attn_fwd_w4_kernelILi0ELb0ELi1ELb0ELb1E", "fp8 QK^T"),
+                                           ("attn_fwd_w4_kernelILi0ELb1ELi1ELb0ELb1E", "fp8 QK^T, split-KV tail")])
+def test_attention_qk8_main_loop_is_clean(attn_asm, mangled, what):
+    """The fp8 QK^T form: 8 scaled fp8 MFMAs + 32 bf16 MFMAs per tile, K fragments in the fixed registers a[224:255] (read by the
+    MFMAs straight from where the two ds_read_b128 of a fragment put them: no copies between the register files)."""
+    body = _kernel(attn_asm, mangled)
+    meta = "\n".join(attn_asm)
+    priv = re.search(re.escape(mangled) + r"\w*\.private_seg_size, (\d+)", meta)
+    assert priv and int(priv.group(1)) == 0, (what, "scratch", priv and priv.group(1))
+    h = _main_loop_histogram(body)                      # two KV-tile intervals
+    assert h.get("v_mfma_scale_f32_32x32x64_f8f6f4") == 16 and h.get("v_mfma_f32_32x32x16_bf16") == 64, h
+    assert h.get("v_exp_f32_e32") == 128 and h.get("ds_read_b128") == 48 and h.get("buffer_load_dwordx4") == 12
+    for bad in ("scratch_load_dword", "scratch_load_dwordx4", "scratch_store_dword", "v_accvgpr_read_b32", "v_accvgpr_write_b32",
+                "v_accvgpr_mov_b32", "v_readlane_b32", "v_writelane_b32"):
+        assert h.get(bad, 0) == 0, (what, bad, h.get(bad))
+    assert sum(c for k, c in h.items() if k.startswith("v_")) <= 420, what
+    loop = [l for l in body if "v_mfma_scale" in l and "a[0x" in l.replace("a[22", "a[0x").replace("a[23", "a[0x").replace("a[24", "a[0x")]
+    assert loop, "the loop's fp8 MFMAs read their K fragments from the fixed AGPR range"
