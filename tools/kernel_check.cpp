@@ -493,6 +493,37 @@ int main(int argc, char** argv) {
         HIP(hipDeviceSynchronize());
         printf("attnprof done\n");
     }
+    if (mode == "gemmring") {     // the four-stage-ring form of the 4-wave GEMM: numerics under every epilogue, then in-process A/B on the 14B shapes
+        if (wan_get_tuning("dev_experiments") != 1) { printf("gemmring needs a `make EXPERIMENTS=1` build\n"); return 2; }
+        WAN(wan_set_tuning("gemm_ring", 1));
+        check_gemm();
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+        const int L = 67080;
+        struct G { int M, N, K; int epi; const char* what; };
+        std::vector<G> gs = {{L, 5120, 5120, WAN_EPI_BF16, "14B o/q proj"}, {L, 10240, 5120, WAN_EPI_BF16, "14B qk proj"},
+                             {L, 13824, 5120, WAN_EPI_GELU_BF16, "14B ffn.0+gelu"}, {L, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2+resid"},
+                             {L, 5120, 5120, WAN_EPI_RESID_F32, "14B o+resid"}, {L, 5120, 5120, WAN_EPI_BF16_T, "14B v proj (T)"},
+                             {8392, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2, SP8 shard"}};
+        WAN(wan_set_tuning("gemm_variant", 2)); WAN(wan_set_tuning("gemm_w4", 3));
+        for (auto g : gs) {
+            auto hA = to_bf(randn((size_t)4096 * 64));
+            Dev<bf16> A((size_t)g.M * g.K), W((size_t)g.N * g.K);
+            for (size_t off = 0; off < A.n; off += hA.size()) HIP(hipMemcpy(A.p + off, hA.data(), std::min(hA.size(), A.n - off) * 2, hipMemcpyHostToDevice));
+            for (size_t off = 0; off < W.n; off += hA.size()) HIP(hipMemcpy(W.p + off, hA.data(), std::min(hA.size(), W.n - off) * 2, hipMemcpyHostToDevice));
+            Dev<float> bias(g.N), gate(g.N); bias.zero(); gate.zero();
+            const int64_t ldo = g.epi == WAN_EPI_BF16_T ? (g.M + 63) / 64 * 64 : g.N;
+            const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
+            Dev<char> out(osz); out.zero();
+            for (int round = 0; round < 2; ++round)
+            for (int ring = 0; ring < 2; ++ring) {
+                WAN(wan_set_tuning("gemm_ring", ring));
+                double ms = time_ms([&] { WAN(wan_gemm_bf16(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
+                                                            g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, nullptr)); }, 3, 1);
+                printf("  gemm[%s] %-20s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", ring ? "ring 4x32" : "2 x 64  ", g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
+                fflush(stdout);
+            }
+        }
+    }
     if (mode == "attnq8") {       // wan_attention_fwd_qk8: exactness against its own (quantised) operands, error against the bf16 operands, speed
         // usage: kernel_check attnq8 [q_exp k_exp]
         const int qe = argc > 3 ? atoi(argv[2]) : 5, ke = argc > 3 ? atoi(argv[3]) : 2;

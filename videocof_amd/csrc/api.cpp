@@ -63,6 +63,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"attn_ref", "WAN_ATTN_REF", 1},            // lazy softmax reference of the 4-wave kernel: 1 = -m splat in the accumulator, 2 = packed subtract
     {"conv_head", "WAN_CONV_HEAD", 1},          // causal 3x3x3 convs with <= 4 output channels on the direct (vector-ALU) kernel (0 = the gather kernel)
     {"gemm_exp", "WAN_GEMM_EXP", 0},            // TIMING-ONLY experiment of the 4-wave GEMM: bit 0 / 1 = skip the W / A tile DMA of the main loop (results are garbage)
+    {"gemm_ring", "WAN_GEMM_RING", 0},          // `make EXPERIMENTS=1` builds only: 4-wave GEMM over a four-stage ring of 32-k tiles (measured 5-9 % slower than two 64-k stages)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

@@ -427,7 +427,18 @@ constexpr int kW4Threads = 256;
 
 __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 
-template <int EPI>
+// RING (round 3): the same wave tiles, MFMA order and epilogues over a FOUR-stage LDS ring of 256 x 32-k tiles (4 x 32 KiB, rows of
+// 64 B, chunk' = chunk ^ ((row >> 2) & 3)) instead of two stages of 64 k.  Why: a K tile's 64 KB come through the CU's
+// vector-memory path at 64 B/clk -- half of the tile's MFMA time -- and the two-stage form has to bunch its 16 requests per wave into
+// 2 of 4 k-steps (they must land before the next barrier), at twice the sustainable rate, with ~1 us of flight time.  Here every
+// k-step carries 4 requests (one per 4 MFMA slots), and a request has 2-3 tiles (>= 2048 MFMA cycles) to land: tile t+4's A pieces
+// leave in k-step 1 of tile t (right behind the barrier that frees stage t % 4), its W pieces in k-step 0 of tile t+1; the barrier
+// in the middle of tile t waits (counted vmcnt) for tile t+1 only.  Price: one barrier per 32 MFMA slots instead of per 64, and
+// 64-byte instead of 128-byte row segments per request.  MEASURED (profiles/r03/gemm_ring_ab.log, in process, numerics green under
+// every epilogue): 5-9 % SLOWER on every 14B shape (q|k 1202 vs 1308, ffn.0 1222 vs 1307, ffn.2 1128 vs 1231, o 1219 vs 1285
+// TFLOP/s) -- flight time and request spacing are not what the two-stage form is short of.  Compiled only with `make EXPERIMENTS=1`
+// ("gemm_ring" = 1), like the gemm_exp variants.
+template <int EPI, bool RING = false>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
@@ -489,6 +500,32 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int s4 = 0; s4 < 4; ++s4) koff[b][s4] = b * kBufBytes + l31 * 128 + (((2 * s4 + hi) ^ sw) << 4);
     const int a_base = wr * 128 * 128, w_base = kOperandBytes + wc * 128 * 128;
 
+    // ---- RING form: staging and fragment addresses of the 32-k stages
+    constexpr int kStageBytes = 32768, kRingOperand = 16384;
+    int ra_voff = 0, rw_voff = 0;            // piece j of wave w = rows 64 w + 16 j + lane / 4 (64-B rows), LDS chunk lane & 3 <- source chunk
+    int rkoff[4][2];                         // [stage][k-step]
+    if constexpr (RING) {
+        const int row = wid * 64 + (lane >> 2);
+        const int c = (lane & 3) ^ ((lane >> 4) & 3);          // (row >> 2) & 3 == (lane >> 4) & 3 for every piece
+        ra_voff = (int)(((int64_t)row * g.lda + c * 8) * 2);
+        rw_voff = (int)(((int64_t)row * g.ldw + c * 8) * 2);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) rkoff[st][ks] = st * kStageBytes + l31 * 64 + (((2 * ks + hi) ^ ((l31 >> 2) & 3)) << 4);
+    }
+    const int nk32 = g.K / 32;
+    auto rsrc32 = [&](const char* tile, int64_t bytes, int kt) {
+        const int64_t left = kt < nk32 ? bytes - (int64_t)kt * 64 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(tile + (int64_t)min(kt, nk32 - 1) * 64), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
+    };
+    auto stage_piece32 = [&](__amdgpu_buffer_rsrc_t r, int stage, int operand, int j, int64_t ld) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            r, (__attribute__((address_space(3))) void*)(smem + stage * kStageBytes + operand * kRingOperand + (wid * 4 + j) * 1024), 16,
+            operand ? rw_voff : ra_voff, (int)(j * 16 * ld * 2), 0, 0);
+    };
+    const int ra_base = wr * 128 * 64, rw_base = kRingOperand + wc * 128 * 64;
+
     f32x16 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -540,6 +577,64 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
+    if constexpr (RING) {
+        // k-step KS (0 / 1) of a tile: 16 MFMAs on registers [KS]; even slots read the NEXT k-step's fragments (stage NST, k-step
+        // 1 - KS) into registers [1 - KS]; slots 1, 5, 9, 13 issue one DMA piece each (operand OP of the tile behind `r`, stage DST)
+        auto rkstep = [&](auto KS_, auto NST_, auto OP_, auto DST_, __amdgpu_buffer_rsrc_t r) __attribute__((always_inline)) {
+            constexpr int KS = decltype(KS_)::value, NST = decltype(NST_)::value, OP = decltype(OP_)::value, DST = decltype(DST_)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int slot = i * 4 + j;
+                    if constexpr (kTransposed) GW4_MFMA(acc[i][j], af[KS][i], wf[KS][j]);
+                    else GW4_MFMA(acc[i][j], wf[KS][j], af[KS][i]);
+                    GW4_SB();
+                    if (slot % 2 == 0) {
+                        const int f = slot / 2;
+                        if (f < 4) af[1 - KS][f] = lds16(smem + ra_base + f * 32 * 64 + rkoff[NST][1 - KS]);
+                        else wf[1 - KS][f - 4] = lds16(smem + rw_base + (f - 4) * 32 * 64 + rkoff[NST][1 - KS]);
+                    } else if (slot % 4 == 1) {
+                        stage_piece32(r, DST, OP, slot / 4, OP ? g.ldw : g.lda);
+                    }
+                    GW4_SB();
+                }
+        };
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+        // prologue: tiles 0..2 and the A half of tile 3 in flight; tile 0 waited for
+        for (int t = 0; t < 4; ++t) {
+            const __amdgpu_buffer_rsrc_t ra = rsrc32(a_tile, a_bytes, t), rw = rsrc32(w_tile, w_bytes, t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stage_piece32(ra, t, 0, j, g.lda);
+            if (t < 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) stage_piece32(rw, t, 1, j, g.ldw);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x4F74);          // vmcnt(20): everything but tile 0 may still be in flight
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            af[0][f] = lds16(smem + ra_base + f * 32 * 64 + rkoff[0][0]);
+            wf[0][f] = lds16(smem + rw_base + f * 32 * 64 + rkoff[0][0]);
+        }
+        auto rtile = [&](int t, auto ST_) __attribute__((always_inline)) {        // tile t lives in stage ST = t % 4
+            constexpr int ST = decltype(ST_)::value;
+            const __amdgpu_buffer_rsrc_t rw3 = rsrc32(w_tile, w_bytes, t + 3);      // W of tile t+3 -> stage (ST + 3) % 4 (its A went out in tile t-1)
+            const __amdgpu_buffer_rsrc_t ra4 = rsrc32(a_tile, a_bytes, t + 4);      // A of tile t+4 -> stage ST, behind the barrier
+            rkstep(J0{}, std::integral_constant<int, ST>{}, J1{}, std::integral_constant<int, (ST + 3) & 3>{}, rw3);
+            __builtin_amdgcn_s_waitcnt(0x4F70);      // vmcnt(16): my pieces of tile t+1 have landed (t+2, t+3 may be in flight) ...
+            __builtin_amdgcn_s_barrier();            // ... everybody's have, and every wave has read the last fragment of tile t
+            GW4_SB();
+            rkstep(J1{}, std::integral_constant<int, (ST + 1) & 3>{}, J0{}, std::integral_constant<int, ST>{}, ra4);
+        };
+        for (int t = 0; t < nk32; t += 4) {           // K % 128 == 0
+            rtile(t, std::integral_constant<int, 0>{});
+            rtile(t + 1, std::integral_constant<int, 1>{});
+            rtile(t + 2, std::integral_constant<int, 2>{});
+            rtile(t + 3, std::integral_constant<int, 3>{});
+        }
+    } else {
     // ---- prologue: K tile 0 -> buffer 0 (waited for), the A half of K tile 1 -> buffer 1 (in flight), fragments of k-step 0
     {
         const __amdgpu_buffer_rsrc_t ra = rsrc(a_tile, a_bytes, 0), rw = rsrc(w_tile, w_bytes, 0);
@@ -579,6 +674,7 @@ __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int kt = 0; kt < nk; kt += 2) {          // nk is even (the dispatcher sends K % 128 != 0 to the 8-wave kernel)
         ktile(kt, 0);
         ktile(kt + 1, 1);
+    }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // zero-length requests past the last tile still write LDS: let them finish
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads of the epilogue
@@ -696,6 +792,10 @@ wan_status_t launch_w4(const GemmArgs& g, hipStream_t s) {
     const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+#if WAN_DEV_EXPERIMENTS
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+#endif
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16(w4): cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
             return WAN_ERR_LAUNCH;
@@ -703,6 +803,13 @@ wan_status_t launch_w4(const GemmArgs& g, hipStream_t s) {
         return WAN_OK;
     });
     if (st != WAN_OK) return st;
+#if WAN_DEV_EXPERIMENTS     // `make EXPERIMENTS=1` only: the ring form is a measured alternative, not a product path
+    if (wan_tune(WAN_TUNE_GEMM_RING) != 0) {
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI, true>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kW4Threads), kLdsBytes, s, g);
+        WAN_CHECK_LAUNCH("wan_gemm_bf16(w4 ring)");
+        return WAN_OK;
+    }
+#endif
     hipLaunchKernelGGL((gemm_w4_kernel<EPI>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kW4Threads), kLdsBytes, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16(w4)");
     return WAN_OK;
