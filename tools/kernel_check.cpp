@@ -307,7 +307,7 @@ static void check_attn() {
         double maxabs = 0; for (size_t i = 0; i < ref.size(); ++i) maxabs = std::max(maxabs, fabs(got[i] - ref[i]));
         char nm[96]; snprintf(nm, sizeof nm, "Lq=%d Lk=%d H=%d qscale=%.0f", Lq, Lk, H, sh.qs);
         report(nm, rel_l2(ref, got), 6e-3);
-        report("   max abs err", maxabs, 3e-2, "max_abs");
+        report("   max abs err", maxabs, 3.2e-2, "max_abs");      // outputs reach |x| in [4, 8): one bf16 ulp there is 2^-5 = 3.125e-2
     }
   }
 }
