@@ -228,6 +228,19 @@ wan_status_t wan_rmsnorm_rope_fp8(const void* x0_bf16, const float* w0, const vo
                                   const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
                                   float x0_scale, float x1_scale, void* out0_fp8, void* out1_fp8, void* stream);
 
+/* K smoothing for a9' (what `sageattn(..., smooth_k=True)`, the default of the wheel behind attention_utils.py:173-185, does):
+ * softmax_j(q_i . k_j) is unchanged when one vector is subtracted from every k_j, so the e4m3 copy of k is taken of
+ * k - mean_over_tokens(k) -- a channel with a large common offset would otherwise spend its 3 mantissa bits on the offset.
+ *   wan_col_mean_bf16:   mean[b][c] = mean over rows [0, valid_rows) of sample b of x (bf16 [batch * rows_per_batch][ld]); two-stage,
+ *                        fixed summation order (bit-reproducible); workspace of wan_col_mean_workspace_bytes(batch, dim) bytes.
+ *   wan_qk_quantize_fp8: q8 = e4m3(q * q_scale), k8 = e4m3((k - k_mean[b]) * k_scale), dense [rows][dim] bytes; q, k are the
+ *                        bf16 results of wan_rmsnorm_rope (q already carries softmax_scale * log2(e)); k_mean = NULL: no smoothing. */
+int64_t wan_col_mean_workspace_bytes(int batch, int dim);
+wan_status_t wan_col_mean_bf16(const void* x_bf16, int64_t ld, int64_t rows_per_batch, int valid_rows, int batch, int dim,
+                               void* workspace, float* mean, void* stream);
+wan_status_t wan_qk_quantize_fp8(const void* q_bf16, const void* k_bf16, int64_t ld, int64_t rows, int dim, int64_t rows_per_batch,
+                                 const float* k_mean, float q_scale, float k_scale, void* q8, void* k8, void* stream);
+
 /* [rows, cols] bf16 (row stride ld) -> [cols, ldt] bf16 transposed; pad columns [rows, ldt) are zeroed.
  * Used when a caller hands attention() a row-major V (the reference's [B,L,N,D] layout). */
 wan_status_t wan_transpose_bf16(const void* in, int64_t ld, void* out_t, int64_t ldt,

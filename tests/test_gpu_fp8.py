@@ -259,8 +259,63 @@ def test_fp8_attention_small_model_follows_bf16():
     bf = m(lat, t, ctx, 420, **kw)
     m.enable_fp8_linear(("attn",))
     f8 = m(lat, t, ctx, 420, **kw)
-    e = rel_l2(f8, bf)
-    print(f"small DiT, fp8 QK^T only: output rel-L2 vs bf16 path {e:.2e}")
-    assert 0 < e < 5e-2
+    m.enable_fp8_linear(("attn",), attn_smooth_k=False)
+    f8_plain = m(lat, t, ctx, 420, **kw)
+    e, e_plain = rel_l2(f8, bf), rel_l2(f8_plain, bf)
+    print(f"small DiT, fp8 QK^T only: output rel-L2 vs bf16 path {e:.2e} (k smoothing, the default), {e_plain:.2e} (without)")
+    assert 0 < e < 5e-2 and 0 < e_plain < 5e-2 and not torch.equal(f8, f8_plain)
+    assert torch.equal(m(lat, t, ctx, 420, **kw), f8_plain)            # and the mode is bit-reproducible
     m.disable_fp8_linear()
     assert torch.equal(m(lat, t, ctx, 420, **kw), bf)
+
+
+def test_col_mean_and_qk_quantise_kernels():
+    """The two kernels behind K smoothing: a bit-reproducible column mean over the valid rows of each sample, and the e4m3 cast of
+    q * s_q and (k - mean) * s_k (torch's float8_e4m3fn cast of the same fp32 values)."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    B, Ll, L, C = 2, 700, 650, 1536
+    qk = (torch.randn(B * Ll, 2 * C, device=DEV, generator=g) * 1.5 + 0.3).bfloat16()
+    qk[:, C + 5] += 40.0                                        # a channel with a large common offset
+    k = qk[:, C:]
+    mean = ops.col_mean(k, Ll, L, B)
+    want = torch.stack([k[b * Ll:b * Ll + L].double().mean(0) for b in range(B)])
+    assert float((mean.double() - want).abs().max()) < 2e-5 * float(want.abs().max() + 1)
+    assert torch.equal(mean, ops.col_mean(k, Ll, L, B))
+    q8, k8 = torch.empty(B * Ll, C, device=DEV, dtype=ops.FP8), torch.empty(B * Ll, C, device=DEV, dtype=ops.FP8)
+    ops.qk_quantize_fp8(qk[:, :C], k, Ll, mean, 32.0, 4.0, q8, k8)
+    want_q = (qk[:, :C].float() * 32.0).clamp(-448, 448).to(ops.FP8)
+    want_k = ((k.float().view(B, Ll, C) - mean[:, None, :]) * 4.0).clamp(-448, 448).view(-1, C).to(ops.FP8)
+    assert torch.equal(q8.view(torch.uint8), want_q.view(torch.uint8))
+    assert torch.equal(k8.view(torch.uint8), want_k.view(torch.uint8))
+    ops.qk_quantize_fp8(qk[:, :C], k, Ll, None, 32.0, 4.0, q8, k8)
+    assert torch.equal(k8.view(torch.uint8), (k.float() * 4.0).clamp(-448, 448).to(ops.FP8).view(torch.uint8))
+
+
+def test_k_smoothing_rescues_fp8_attention_on_offset_channels():
+    """MODE statement for the massive-activation pattern: one channel per head of q and k carries a large common offset.  Its product is
+    the same for every key, so the softmax does not see it -- but an e4m3 k spends its 3 mantissa bits on the offset and the key-to-key
+    differences of that channel (which DO matter, multiplied by a large q) are rounded away.  Quantising k - mean(k) removes exactly
+    that; the unsmoothed error is printed next to it."""
+    Lq, Lk, H, qe, ke = 1024, 4096, 2, 5, 2
+    C = H * 128
+    g = torch.Generator(device=DEV).manual_seed(21)
+    qf = torch.randn(Lq, C, device=DEV, generator=g)
+    kf = torch.randn(Lk, C, device=DEV, generator=g)
+    for h in range(H):
+        qf[:, h * 128 + 5] = 12.0 + qf[:, h * 128 + 5]
+        kf[:, h * 128 + 5] = 20.0 + kf[:, h * 128 + 5]
+    qs_ = ops.q_prescale(128)
+    q, k = (qf * qs_).bfloat16(), kf.bfloat16()
+    v = (torch.randn(Lk, C, device=DEV, generator=g) + torch.linspace(-1, 1, C, device=DEV)).bfloat16()
+    vt = ops.transpose_pad(v)[None]
+    ref = _attention_ref_log2(q.view(-1, H, 128), k.view(-1, H, 128), v.view(-1, H, 128), Lk)
+    err = {}
+    for smooth in (False, True):
+        q8, k8 = torch.empty(Lq, C, device=DEV, dtype=ops.FP8), torch.empty(Lk, C, device=DEV, dtype=ops.FP8)
+        mean = ops.col_mean(k, Lk, Lk, 1) if smooth else None
+        ops.qk_quantize_fp8(q, q, Lq, None, 2.0 ** qe, 1.0, q8, torch.empty_like(q8))            # Lq != Lk here: q8 from one call ...
+        ops.qk_quantize_fp8(k, k, Lk, mean, 1.0, 2.0 ** ke, torch.empty_like(k8), k8)            # ... k8 from another
+        out = ops.attention_fwd_qk8(q8[None], k8[None], vt, H, qe, ke)[0]
+        err[smooth] = rel_l2(out.view(-1, H, 128), ref)
+    print(f"offset channels (q +12, k +20): fp8 QK^T rel-L2 vs bf16 operands {err[False]:.2e} without, {err[True]:.2e} with k smoothing")
+    assert err[True] < 3e-2 and err[False] > 2 * err[True]

@@ -115,6 +115,10 @@ SIGNATURES = {
     "wan_rmsnorm_rope_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                      c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_float, c_void_p, c_void_p,
                                      c_void_p]),
+    "wan_col_mean_workspace_bytes": (c_int64, [c_int, c_int]),
+    "wan_col_mean_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wan_qk_quantize_fp8": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                    c_void_p]),
     "wan_attention_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "wan_sp_unique_id": (c_int, [c_void_p]),
     "wan_sp_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),

@@ -356,3 +356,100 @@ extern "C" wan_status_t wan_rmsnorm_rope_fp8(const void* x0, const float* w0, co
     return rmsnorm_rope_impl_ex(const_cast<void*>(x0), w0, const_cast<void*>(x1), w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp,
                                 x0_scale, out0_fp8, out1_fp8, 1, 1, stream, x1_scale, 1);
 }
+
+// ------------------------------------------------------------------ K smoothing for the fp8 QK^T attention variant
+// softmax_j(q_i . k_j) does not change when one vector mu is subtracted from every k_j (it adds q_i . mu to a whole row), so the
+// e4m3 copy of k is taken of k - mean_tokens(k): a channel that carries a large common offset (the "massive activation" pattern of
+// trained checkpoints; SageAttention's smooth_k) would otherwise spend its 3 mantissa bits on the offset.  Deterministic two-stage
+// column mean (fixed summation order: no atomics), then one elementwise pass that writes both e4m3 operands.
+namespace {
+constexpr int kMeanChunks = 128;
+
+// grid (ceil(dim / 1024), kMeanChunks, batch), 128 threads x 8 columns; rows [0, valid_rows) of each sample
+__global__ __launch_bounds__(128) void col_partial_sums_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows_per_batch,
+                                                               int valid_rows, int dim, float* __restrict__ partial) {
+    const int c0 = (blockIdx.x * 128 + threadIdx.x) * 8;
+    if (c0 >= dim) return;
+    const int chunk = blockIdx.y, b = blockIdx.z;
+    const int per = (valid_rows + kMeanChunks - 1) / kMeanChunks;
+    const int r0 = chunk * per, r1 = min(valid_rows, r0 + per);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t* p = x + ((int64_t)b * rows_per_batch + r0) * ld + c0;
+    for (int r = r0; r < r1; ++r, p += ld) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[2 * j] += bf16lo_to_f32(v[j]); s[2 * j + 1] += bf16hi_to_f32(v[j]); }
+    }
+    float* o = partial + ((int64_t)b * kMeanChunks + chunk) * dim + c0;
+    *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+}
+
+__global__ __launch_bounds__(256) void col_mean_finish_kernel(const float* __restrict__ partial, int dim, float inv_rows, float* __restrict__ mean) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= dim) return;
+    float s = 0.f;
+    for (int k = 0; k < kMeanChunks; ++k) s += partial[((int64_t)b * kMeanChunks + k) * dim + c];
+    mean[(int64_t)b * dim + c] = s * inv_rows;
+}
+
+// one workgroup per row; q8 = e4m3(q * q_scale), k8 = e4m3((k - mean[b]) * k_scale); dense [rows][dim] byte outputs
+__global__ __launch_bounds__(kThreads) void qk_quantize_fp8_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld,
+                                                                   int dim, int64_t rows_per_batch, const float* __restrict__ mean,
+                                                                   float q_scale, float k_scale, unsigned char* __restrict__ q8,
+                                                                   unsigned char* __restrict__ k8) {
+    const int64_t row = blockIdx.x;
+    const float* mu = mean ? mean + (row / rows_per_batch) * dim : nullptr;
+    for (int c = threadIdx.x * 8; c < dim; c += kThreads * 8) {
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + row * ld + c), kv = *reinterpret_cast<const u32x4*>(k + row * ld + c);
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (mu) {
+            const float4 m0 = *reinterpret_cast<const float4*>(mu + c), m1 = *reinterpret_cast<const float4*>(mu + c + 4);
+            m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+        }
+        float qf[8], kf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[2 * j] = bf16lo_to_f32(qv[j]) * q_scale; qf[2 * j + 1] = bf16hi_to_f32(qv[j]) * q_scale;
+            kf[2 * j] = (bf16lo_to_f32(kv[j]) - m[2 * j]) * k_scale; kf[2 * j + 1] = (bf16hi_to_f32(kv[j]) - m[2 * j + 1]) * k_scale;
+        }
+        const u32x2 qo = {pack_fp8x4(qf[0], qf[1], qf[2], qf[3]), pack_fp8x4(qf[4], qf[5], qf[6], qf[7])};
+        const u32x2 ko = {pack_fp8x4(kf[0], kf[1], kf[2], kf[3]), pack_fp8x4(kf[4], kf[5], kf[6], kf[7])};
+        *reinterpret_cast<u32x2*>(q8 + row * (int64_t)dim + c) = qo;
+        *reinterpret_cast<u32x2*>(k8 + row * (int64_t)dim + c) = ko;
+    }
+}
+}  // namespace
+
+extern "C" int64_t wan_col_mean_workspace_bytes(int batch, int dim) {
+    return batch > 0 && dim > 0 ? (int64_t)batch * kMeanChunks * dim * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" wan_status_t wan_col_mean_bf16(const void* x_bf16, int64_t ld, int64_t rows_per_batch, int valid_rows, int batch, int dim,
+                                          void* workspace, float* mean, void* stream) {
+    WAN_REQUIRE(x_bf16 && workspace && mean, WAN_ERR_INVALID, "wan_col_mean_bf16: null tensor");
+    WAN_REQUIRE(dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= dim, WAN_ERR_INVALID, "wan_col_mean_bf16: dim=%d ld=%lld", dim, (long long)ld);
+    WAN_REQUIRE(batch > 0 && valid_rows > 0 && rows_per_batch >= valid_rows, WAN_ERR_INVALID,
+                "wan_col_mean_bf16: batch=%d valid_rows=%d rows_per_batch=%lld", batch, valid_rows, (long long)rows_per_batch);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(col_partial_sums_kernel, dim3((unsigned)((dim + 1023) / 1024), kMeanChunks, (unsigned)batch), dim3(128), 0, s,
+                       (const bf16_t*)x_bf16, ld, rows_per_batch, valid_rows, dim, (float*)workspace);
+    hipLaunchKernelGGL(col_mean_finish_kernel, dim3((unsigned)((dim + 255) / 256), (unsigned)batch), dim3(256), 0, s,
+                       (const float*)workspace, dim, 1.0f / (float)valid_rows, mean);
+    WAN_CHECK_LAUNCH("wan_col_mean_bf16");
+    return WAN_OK;
+}
+
+extern "C" wan_status_t wan_qk_quantize_fp8(const void* q_bf16, const void* k_bf16, int64_t ld, int64_t rows, int dim,
+                                            int64_t rows_per_batch, const float* k_mean, float q_scale, float k_scale,
+                                            void* q8, void* k8, void* stream) {
+    WAN_REQUIRE(q_bf16 && k_bf16 && q8 && k8, WAN_ERR_INVALID, "wan_qk_quantize_fp8: null tensor");
+    WAN_REQUIRE(dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= dim && rows >= 0 && rows_per_batch > 0, WAN_ERR_INVALID,
+                "wan_qk_quantize_fp8: dim=%d ld=%lld rows=%lld rows_per_batch=%lld", dim, (long long)ld, (long long)rows, (long long)rows_per_batch);
+    WAN_REQUIRE(q_scale == q_scale && k_scale == k_scale && q_scale != 0.f && k_scale != 0.f, WAN_ERR_INVALID, "wan_qk_quantize_fp8: scales must be non-zero numbers");
+    if (rows == 0) return WAN_OK;
+    hipLaunchKernelGGL(qk_quantize_fp8_kernel, dim3((unsigned)rows), dim3(kThreads), 0, (hipStream_t)stream, (const bf16_t*)q_bf16,
+                       (const bf16_t*)k_bf16, ld, dim, rows_per_batch, k_mean, q_scale, k_scale, (unsigned char*)q8, (unsigned char*)k8);
+    WAN_CHECK_LAUNCH("wan_qk_quantize_fp8");
+    return WAN_OK;
+}

@@ -142,7 +142,7 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
     if getattr(model, "_fp8", ()):
         # the reference quantises first and merges afterwards (fast_infer.py:352-359, 371-385): the e4m3 copies made by
         # enable_fp8_linear must follow the merged bf16 weights, or q|k / v / ffn keep running the pre-LoRA values
-        model.enable_fp8_linear(model._fp8)
+        model.enable_fp8_linear(model._fp8, attn_smooth_k=model.fp8_attn_smooth_k)
     return pipeline
 
 

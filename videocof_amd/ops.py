@@ -453,6 +453,51 @@ def rmsnorm_rope_fp8(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tens
 
 
 @_on_tensor_device
+def col_mean(x: torch.Tensor, rows_per_batch: int, valid_rows: int, batch: int, out: Optional[torch.Tensor] = None,
+             workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [batch, dim]: mean over the first ``valid_rows`` rows of every sample of bf16 x [batch * rows_per_batch, dim] (row
+    stride free).  Two-stage, fixed summation order.  ``workspace``: fp32, >= wan_col_mean_workspace_bytes / 4 elements."""
+    _need(x, torch.bfloat16, "col_mean.x")
+    dim = x.shape[1]
+    lib = _lib.load()
+    need = int(lib.wan_col_mean_workspace_bytes(batch, dim)) // 4
+    if workspace is None:
+        workspace = torch.empty(need, device=x.device, dtype=torch.float32)
+    _need(workspace, torch.float32, "col_mean.workspace")
+    if workspace.numel() < need or not workspace.is_contiguous():
+        raise ValueError(f"col_mean.workspace needs {need} contiguous fp32 elements")
+    if out is None:
+        out = torch.empty(batch, dim, device=x.device, dtype=torch.float32)
+    _need(out, torch.float32, "col_mean.out")
+    _lib.check(lib.wan_col_mean_bf16(_p(x), x.stride(0), int(rows_per_batch), int(valid_rows), int(batch), dim, _p(workspace), _p(out),
+                                     _stream()), "wan_col_mean_bf16")
+    return out
+
+
+@_on_tensor_device
+def qk_quantize_fp8(q: torch.Tensor, k: torch.Tensor, rows_per_batch: int, k_mean: Optional[torch.Tensor], q_scale: float,
+                    k_scale: float, q8: torch.Tensor, k8: torch.Tensor) -> None:
+    """q8 = e4m3(q * q_scale), k8 = e4m3((k - k_mean[sample]) * k_scale) from two bf16 [rows, dim] views sharing a row stride
+    (``k_mean`` fp32 [batch, dim] or None); dense ``FP8`` [rows, dim] outputs."""
+    _need(q, torch.bfloat16, "qk_quantize_fp8.q")
+    _need(k, torch.bfloat16, "qk_quantize_fp8.k")
+    if q.shape != k.shape or q.stride(0) != k.stride(0):
+        raise ValueError("qk_quantize_fp8: q and k must share shape and row stride")
+    rows, dim = q.shape
+    for nm, t in (("q8", q8), ("k8", k8)):
+        _need(t, FP8, "qk_quantize_fp8." + nm)
+        if not t.is_contiguous() or t.numel() < rows * dim:
+            raise ValueError(f"qk_quantize_fp8.{nm} must be contiguous with >= rows * dim bytes")
+    if k_mean is not None:
+        _need(k_mean, torch.float32, "qk_quantize_fp8.k_mean")
+        if not k_mean.is_contiguous() or k_mean.shape[-1] != dim:
+            raise ValueError("qk_quantize_fp8.k_mean must be contiguous [batch, dim]")
+    lib = _lib.load()
+    _lib.check(lib.wan_qk_quantize_fp8(_p(q), _p(k), q.stride(0), rows, dim, int(rows_per_batch), _p(k_mean), float(q_scale),
+                                       float(k_scale), _p(q8), _p(k8), _stream()), "wan_qk_quantize_fp8")
+
+
+@_on_tensor_device
 def attention_fwd_qk8(q8: torch.Tensor, k8: torch.Tensor, vt: torch.Tensor, num_heads: int, q_exp: int, k_exp: int,
                       k_len: Optional[int] = None, out: Optional[torch.Tensor] = None,
                       workspace: Optional[AttentionWorkspace] = None) -> torch.Tensor:

@@ -125,6 +125,7 @@ class WanTransformer3DModel(nn.Module):
         self._ctx_cache = None
         self._fp8 = ()                      # enable_fp8_linear: which projections run in e4m3 (lossy, opt-in)
         self.fp8_attn_exponents = (5, 2)    # "attn": q8 = e4m3(q * scale * log2e * 2^5), k8 = e4m3(k * 2^2) (include/wan_hip.h a9')
+        self.fp8_attn_smooth_k = True       # "attn": quantise k - mean_tokens(k) (sageattn's smooth_k; softmax-invariant)
         self.use_block_composite = True     # single-device blocks through wan_dit_block_forward (one C call per block)
         self.use_forward_composite = True   # ... and, when nothing hooks into the block loop, the whole token path through wan_dit_forward
         self._cdw = None                    # ctypes wan_dit_weights of the loaded blocks (built on first use)
@@ -247,7 +248,7 @@ class WanTransformer3DModel(nn.Module):
         for ws in (self._ws_self, self._ws_cross, self._ws_self_sfx, self._ws_cross_sfx):
             ws.reset()                                 # the sticky "max-free attempt off" word described the OLD weights' scores
         if self._fp8:
-            self.enable_fp8_linear(self._fp8)          # re-quantise from the new bf16 weights
+            self.enable_fp8_linear(self._fp8, attn_smooth_k=self.fp8_attn_smooth_k)          # re-quantise from the new bf16 weights
         return IncompatibleKeys(missing, extra)
 
     def state_dict(self, *args, **kwargs):  # type: ignore[override]
@@ -328,7 +329,7 @@ class WanTransformer3DModel(nn.Module):
             raise ValueError(f"num_heads={self.num_heads} is not divisible by ulysses degree {sp.world_size}")
         self._sp, self.sp_world_size, self.sp_world_rank = sp, sp.world_size, sp.rank
 
-    def enable_fp8_linear(self, layers=("qkv", "ffn")):
+    def enable_fp8_linear(self, layers=("qkv", "ffn"), attn_smooth_k: bool = True):
         """FP8 (OCP e4m3) projections, SURVEY.md 8f-4 -- an explicit LOSSY option, off by default and never used by a
         parity statement or the headline benchmark.  The reference's fp8 mode (``convert_model_weight_to_float8`` +
         ``convert_weight_dtype_wrapper``, videox_fun/utils/fp8_optimization.py:19-57; ``GPU_memory_mode =
@@ -342,7 +343,10 @@ class WanTransformer3DModel(nn.Module):
         K / V projections stay bf16.  "attn" is not a Linear: it moves the self-attention QK^T product to the fp8 matrix pipe
         (e4m3 q and k with static power-of-two scales ``fp8_attn_exponents``, written by the RMSNorm+RoPE kernel; softmax and
         P.V stay bf16 / fp32) -- the role of the reference's ``sageattn`` branch (attention_utils.py:152-211,
-        ``attention_type = "SAGE_ATTENTION"``: 8-bit QK^T, 16-bit P.V); single-device path only.
+        ``attention_type = "SAGE_ATTENTION"``: 8-bit QK^T, 16-bit P.V); single-device path only.  ``attn_smooth_k`` (default on, as
+        ``sageattn``'s ``smooth_k``): the e4m3 copy of k is taken of k minus its per-sample mean over the tokens, which the softmax
+        cannot see and which keeps a channel with a large common offset from eating the 3 mantissa bits (one extra 0.5 ms pass
+        per layer at the 14B shape); off: the RMSNorm+RoPE kernel writes the e4m3 operands directly.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
@@ -352,6 +356,7 @@ class WanTransformer3DModel(nn.Module):
             raise NotImplementedError("the fp8 QK^T attention kernel is built for head_dim 128")
         if self.dim % 128 or self.ffn_dim % 128:
             raise NotImplementedError("fp8 projections need dim and ffn_dim to be multiples of 128")
+        self.fp8_attn_smooth_k = bool(attn_smooth_k)
         for blk in self.blocks:
             blk.f8 = {}
             if "qkv" in layers:
@@ -561,6 +566,9 @@ class WanTransformer3DModel(nn.Module):
             if "attn" in self._fp8:
                 b.q8 = torch.empty(M, C, device=dev, dtype=ops.FP8)
                 b.k8 = torch.empty(M, C, device=dev, dtype=ops.FP8)
+                b.kmean = torch.empty(B, C, device=dev, dtype=torch.float32)
+                from ._lib import load
+                b.kmean_ws = torch.empty(int(load().wan_col_mean_workspace_bytes(B, C)) // 4, device=dev, dtype=torch.float32)
         b.pinned = False
         self._bufs[key] = b
         self._bufs_last = key
@@ -599,7 +607,12 @@ class WanTransformer3DModel(nn.Module):
         qe, ke = self.fp8_attn_exponents
 
         def norm_rope():
-            if a8:
+            if a8 and self.fp8_attn_smooth_k:
+                # K smoothing (sageattn's smooth_k): the bf16 norm + rope as usual, the per-sample token mean of k, then e4m3 q and k - mean
+                ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
+                ops.col_mean(qk[:, C:], Ll, L, B, out=bufs.kmean, workspace=bufs.kmean_ws)
+                ops.qk_quantize_fp8(qk[:, :C], qk[:, C:], Ll, bufs.kmean, 2.0 ** qe, 2.0 ** ke, bufs.q8, bufs.k8)
+            elif a8:
                 ops.rmsnorm_rope_fp8(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, bufs.q8, bufs.k8,
                                      x0_scale=self._qs * 2.0 ** qe, x1_scale=2.0 ** ke)
             else:
