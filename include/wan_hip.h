@@ -58,6 +58,7 @@ int wan_get_tuning(const char* key);
 #define WAN_ATTN_VARIANT_W4_MAXFREE 2       /* attn_fwd_w4_kernel<.,false,0> + its checked fix-up launch attn_fwd_w4_kernel<.,false,1,true> */
 #define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* attn_fwd_v2_kernel, 8 waves, running max per tile ("attn_w4" = 0: developer A/B partner) */
 #define WAN_ATTN_VARIANT_W4_LAZY_QK8 4      /* attn_fwd_w4_kernel<0,.,1,false,true>: the lazy form with QK^T on the fp8 matrix pipe (wan_attention_fwd_qk8) */
+#define WAN_ATTN_VARIANT_W4_F8 5            /* attn_fwd_f8_kernel (fp8 QK^T and fp8 P.V, checked max-free softmax) + the fp8-QK^T lazy kernel on flagged workgroups (wan_attention_fwd_f8) */
 #define WAN_ATTN_VARIANT_FAMILY_MASK 15
 #define WAN_ATTN_VARIANT_XCD_PINNED 16      /* every (batch, head) pinned to one XCD */
 #define WAN_ATTN_VARIANT_SPLIT_TAIL 32      /* the last partial round ran split over the keys (+ merge kernel) */
@@ -220,6 +221,23 @@ wan_status_t wan_attention_fwd_qk8(const void* q8, int64_t ldq8, int64_t q8_bstr
                                    void* out, int64_t ldo, int64_t o_bstride,
                                    int batch, int Lq, int Lk, int num_heads, int head_dim,
                                    void* workspace, int64_t workspace_bytes, void* stream);
+/* a9'' Both attention products on the fp8 matrix pipe (LOSSY, opt-in; SageAttention-2's operating point: 8-bit QK^T, fp8 P.V).
+ *     q8 / k8 / vt / out / workspace as wan_attention_fwd_qk8 (the scratch is REQUIRED here: the softmax is the checked max-free form,
+ *     a flagged workgroup is redone by the fp8-QK^T lazy-reference kernel with the bf16 vt).  v8 / v8_scales: V^T as MX e4m3, written by
+ *     wan_vt_quantize_mx from the bf16 vt -- per channel row and per block of 32 consecutive keys one E8M0 scale (block max / scale in [128, 256)),
+ *     the 64 keys of a tile stored in the order the kernel's P registers hold them; v8 [B][H*128][ldv8 bytes], ldv8 >= roundup(Lk, 64),
+ *     % 16; v8_scales: wan_vt_mx_scale_bytes(batch, heads, Lk) bytes.  P is quantised inside the kernel, also as MX blocks (32 keys
+ *     per query row, scale from the block's fp32 sum), so neither operand needs a bounded range.  Error / speed: DESIGN.md section 13. */
+wan_status_t wan_attention_fwd_f8(const void* q8, int64_t ldq8, int64_t q8_bstride, int q_exp,
+                                  const void* k8, int64_t ldk8, int64_t k8_bstride, int k_exp,
+                                  const void* v8, int64_t ldv8, int64_t v8_bstride, const void* v8_scales,
+                                  const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                  void* out, int64_t ldo, int64_t o_bstride,
+                                  int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
+int64_t wan_vt_mx_scale_bytes(int batch, int num_heads, int Lk);
+wan_status_t wan_vt_quantize_mx(const void* vt_bf16, int64_t ldvt, int64_t vt_bstride, int batch, int num_heads, int Lk,
+                                void* v8, int64_t ldv8, int64_t v8_bstride, void* v8_scales, void* stream);
 /* wan_rmsnorm_rope that leaves x0 / x1 untouched and writes e4m3 copies of the results, dense [rows][dim] bytes:
  * out0 = e4m3(bf16(result0 * x0_scale)), out1 = e4m3(bf16(result1 * x1_scale)) -- the bf16 rounding first, so that with
  * power-of-two extra factors the e4m3 value is a quantisation of exactly the number the bf16 path would have used. */

@@ -596,6 +596,113 @@ int main(int argc, char** argv) {
             }
         }
     }
+    if (mode == "attnf8") {       // wan_attention_fwd_f8 (fp8 QK^T and fp8 P.V): the V^T quantiser, the kernel against its own operands, speed
+        const int qe = 5, ke = 2;
+        auto f2e4m3 = [](float x) -> uint8_t {
+            const uint8_t sgn = x < 0 ? 0x80 : 0; float ax = fabsf(x);
+            if (!(ax == ax)) return 0x7f;
+            if (ax >= 448.f) return sgn | 0x7e;
+            if (ax < 0.015625f) return sgn | (uint8_t)lrintf(ax * 512.f);
+            uint32_t u; memcpy(&u, &ax, 4);
+            u += 0x7ffffu + ((u >> 20) & 1); u &= ~0xfffffu;
+            const int e = (int)(u >> 23) - 127 + 7; const uint32_t m = (u >> 20) & 7;
+            return sgn | (uint8_t)((e << 3) | m);
+        };
+        auto e4m32f = [](uint8_t b) -> float {
+            const int e = (b >> 3) & 15, m = b & 7; const float v = e == 0 ? m * (1.f / 512.f) : ldexpf(1.f + m / 8.f, e - 7);
+            return (b & 0x80) ? -v : v;
+        };
+        const float scale = 1.f / sqrtf(128.f), cc = WAN_ATTN_QSCALE(scale);
+        struct Shape { int Lq, Lk, H; float qs; };
+        for (Shape sh : {Shape{300, 420, 2, 1.f}, Shape{64, 64, 1, 1.f}, Shape{257, 8, 3, 1.f}, Shape{33, 1000, 1, 6.f}, Shape{520, 1500, 2, 40.f},
+                         Shape{256, 4096, 1, 100.f}, Shape{86 * 256 + 10, 1100, 3, 1.f}}) {
+            const int Lq = sh.Lq, Lk = sh.Lk, H = sh.H, C = H * 128;
+            auto q = bf_round(randn((size_t)Lq * C, sh.qs)), k = bf_round(randn((size_t)Lk * C)), v = bf_round(randn((size_t)Lk * C));
+            for (int j = 0; j < Lk; ++j) for (int c = 0; c < C; ++c) v[(size_t)j * C + c] = bf2f(f2bf(v[(size_t)j * C + c] + 0.01f * (c % 128) - 0.003f * (j % 97)));
+            std::vector<uint8_t> q8(q.size()), k8(k.size());
+            std::vector<float> qd(q.size()), kd(k.size()), qb(q.size());
+            for (size_t i = 0; i < q.size(); ++i) {
+                qb[i] = bf2f(f2bf(q[i] * cc));
+                q8[i] = f2e4m3(ldexpf(qb[i], qe)); qd[i] = ldexpf(e4m32f(q8[i]), -qe) / cc; qb[i] /= cc;
+            }
+            for (size_t i = 0; i < k.size(); ++i) { k8[i] = f2e4m3(ldexpf(k[i], ke)); kd[i] = ldexpf(e4m32f(k8[i]), -ke); }
+            const int64_t ldvt = (Lk + 63) / 64 * 64; const int nt = (int)(ldvt / 64);
+            Dev<uint8_t> dq8(q8), dk8(k8), dv8((size_t)C * ldvt), dvs((size_t)wan_vt_mx_scale_bytes(1, H, Lk));
+            Dev<bf16> dv(to_bf(v)), dvt((size_t)C * ldvt), dout((size_t)Lq * C);
+            WAN(wan_transpose_bf16(dv.p, C, dvt.p, ldvt, Lk, C, nullptr));
+            WAN(wan_vt_quantize_mx(dvt.p, ldvt, 0, 1, H, Lk, dv8.p, ldvt, 0, dvs.p, nullptr));
+            HIP(hipDeviceSynchronize());
+            // de-quantise V on the host from what the device wrote (layout: position 32 hi + 16 kt + 8 g + j <- key 32 kt + 16 g + 8 hi + j)
+            auto hv8 = dv8.host(); auto hvs = dvs.host();
+            std::vector<float> vd((size_t)Lk * C);
+            double vnum = 0, vden = 0; bool range_ok = true;
+            for (int c = 0; c < C; ++c) for (int key = 0; key < Lk; ++key) {
+                const int tile = key >> 6, kk = key & 63, kt = kk >> 5, g = (kk >> 4) & 1, hi = (kk >> 3) & 1, j = kk & 7, d = c & 127, head = c >> 7;
+                const uint8_t b = hv8[(size_t)c * ldvt + tile * 64 + 32 * hi + 16 * kt + 8 * g + j];
+                const uint8_t sb = hvs[((size_t)head * nt + tile) * 256 + (32 * kt + (d & 31)) * 4 + (d >> 5)];      // MX block = (row, 32 consecutive keys)
+                if (fabsf(e4m32f(b)) > 256.f) range_ok = false;            // block max / scale is in [128, 256): rounds to <= 256
+                const float val = ldexpf(e4m32f(b), (int)sb - 127);
+                vd[(size_t)key * C + c] = val;
+                const double dd = val - v[(size_t)key * C + c]; vnum += dd * dd; vden += (double)v[(size_t)key * C + c] * v[(size_t)key * C + c];
+            }
+            if (getenv("F8_DEBUG")) {
+                for (int key = 0; key < std::min(Lk, 72); key += 1) {
+                    const int c = 5; const int tile = key >> 6, kk = key & 63, kt = kk >> 5, g = (kk >> 4) & 1, hi = (kk >> 3) & 1, j = kk & 7, d = c & 127;
+                    printf("    c=5 key=%2d v=% .4f  byte 0x%02x scale 0x%02x -> % .4f | raw row bytes at key pos 0x%02x\n", key, v[(size_t)key * C + c],
+                           hv8[(size_t)c * ldvt + tile * 64 + 32 * hi + 16 * kt + 8 * g + j], hvs[((size_t)0 * nt + tile) * 256 + (32 * kt + (d & 31)) * 4 + (d >> 5)],
+                           vd[(size_t)key * C + c], hv8[(size_t)c * ldvt + key]);
+                }
+            }
+            char nm[160]; snprintf(nm, sizeof nm, "f8 Lq=%d Lk=%d H=%d qscale=%.0f: wan_vt_quantize_mx round trip (MX e4m3, block values < 256: %s)", Lq, Lk, H, sh.qs, range_ok ? "yes" : "NO");
+            report(nm, sqrt(vnum / vden) + (range_ok ? 0 : 1), 4e-2);
+            const int64_t wsb = wan_attention_workspace_bytes(1, Lq, Lk, H, 128);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            WAN(wan_attention_fwd_f8(dq8.p, C, 0, qe, dk8.p, C, 0, ke, dv8.p, ldvt, 0, dvs.p, dvt.p, ldvt, 0, dout.p, C, 0, 1, Lq, Lk, H, 128, ws.p, wsb, nullptr));
+            HIP(hipDeviceSynchronize());
+            std::vector<int> hdr(4); HIP(hipMemcpy(hdr.data(), ws.p, 16, hipMemcpyDeviceToHost));
+            std::vector<int> rows;
+            for (int i = 0; i < Lq; ++i) if (Lq <= 1024 || i < 64 || i >= Lq - 600 || i % 211 == 0) rows.push_back(i);
+            std::vector<double> ref, ref16; attn_ref(qd, kd, vd, Lq, Lk, H, scale, ref, rows); attn_ref(qb, k, v, Lq, Lk, H, scale, ref16, rows);
+            auto all = bf_to_f(dout.host());
+            std::vector<float> got(rows.size() * C);
+            for (size_t ri = 0; ri < rows.size(); ++ri) memcpy(&got[ri * C], &all[(size_t)rows[ri] * C], C * sizeof(float));
+            if (getenv("F8_DEBUG")) {
+                for (int ri : {0, 1, 40}) if (ri < (int)rows.size())
+                    for (int c : {0, 5, 64, 127})
+                        printf("    row %d c %d: got % .4f  ref(own operands) % .4f  ref(bf16 operands) % .4f\n", rows[ri], c, got[(size_t)ri * C + c], ref[(size_t)ri * C + c], ref16[(size_t)ri * C + c]);
+            }
+            snprintf(nm, sizeof nm, "   attention vs its own e4m3 q, k, V (what is left: the MX e4m3 rounding of P; variant 0x%x, redone %d)", wan_get_tuning("last_attn_variant"), hdr[1]);
+            report(nm, rel_l2(ref, got), 4e-2);
+            printf("       error against the bf16 operands: rel_l2 %.3e\n", rel_l2(ref16, got));
+        }
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+        {   // speed at the bench shape, alternating in one process
+            const int L = 67080, H = 40, C = H * 128; const int64_t ldvt = (L + 63) / 64 * 64;
+            auto hf = randn((size_t)4096 * 128);
+            auto hq = to_bf(hf);
+            std::vector<uint8_t> h8q(hf.size()), h8k(hf.size());
+            for (size_t i = 0; i < hf.size(); ++i) { h8q[i] = f2e4m3(ldexpf(bf2f(f2bf(hf[i] * cc)), qe)); h8k[i] = f2e4m3(ldexpf(bf2f(hq[i]), ke)); }
+            Dev<bf16> q((size_t)L * C), k((size_t)L * C), vt((size_t)C * ldvt), o((size_t)L * C);
+            Dev<uint8_t> q8((size_t)L * C), k8((size_t)L * C), v8((size_t)C * ldvt), vs((size_t)wan_vt_mx_scale_bytes(1, H, L));
+            auto fill = [&](auto& d, const auto& src) { for (size_t off = 0; off < d.n; off += src.size()) HIP(hipMemcpy(d.p + off, src.data(), std::min(src.size(), d.n - off) * sizeof(src[0]), hipMemcpyHostToDevice)); };
+            fill(k, hq); fill(vt, hq); fill(q8, h8q); fill(k8, h8k);
+            { std::vector<float> t = bf_to_f(hq); for (auto& x : t) x *= cc; fill(q, to_bf(t)); }
+            const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            double msq = time_ms([&] { WAN(wan_vt_quantize_mx(vt.p, ldvt, 0, 1, H, L, v8.p, ldvt, 0, vs.p, nullptr)); }, 3, 1);
+            printf("  wan_vt_quantize_mx L=%d H=%d: %.3f ms (%.0f GB/s)\n", L, H, msq, 3.0 * C * ldvt / msq / 1e6);
+            for (int round = 0; round < 2; ++round) {
+                double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, scale, WAN_ATTN_Q_PRESCALED, ws.p, wsb, nullptr)); }, 4, 1);
+                printf("  bf16 dispatch       L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
+                ms = time_ms([&] { WAN(wan_attention_fwd_qk8(q8.p, C, 0, qe, k8.p, C, 0, ke, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, ws.p, wsb, nullptr)); }, 4, 1);
+                printf("  fp8 QK^T            L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
+                ms = time_ms([&] { WAN(wan_attention_fwd_f8(q8.p, C, 0, qe, k8.p, C, 0, ke, v8.p, ldvt, 0, vs.p, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, ws.p, wsb, nullptr)); }, 4, 1);
+                std::vector<int> hdr(4); HIP(hipMemcpy(hdr.data(), ws.p, 16, hipMemcpyDeviceToHost));
+                printf("  fp8 QK^T + fp8 P.V  L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x, redone workgroups %d)\n", L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"), hdr[1]);
+                fflush(stdout);
+            }
+        }
+    }
     if (mode == "attnx") {        // in-process A/B of the self-attention launch at the bench shape: tuning key=value sets from argv
         // usage: kernel_check attnx [H] "k1=v1,k2=v2" "k1=v1" ...   (each quoted group is one arm; "" = defaults)
         const int L = 67080; int H = 40; int first = 2;

@@ -66,6 +66,10 @@ struct AttnArgs {
     const unsigned char* q8; int64_t ldq8, q8_bs;
     const unsigned char* k8; int64_t ldk8, k8_bs;
     unsigned q8_scale, k8_scale;
+    // fp8 P.V form (wan_attention_fwd_f8): V^T as MX e4m3 [B][H*128][ldv8 bytes] (keys of a 64-tile in register order) and its
+    // scale bytes [B][H][tiles][64 lanes][4 d-blocks] (vs8_hs = bytes per head), both written by wan_vt_quantize_mx
+    const unsigned char* v8; int64_t ldv8, v8_bs;
+    const unsigned char* vs8; int64_t vs8_hs;
     int tile_mask;        // developer experiment (attn_exp & 1): staging reads tile (t & tile_mask); 0x7fffffff in product
     int exp_nocheck;      // developer experiment (attn_exp & 2), TIMING ONLY: the lazy form skips its per-tile window check
 };
@@ -529,7 +533,7 @@ template <int VARIANT, bool SPLIT, int REF, bool FIX = false, bool QK8 = false>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {
     constexpr bool MAXFREE = REF == 0, SPLAT = REF == 1, PKSUB = REF == 2;
-    static_assert(!QK8 || (SPLAT && !FIX && VARIANT == 0), "the fp8 QK^T form is the self-attention lazy-reference kernel");
+    static_assert(!QK8 || (SPLAT && VARIANT == 0), "the fp8 QK^T form is the self-attention lazy-reference kernel");
     static_assert(!(SPLIT && MAXFREE), "the split tail round runs the lazy-reference form");
     static_assert(!FIX || (!SPLIT && !MAXFREE), "the fix-up launch is the unsplit lazy-reference form");
     const int wg_linear = blockIdx.x;
@@ -707,6 +711,8 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 // 32 as clobbered, so hipcc keeps its own AGPR values (O, Q, the V^T ring) out of that range.
 #define W8_KCLOB "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
                  "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define W8_VCLOB "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+                 "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"
 #define W8K_MFMA_C(D, F, B, C) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%5:%6], %1, %2, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(D) : "a"(B), "v"(C), "v"(sc_k), "v"(sc_q), "i"(224 + 8 * (F)), "i"(231 + 8 * (F)) : W8_KCLOB)
 #define W8K_MFMA_S(D, F, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%4:%5], %1, %0, %2, %3 op_sel_hi:[0,0,0]" : "+v"(D) : "a"(B), "v"(sc_k), "v"(sc_q), "i"(224 + 8 * (F)), "i"(231 + 8 * (F)) : W8_KCLOB)
     if constexpr (QK8) {
@@ -1002,7 +1008,6 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #undef W8_MFMA_SV
 #undef W8K_MFMA_C
 #undef W8K_MFMA_S
-#undef W8_KCLOB
 #undef W4_MFMA0
 #undef W4A_MFMA_C
 #undef W4_SCALE_ACC
@@ -1057,6 +1062,376 @@ void attn_fwd_w4_kernel(AttnArgs a) {
                     *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
                 }
         }
+    }
+}
+
+// ====================================================================================================
+// fp8 QK^T AND fp8 P.V (opt-in, lossy; wan_attention_fwd_f8): the 4-wave structure with BOTH products on the fp8 matrix pipe --
+// 16 x v_mfma_scale_f32_32x32x64_f8f6f4 per tile (256 matrix-pipe passes; the fp8-QK^T form: 384, bf16: 512).
+//   * S = K.Q^T as in the QK8 form (e4m3 q / k with static power-of-two scales undone by the MFMA's operand scales);
+//   * operand layout of the 32x32x64 fp8 MFMA (tools/probe/mx_block_probe.hip): byte b of lane (row, hi) is k = 32 (b >> 4) + 16 hi + (b & 15),
+//     and the MX block kb (k in [32 kb, 32 kb + 32)) -- bytes [16 kb, 16 kb + 16) of BOTH lanes of a row -- takes its scale from lane hi = kb.
+//     With the key order of the S registers (byte 16 kt + 8 g + j of lane hi = key 32 kt + 16 g + 8 hi + j) block kb is simply the key
+//     half kt = kb of the tile: 32 consecutive keys;
+//   * P is quantised as MX blocks: the 32 probabilities of one query row and key half (16 in each of the row's two lanes) share ONE
+//     power-of-two scale taken from their fp32 sum s (one v_permlane32_swap + add per query block; scale = 2^(floor(log2 s) - 7): every
+//     p / scale < 256, the largest >= 4), applied by v_cvt_scalef32_pk_fp8_f32 on the way to e4m3 and undone exactly by the MFMA's
+//     E8M0 scale operand.  No bound on p is needed and none on the softmax reference: the error is relative to the block;
+//   * V^T arrives as MX e4m3 from wan_vt_quantize_mx: per channel row and per 32 consecutive keys an E8M0 scale, the 64 keys of a tile
+//     stored in the order the P registers hold them (position 32 hi + 16 kt + 8 g + j <- key 32 kt + 16 g + 8 hi + j);
+//     tile image in LDS [128 d][64 B], chunk' = chunk ^ ((row >> 2) & 3); the tile's 256 scale bytes ([lane][dt]) ride in a 4-byte DMA;
+//   * max-free softmax (reference 0: p = exp2(S), checked at the end like the bf16 max-free form; a flagged workgroup is redone by
+//     the fp8-QK^T lazy-reference kernel launched right behind): with no -m splats and half-size P registers the 32 exponentials of a
+//     block fit next to both S sets;
+//   * the softmax stream runs in blocks (attn_f8_sched.inc): segment B finishes tile t (query block 1), segment C starts tile t+1
+//     (query block 0), 10-11 micro-ops under each 64-cycle MFMA.
+// K / V^T fragments live in fixed registers a[224:255] / a[192:223] (see W8_KCLOB above).
+// ====================================================================================================
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+constexpr int kF8KTile = kKV * kD;               // 8 KiB: 64 keys x 128 B
+constexpr int kF8VTile = kD * kKV;               // 8 KiB: 128 d x 64 B
+constexpr int kF8VOff = 2 * kF8KTile, kF8SOff = kF8VOff + 2 * kF8VTile;
+constexpr int kLdsBytesF8 = kF8SOff + 2 * 256;
+
+__global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_fwd_f8_kernel(AttnArgs a) {
+    const int wg_linear = blockIdx.x;
+    {
+        int* const hdr = a.flags - 4;
+        if (wg_linear == 0 && threadIdx.x == 0) hdr[1] = 0;
+        if (hdr[0] != 0) {                                       // sticky "attempt off": hand everything to the fix-up launch
+            if (threadIdx.x == 0) a.flags[wg_linear] = 1;
+            return;
+        }
+    }
+    int qblk, bh;
+    if (a.xcd_map) {
+        const int s_ = wg_linear >> 3, g_ = s_ / a.nqb;
+        qblk = s_ - g_ * a.nqb;
+        bh = g_ * 8 + (wg_linear & 7);
+    } else {
+        bh = wg_linear / a.nqb;
+        qblk = wg_linear - bh * a.nqb;
+    }
+    const int batch = bh / a.H, head = bh - batch * a.H;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int Lk = a.Lk, nkv = (Lk + kKV - 1) / kKV;
+    const unsigned char* K8 = a.k8 + batch * a.k8_bs + head * kD;
+    const unsigned char* V8 = a.v8 + batch * a.v8_bs + (int64_t)head * kD * a.ldv8;
+    const unsigned char* VS = a.vs8 + ((int64_t)batch * a.H + head) * a.vs8_hs;
+    bf16_t* O = a.o + batch * a.o_bs + head * kD;
+
+    int qrow[2];
+    i32x8 qf8[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qrow[qb] = qblk * kQPerWG + wid * 64 + qb * 32 + l31;
+        const unsigned char* qp = a.q8 + batch * a.q8_bs + head * kD + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq8 + hi * 32;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(qp + dh * 64), up = *reinterpret_cast<const u32x4*>(qp + dh * 64 + 16);
+            qf8[qb][dh] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+        }
+    }
+    // ---- staging: per tile this wave copies K pieces 2 wid, 2 wid + 1 (8 rows x 128 B), V^T pieces 2 wid, 2 wid + 1 (16 rows x 64 B);
+    // wave 0 also the tile's 256 scale bytes
+    int k_voff[2], v_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kr = (wid * 2 + j) * 8 + (lane >> 3);
+        k_voff[j] = (int)(kr * a.ldk8 + ((lane & 7) ^ ((kr >> 1) & 7)) * 16);
+        const int vr = (wid * 2 + j) * 16 + (lane >> 2);
+        v_voff[j] = (int)(vr * a.ldv8 + ((lane & 3) ^ ((lane >> 4) & 3)) * 16);      // (vr >> 2) & 3 == (lane >> 4) & 3
+    }
+    const int64_t k_tile_bytes = (int64_t)kKV * a.ldk8;
+    auto k_rsrc = [&](int t) {
+        const int tc = min(t, nkv - 1);
+        const int64_t left = (int64_t)(Lk - tc * kKV) * a.ldk8;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(K8 + tc * k_tile_bytes), 0, (int)min(left, (int64_t)0x7fffffff), 0x00020000);
+    };
+    auto v_rsrc = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void*)(V8 + (int64_t)min(t, nkv - 1) * kKV), 0, 0x7fffffff, 0x00020000); };
+    auto s_rsrc = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void*)(VS + (int64_t)min(t, nkv - 1) * 256), 0, 256, 0x00020000); };
+    auto stage_k = [&](__amdgpu_buffer_rsrc_t r, int slot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + slot * kF8KTile + (wid * 2 + j) * 1024), 16, k_voff[j], 0, 0, 0);
+    };
+    auto stage_v = [&](__amdgpu_buffer_rsrc_t r, int slot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + kF8VOff + slot * kF8VTile + (wid * 2 + j) * 1024), 16, v_voff[j], 0, 0, 0);
+    };
+    auto stage_s = [&](__amdgpu_buffer_rsrc_t r, int slot) {
+        if (wid == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + kF8SOff + slot * 256), 4, lane * 4, 0, 0, 0);
+    };
+    const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned k8_adr[4];         // chunk 4 dh + 2 hi + x of K row pi (index 2 dh + x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k8_adr[i] = lds_base + pi * 128 + (((4 * (i >> 1) + 2 * hi + (i & 1)) ^ ((pi >> 1) & 7)) << 4);
+    unsigned v8_adr[2];         // chunk 2 hi + x of V^T row l31 (+ 32 dt rows = + 2048 dt bytes)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) v8_adr[x] = lds_base + kF8VOff + l31 * 64 + (((2 * hi + x) ^ ((l31 >> 2) & 3)) << 4);
+    const unsigned vs_adr = lds_base + kF8SOff + lane * 4;
+    unsigned sc_k, sc_q;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(sc_k), "=v"(sc_q) : "s"(a.k8_scale), "s"(a.q8_scale));
+
+    f32x16 o[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    float l_run[2] = {0.f, 0.f};
+    auto fence = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    };
+    // one MX block: 32 probabilities -> e4m3 / their sum's scale; the E8M0 byte of the scale lands in bits 0..7 of `sbyte`
+    // (P blocks are kept as eight separate 2 x 16-bit registers: __builtin_bit_cast of an ELEMENT of an ext-vector is folded to
+    // element 0 by this hipcc -- every conversion's "old" operand became register 0 of the block)
+    // sk0 / sk1: this lane's sums of its 16 probabilities of key half 0 / 1.  The two lanes of a query row exchange them (one
+    // v_permlane32_swap): lane hi ends up with the total of key half kt = hi -- the block whose scale it owes the MFMA -- and a second
+    // swap hands both lanes both scales for their conversions.
+    auto block_scales = [&](float sk0, float sk1, float& sc0, float& sc1, unsigned& sbyte) {
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(sk0), "+v"(sk1));
+        const float sc = __uint_as_float(__float_as_uint((sk0 + sk1) * 0x1p-7f) & 0x7f800000u);      // an exact power of two
+        sbyte = __float_as_uint(sc) >> 23;
+        sc0 = sc; sc1 = sc;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(sc0), "+v"(sc1));
+    };
+    auto quantise_block = [&](const float (&e)[32], float sk0, float sk1, i16x2 (&p8)[8], unsigned& sbyte) {
+        float sc0, sc1;
+        block_scales(sk0, sk1, sc0, sc1, sbyte);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float sc = r < 4 ? sc0 : sc1;
+            i16x2 h = {0, 0};
+            h = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h, e[4 * r], e[4 * r + 1], sc, false);
+            h = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h, e[4 * r + 2], e[4 * r + 3], sc, true);
+            p8[r] = h;
+        }
+    };
+#define F8_PBLOCK(P) (i32x8{__builtin_bit_cast(int, (P)[0]), __builtin_bit_cast(int, (P)[1]), __builtin_bit_cast(int, (P)[2]), __builtin_bit_cast(int, (P)[3]), \
+                            __builtin_bit_cast(int, (P)[4]), __builtin_bit_cast(int, (P)[5]), __builtin_bit_cast(int, (P)[6]), __builtin_bit_cast(int, (P)[7])})
+
+    // ---- prologue: K(0), V(0) + scales, K(1) in flight; S(0); the first block of P(0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { stage_k(k_rsrc(0), 0, j); stage_v(v_rsrc(0), 0, j); }
+    stage_s(s_rsrc(0), 0);
+    if (nkv > 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) stage_k(k_rsrc(1), 1, j);
+    }
+    fence();
+    f32x16 s0[2][2], s1[2][2];
+#define F8_MFMA0(D, A, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(D) : "v"(A), "a"(B), "v"(sc_k), "v"(sc_q))
+#define F8_MFMA_S(D, A, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(D) : "v"(A), "a"(B), "v"(sc_k), "v"(sc_q))
+#define F8K_MFMA0(D, F, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%4:%5], %1, 0, %2, %3 op_sel_hi:[0,0,0]" : "=&v"(D) : "a"(B), "v"(sc_k), "v"(sc_q), "i"(224 + 8 * (F)), "i"(231 + 8 * (F)) : W8_KCLOB)
+#define F8K_MFMA_S(D, F, B) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%4:%5], %1, %0, %2, %3 op_sel_hi:[0,0,0]" : "+v"(D) : "a"(B), "v"(sc_k), "v"(sc_q), "i"(224 + 8 * (F)), "i"(231 + 8 * (F)) : W8_KCLOB)
+// O[qb][dt] (AGPR) += V^T fragment dt (fixed a[192 + 8 dt ..]) . P block (VGPR); scale_a = byte dt of the tile's scale dword, scale_b = byte 0
+#define F8V_MFMA(ACC, DT, P, VSC, PSC) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, a[%4:%5], %1, %0, %2, %3 op_sel:[%6,0,0] op_sel_hi:[%7,0,0]" \
+        : "+a"(ACC) : "v"(P), "v"(VSC), "v"(PSC), "i"(192 + 8 * (DT)), "i"(199 + 8 * (DT)), "i"((DT) & 1), "i"((DT) >> 1) : W8_VCLOB)
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const u32x4 lo = lds_read16_at(k8_adr[2 * dh] + kt * 32 * 128), up = lds_read16_at(k8_adr[2 * dh + 1] + kt * 32 * 128);
+            const i32x8 kf0 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                if (dh == 0) F8_MFMA0(s0[qb][kt], kf0, qf8[qb][0]);
+                else F8_MFMA_S(s0[qb][kt], kf0, qf8[qb][1]);
+            }
+        }
+    __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");      // S(0) is read by VALU code below (16-pass MFMA results)
+
+    i16x2 p8a0[8] = {}, p8a1[8] = {}, p8b[8] = {};     // P blocks: query block 0 ping-pongs (produced one interval ahead), query block 1
+    unsigned psa0 = 0, psa1 = 0, psb = 0;     // their E8M0 scale bytes
+    float suma = 0.f;                         // sum of the query-block-0 block that is waiting for its interval
+    if (nkv > 1) {                            // (a single tile is the peeled tile: masked, computed there)
+        float e[32], sk[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { e[i] = __builtin_amdgcn_exp2f(s0[0][i >> 4][i & 15]); sk[i >> 4] += e[i]; }
+        suma = sk[0] + sk[1];
+        quantise_block(e, sk[0], sk[1], p8a0, psa0);
+    }
+
+    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], i16x2 (&pa_cur)[8], unsigned psa_cur, i16x2 (&pa_next)[8], unsigned& psa_next,
+                        auto kslot_c, auto vslot_c, int t) __attribute__((always_inline)) {
+        constexpr int kslot_next = decltype(kslot_c)::value, vslot = decltype(vslot_c)::value;
+        const __amdgpu_buffer_rsrc_t rk = k_rsrc(t + 2), rv = v_rsrc(t + 1), rs = s_rsrc(t + 1);
+        float e[32];
+        // stream 1 = query block 1 of this tile, stream 0 = query block 0 of the next; per stream the lane's sums of key half 0 / 1,
+        // their exchanged copies, the two block scales
+        float s1k0 = 0.f, s1k1 = 0.f, s0k0 = 0.f, s0k1 = 0.f, x1a, x1b, x0a, x0b, sc1k0, sc1k1, sc0k0, sc0k1;
+        unsigned vsc;
+        l_run[0] += suma;                      // the query-block-0 block of this tile was summed one interval ago
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define W4_LGKM(w) do { if constexpr ((w) >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"((w) < 0 ? 0 : (w))); } while (0)
+#define RDK8(f) asm volatile("ds_read_b128 a[%2:%3], %0 offset:%6\n\tds_read_b128 a[%4:%5], %1 offset:%6" \
+                             :: "v"(k8_adr[2 * ((f) >> 1)]), "v"(k8_adr[2 * ((f) >> 1) + 1]), "i"(224 + 8 * (f)), "i"(227 + 8 * (f)), "i"(228 + 8 * (f)), \
+                                "i"(231 + 8 * (f)), "i"(kslot_next * kF8KTile + ((f) & 1) * 32 * 128) : W8_KCLOB)
+#define RDV8(dt) asm volatile("ds_read_b128 a[%2:%3], %0 offset:%6\n\tds_read_b128 a[%4:%5], %1 offset:%6" \
+                              :: "v"(v8_adr[0]), "v"(v8_adr[1]), "i"(192 + 8 * (dt)), "i"(195 + 8 * (dt)), "i"(196 + 8 * (dt)), \
+                                 "i"(199 + 8 * (dt)), "i"(vslot * kF8VTile + (dt) * 32 * 64) : W8_VCLOB)
+#define RDVS() asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vsc) : "v"(vs_adr), "i"(vslot * 256))
+#define QK8F(qb, kt, dh, f, w) do { W4_LGKM(w); if ((dh) == 0) F8K_MFMA0(sn[qb][kt], f, qf8[qb][0]); else F8K_MFMA_S(sn[qb][kt], f, qf8[qb][1]); SB(); } while (0)
+#define PV8(qb, dt, w) do { W4_LGKM(w); if ((qb) == 0) { const i32x8 p_ = F8_PBLOCK(pa_cur); F8V_MFMA(o[0][dt], dt, p_, vsc, psa_cur); } \
+                            else { const i32x8 p_ = F8_PBLOCK(p8b); F8V_MFMA(o[1][dt], dt, p_, vsc, psb); } SB(); } while (0)
+#define G8F(j) do { if ((j) < 2) stage_k(rk, 1 - kslot_next, (j)); else if ((j) < 4) stage_v(rv, 1 - vslot, (j) - 2); else stage_s(rs, 1 - vslot); } while (0)
+// block 1 reads S(t) of query block 1, block 0 reads S(t+1) of query block 0; score i of a block = key-half kt = i >> 4, register i & 15
+#define E8(blk, i) do { e[i] = __builtin_amdgcn_exp2f((blk) ? sc[1][(i) >> 4][(i) & 15] : sn[0][(i) >> 4][(i) & 15]); } while (0)
+#define A8(blk, i) do { if (blk) { if ((i) < 16) s1k0 += e[i]; else s1k1 += e[i]; } else { if ((i) < 16) s0k0 += e[i]; else s0k1 += e[i]; } } while (0)
+// the six steps of block_scales() as single instructions: exchange | total | * 2^-7 | keep the exponent | its byte for the MFMA | broadcast both
+#define F8_SC(k, SK0, SK1, XA, XB, C0, C1, PS) do { \
+        if ((k) == 0) { XA = SK0; XB = SK1; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(XA), "+v"(XB)); } \
+        else if ((k) == 1) XA = XA + XB; \
+        else if ((k) == 2) XA = XA * 0x1p-7f; \
+        else if ((k) == 3) C0 = __uint_as_float(__float_as_uint(XA) & 0x7f800000u); \
+        else if ((k) == 4) PS = __float_as_uint(C0) >> 23; \
+        else { C1 = C0; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(C0), "+v"(C1)); } } while (0)
+#define SC8(blk, k) do { if (blk) F8_SC(k, s1k0, s1k1, x1a, x1b, sc1k0, sc1k1, psb); else F8_SC(k, s0k0, s0k1, x0a, x0b, sc0k0, sc0k1, psa_next); } while (0)
+#define C8(blk, w) do { if (blk) p8b[(w) >> 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8b[(w) >> 1], e[2 * (w)], e[2 * (w) + 1], (w) < 8 ? sc1k0 : sc1k1, ((w) & 1) != 0); \
+                        else pa_next[(w) >> 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(pa_next[(w) >> 1], e[2 * (w)], e[2 * (w) + 1], (w) < 8 ? sc0k0 : sc0k1, ((w) & 1) != 0); } while (0)
+#define MIDPOINT() do { l_run[1] += s1k0 + s1k1; } while (0)
+#include "attn_f8_sched.inc"
+#undef RDK8
+#undef RDV8
+#undef RDVS
+#undef QK8F
+#undef PV8
+#undef G8F
+#undef E8
+#undef A8
+#undef SC8
+#undef F8_SC
+#undef C8
+#undef MIDPOINT
+#undef W4_LGKM
+        suma = s0k0 + s0k1;
+    };
+
+    const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
+    int it = 0;
+    bool last_in_s1 = false;
+    for (; it + 2 <= nfull; it += 2) {          // `it` is even: K(it+1) sits in slot 1, V(it) in slot 0; P block of query block 0 in p8a0
+        interval(s0, s1, p8a0, psa0, p8a1, psa1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, it);
+        fence();
+        interval(s1, s0, p8a1, psa1, p8a0, psa0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, it + 1);
+        fence();
+    }
+    if (it < nfull) {
+        interval(s0, s1, p8a0, psa0, p8a1, psa1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, it);
+        fence();
+        ++it;
+        last_in_s1 = true;
+    }
+    // ---- peeled last tile (it == nkv - 1): keys >= Lk masked (p = 0); both P blocks are (re)computed here
+    {
+        const int kv0 = it * kKV;
+        const unsigned vb = (it & 1) * kF8VTile;
+        if (last_in_s1) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) s0[qb][kt] = s1[qb][kt];
+        }
+        i16x2 plh[2][8];
+        i32x8 pl[2];
+        unsigned psl[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float e[32], sk[2] = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int key = kv0 + 32 * (i >> 4) + 16 * ((i >> 3) & 1) + 8 * hi + (i & 7);
+                e[i] = key < Lk ? __builtin_amdgcn_exp2f(s0[qb][i >> 4][i & 15]) : 0.f;
+                sk[i >> 4] += e[i];
+            }
+            quantise_block(e, sk[0], sk[1], plh[qb], psl[qb]);
+            pl[qb] = F8_PBLOCK(plh[qb]);
+            l_run[qb] += sk[0] + sk[1];
+        }
+        const unsigned vsc = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)(vs_adr + (it & 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7" ::: "memory");             // VALU-written P blocks -> MFMA operands
+#define F8_PEEL_PV(DT) do { \
+            const u32x4 lo = lds_read16_at(v8_adr[0] + vb + (DT) * 32 * 64), up = lds_read16_at(v8_adr[1] + vb + (DT) * 32 * 64); \
+            const i32x8 vf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]}; \
+            asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,0,0] op_sel_hi:[%6,0,0]" \
+                         : "+a"(o[0][DT]) : "v"(vf), "v"(pl[0]), "v"(vsc), "v"(psl[0]), "i"((DT) & 1), "i"((DT) >> 1)); \
+            asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,0,0] op_sel_hi:[%6,0,0]" \
+                         : "+a"(o[1][DT]) : "v"(vf), "v"(pl[1]), "v"(vsc), "v"(psl[1]), "i"((DT) & 1), "i"((DT) >> 1)); } while (0)
+        F8_PEEL_PV(0); F8_PEEL_PV(1); F8_PEEL_PV(2); F8_PEEL_PV(3);
+#undef F8_PEEL_PV
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' D -> the accumulator reads below
+    }
+#undef SB
+#undef F8_MFMA0
+#undef F8_MFMA_S
+#undef F8K_MFMA0
+#undef F8K_MFMA_S
+#undef F8V_MFMA
+#undef F8_PBLOCK
+
+    bool ok = true;
+    float inv[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        ok = ok && ((l_tot >= 0x1p-90f && l_tot <= 0x1p100f) || qrow[qb] >= a.Lq);     // NaN fails both comparisons
+        inv[qb] = 1.0f / l_tot;
+    }
+    const int bad = __syncthreads_or(!ok);
+    if (tid == 0) a.flags[wg_linear] = bad;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (qrow[qb] >= a.Lq) continue;
+        bf16_t* op = O + (int64_t)qrow[qb] * a.ldo + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w = {pack_bf16x2(o[qb][dt][4 * g + 0] * inv[qb], o[qb][dt][4 * g + 1] * inv[qb]),
+                           pack_bf16x2(o[qb][dt][4 * g + 2] * inv[qb], o[qb][dt][4 * g + 3] * inv[qb])};
+                *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
+            }
+    }
+}
+
+// V^T bf16 [B][C][ldvt] -> MX e4m3 (see attn_fwd_f8_kernel): one wave per (channel row, 8 tiles); lane = (tile, 16-byte chunk m' of the
+// tile's 64 keys): hi = m' & 1, group m = m' >> 1 = 2 kt + g; the 4 lanes of a (tile, key half kt = m' >> 2) hold one MX block of 32
+// consecutive keys, whose scale byte goes where lane hi = kt of the attention kernel reads it
+__global__ __launch_bounds__(64) void vt_quantize_mx_kernel(const bf16_t* __restrict__ vt, int64_t ldvt, int64_t vt_bs, int C, int H, int ntiles,
+                                                            unsigned char* __restrict__ v8, int64_t ldv8, int64_t v8_bs,
+                                                            unsigned char* __restrict__ vs8, int64_t vs8_hs) {
+    const int lane = threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int tile = blockIdx.x * 8 + (lane >> 3), mp = lane & 7, hi = mp & 1, m = mp >> 1;
+    if (tile >= ntiles) return;                     // whole (tile, *) lane groups leave together: the shuffles below stay inside a group of 8
+    const u32x4 v = *reinterpret_cast<const u32x4*>(vt + b * vt_bs + (int64_t)c * ldvt + tile * 64 + mp * 8);
+    float f[8], amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf16lo_to_f32(v[j]); f[2 * j + 1] = bf16hi_to_f32(v[j]); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    // scale = 2^(floor(log2 amax) - 7): amax / scale in [128, 256); an all-zero (or denormal) block takes the smallest normal scale
+    const unsigned ebyte = max((int)(__float_as_uint(amax) >> 23) - 7, 1);
+    const float scale = __uint_as_float(ebyte << 23);
+    i16x2 h0 = {0, 0}, h1 = {0, 0};
+    h0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h0, f[0], f[1], scale, false);
+    h0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h0, f[2], f[3], scale, true);
+    h1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h1, f[4], f[5], scale, false);
+    h1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h1, f[6], f[7], scale, true);
+    const u32x2 out = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+    *reinterpret_cast<u32x2*>(v8 + b * v8_bs + (int64_t)c * ldv8 + tile * 64 + 32 * hi + 8 * m) = out;
+    if ((mp & 3) == 0) {
+        const int head = c / kD, d = c - head * kD, kt = mp >> 2;
+        vs8[((int64_t)b * H + head) * vs8_hs + (int64_t)tile * 256 + (32 * kt + (d & 31)) * 4 + (d >> 5)] = (unsigned char)ebyte;
     }
 }
 
@@ -1210,7 +1585,7 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
     // heads pinned to XCDs: only worth it (and only balanced) when the (batch, head) pairs split evenly over the 8 XCDs
     p.xcd = wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && (num_heads * batch) % 8 == 0;
     if (qk8) p.ref2 = false;
-    p.variant = qk8 ? WAN_ATTN_VARIANT_W4_LAZY_QK8
+    p.variant = qk8 ? WAN_ATTN_VARIANT_W4_LAZY_QK8      // (the fp8 P.V form reports WAN_ATTN_VARIANT_W4_F8 from the launcher)
                     : (!p.w4 ? WAN_ATTN_VARIANT_W8_RUNNING_MAX : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY));
     if (p.xcd) p.variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (p.tail.tq > 0) p.variant |= WAN_ATTN_VARIANT_SPLIT_TAIL;
@@ -1229,7 +1604,12 @@ extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int 
 }
 
 namespace {
-struct Qk8Operands { int q_exp, k_exp; };      // q8 = e4m3(q * softmax_scale * log2(e) * 2^q_exp), k8 = e4m3(k * 2^k_exp)
+struct Qk8Operands {            // q8 = e4m3(q * softmax_scale * log2(e) * 2^q_exp), k8 = e4m3(k * 2^k_exp)
+    int q_exp, k_exp;
+    // fp8 P.V as well (wan_attention_fwd_f8): the MX e4m3 V^T of wan_vt_quantize_mx; v8 = NULL: bf16 P.V
+    const void* v8; int64_t ldv8, v8_bs; const void* vs8;
+};
+int64_t vt_mx_scale_bytes_per_head(int Lk) { return (int64_t)((Lk + kKV - 1) / kKV) * 256; }
 }
 
 // q / k are bf16 tensors, or -- with `qk8` -- e4m3 tensors whose strides count BYTES
@@ -1260,6 +1640,14 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     WAN_REQUIRE(ldvt >= lk_pad && ldvt % 8 == 0, WAN_ERR_INVALID,
                 "wan_attention_fwd: ldvt=%lld must be >= roundup(Lk,64)=%lld and a multiple of 8",
                 (long long)ldvt, (long long)lk_pad);
+    if (qk8 && qk8->v8) {
+        WAN_REQUIRE(qk8->vs8 != nullptr && qk8->ldv8 >= lk_pad && qk8->ldv8 % 16 == 0 && qk8->v8_bs % 16 == 0 && ((uintptr_t)qk8->v8 & 15) == 0 &&
+                        ((uintptr_t)qk8->vs8 & 3) == 0, WAN_ERR_INVALID,
+                    "wan_attention_fwd_f8: v8 rows must be 16-byte aligned with ldv8=%lld >= roundup(Lk,64)=%lld, scales 4-byte aligned",
+                    (long long)qk8->ldv8, (long long)lk_pad);
+        WAN_REQUIRE(workspace != nullptr && workspace_bytes >= flag_bytes(batch, Lq, num_heads), WAN_ERR_INVALID,
+                    "wan_attention_fwd_f8: needs the scratch of wan_attention_workspace_bytes (its softmax is the checked max-free form)");
+    }
     if (Lq == 0) return WAN_OK;
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t ast = wan_once_per_device(attr_done, +[]() -> wan_status_t {
@@ -1273,7 +1661,9 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 2>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 2>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 2>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, false, true>),
-                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1, false, true>)};
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1, false, true>),
+                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, true, true>),
+                             reinterpret_cast<const void*>(&attn_fwd_f8_kernel)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
             if (e != hipSuccess) {
@@ -1293,6 +1683,12 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
         a.k8 = (const unsigned char*)k; a.ldk8 = ldk; a.k8_bs = k_bstride;
         a.q8_scale = 0x01010101u * (unsigned)(127 - qk8->q_exp);
         a.k8_scale = 0x01010101u * (unsigned)(127 - qk8->k_exp);
+    }
+    a.v8 = nullptr; a.vs8 = nullptr; a.ldv8 = a.v8_bs = a.vs8_hs = 0;
+    const bool pv8 = qk8 != nullptr && qk8->v8 != nullptr;
+    if (pv8) {
+        a.v8 = (const unsigned char*)qk8->v8; a.ldv8 = qk8->ldv8; a.v8_bs = qk8->v8_bs;
+        a.vs8 = (const unsigned char*)qk8->vs8; a.vs8_hs = vt_mx_scale_bytes_per_head(Lk);
     }
     a.vt = (const bf16_t*)vt; a.ldvt = ldvt; a.vt_bs = vt_bstride;
     a.o = (bf16_t*)out; a.ldo = ldo; a.o_bs = o_bstride;
@@ -1339,7 +1735,12 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     const bool w4 = plan.w4, ref2 = plan.ref2;
     const dim3 block4(kW4Threads);
     int variant;
-    if (qk8) {                       // fp8 QK^T (opt-in, lossy): the lazy-reference kernel with its S product on the fp8 pipe
+    if (pv8) {                       // fp8 QK^T and fp8 P.V (opt-in, lossy): checked max-free form, flagged workgroups redone by the fp8-QK^T lazy kernel
+        variant = WAN_ATTN_VARIANT_W4_F8;
+        hipLaunchKernelGGL(attn_fwd_f8_kernel, grid, block4, kLdsBytesF8, st, a);
+        WAN_CHECK_LAUNCH("wan_attention_fwd_f8");
+        hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, true, true>), grid, block4, kLdsBytesW4, st, a);
+    } else if (qk8) {                // fp8 QK^T (opt-in, lossy): the lazy-reference kernel with its S product on the fp8 pipe
         variant = WAN_ATTN_VARIANT_W4_LAZY_QK8;
         hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, false, true>), grid, block4, kLdsBytesW4, st, a);
     } else if (w4 && !fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
@@ -1408,9 +1809,42 @@ extern "C" wan_status_t wan_attention_fwd_qk8(const void* q8, int64_t ldq8, int6
                                               void* out, int64_t ldo, int64_t o_bstride,
                                               int batch, int Lq, int Lk, int num_heads, int head_dim,
                                               void* workspace, int64_t workspace_bytes, void* stream) {
-    const Qk8Operands ops = {q_exp, k_exp};
+    const Qk8Operands ops = {q_exp, k_exp, nullptr, 0, 0, nullptr};
     return attention_fwd_impl(q8, ldq8, q8_bstride, k8, ldk8, k8_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, batch, Lq, Lk,
                               num_heads, head_dim, 1.0f, WAN_ATTN_Q_PRESCALED, workspace, workspace_bytes, stream, &ops);
+}
+
+extern "C" wan_status_t wan_attention_fwd_f8(const void* q8, int64_t ldq8, int64_t q8_bstride, int q_exp,
+                                             const void* k8, int64_t ldk8, int64_t k8_bstride, int k_exp,
+                                             const void* v8, int64_t ldv8, int64_t v8_bstride, const void* v8_scales,
+                                             const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                             void* out, int64_t ldo, int64_t o_bstride,
+                                             int batch, int Lq, int Lk, int num_heads, int head_dim,
+                                             void* workspace, int64_t workspace_bytes, void* stream) {
+    WAN_REQUIRE(v8 && v8_scales, WAN_ERR_INVALID, "wan_attention_fwd_f8: null tensor");
+    const Qk8Operands ops = {q_exp, k_exp, v8, ldv8, v8_bstride, v8_scales};
+    return attention_fwd_impl(q8, ldq8, q8_bstride, k8, ldk8, k8_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, batch, Lq, Lk,
+                              num_heads, head_dim, 1.0f, WAN_ATTN_Q_PRESCALED, workspace, workspace_bytes, stream, &ops);
+}
+
+extern "C" int64_t wan_vt_mx_scale_bytes(int batch, int num_heads, int Lk) {
+    return batch > 0 && num_heads > 0 && Lk > 0 ? (int64_t)batch * num_heads * vt_mx_scale_bytes_per_head(Lk) : 0;
+}
+
+extern "C" wan_status_t wan_vt_quantize_mx(const void* vt_bf16, int64_t ldvt, int64_t vt_bstride, int batch, int num_heads, int Lk,
+                                           void* v8, int64_t ldv8, int64_t v8_bstride, void* v8_scales, void* stream) {
+    WAN_REQUIRE(vt_bf16 && v8 && v8_scales, WAN_ERR_INVALID, "wan_vt_quantize_mx: null tensor");
+    WAN_REQUIRE(batch > 0 && num_heads > 0 && Lk > 0, WAN_ERR_INVALID, "wan_vt_quantize_mx: batch=%d heads=%d Lk=%d", batch, num_heads, Lk);
+    const int64_t lk_pad = ((int64_t)Lk + kKV - 1) / kKV * kKV;
+    WAN_REQUIRE(ldvt >= lk_pad && ldvt % 8 == 0 && ldv8 >= lk_pad && ldv8 % 16 == 0 && ((uintptr_t)vt_bf16 & 15) == 0 && ((uintptr_t)v8 & 15) == 0,
+                WAN_ERR_INVALID, "wan_vt_quantize_mx: ldvt=%lld / ldv8=%lld must be >= roundup(Lk,64)=%lld (multiples of 8 / 16), 16-byte aligned",
+                (long long)ldvt, (long long)ldv8, (long long)lk_pad);
+    const int ntiles = (int)(lk_pad / kKV), C = num_heads * kD;
+    hipLaunchKernelGGL(vt_quantize_mx_kernel, dim3((unsigned)((ntiles + 7) / 8), (unsigned)C, (unsigned)batch), dim3(64), 0, (hipStream_t)stream,
+                       (const bf16_t*)vt_bf16, ldvt, vt_bstride, C, num_heads, ntiles, (unsigned char*)v8, ldv8, v8_bstride,
+                       (unsigned char*)v8_scales, vt_mx_scale_bytes_per_head(Lk));
+    WAN_CHECK_LAUNCH("wan_vt_quantize_mx");
+    return WAN_OK;
 }
 
 extern "C" wan_status_t wan_transpose_bf16(const void* in, int64_t ld, void* out_t, int64_t ldt,
