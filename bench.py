@@ -290,8 +290,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of the last block")
     ap.add_argument("--fp8-layers", default="qkv,ffn",
-                    help="with --fp8: comma-separated subset of qkv,ffn,o,cross (all four = every per-token Linear of a block) and attn "
-                         "(self-attention QK^T on the fp8 matrix pipe, P.V stays bf16)")
+                    help="with --fp8: comma-separated subset of qkv,ffn,o,cross (all four = every per-token Linear of a block), attn "
+                         "(self-attention QK^T on the fp8 matrix pipe, P.V stays bf16) and attn_pv (with attn: P.V in fp8 as well)")
     ap.add_argument("--fp8-no-smooth-k", action="store_true",
                     help="with --fp8-layers ...,attn: quantise k as it is instead of k minus its token mean (saves one 0.5 ms pass per layer)")
     ap.add_argument("--fp8", action="store_true",
@@ -498,6 +498,11 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
+        if (vcode & 15) == 5:       # both products at the fp8 rate (2 x bf16)
+            peak = 2 * PEAK_BF16_TFLOPS
+            roof.update(peak=round(peak, 1), frac=round(ach / peak, 4), traffic=None,
+                        traffic_detail={"note": "the committed PMC passes are of the bf16 kernel; none was taken for this lossy variant"},
+                        dtype_peak="dense fp8 MFMA (2 x bf16): QK^T and P.V both on the fp8 matrix pipe")
         if (vcode & 15) == 4:       # fp8 QK^T: half of the flops run at the fp8 rate (2 x bf16), half (P.V) at the bf16 rate
             peak = 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS)
             roof.update(peak=round(peak, 1), frac=round(ach / peak, 4), traffic=None,
@@ -514,7 +519,7 @@ def main():
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "strong" if sp or world == 1 else "weak", "vs_baseline": None,
-        "dtype": (f"fp8-e4m3 ({args.fp8_layers}; 'attn' = the QK^T product of self-attention) + bf16 (softmax, P.V, the rest); "
+        "dtype": (f"fp8-e4m3 ({args.fp8_layers}; 'attn' = the QK^T product of self-attention, 'attn_pv' = its P.V product) + bf16 (softmax, the rest); "
                   "LOSSY option, not the headline") if args.fp8 else "bf16",
         "data": "synthetic (random-init weights, N(0,1) latents + text embeddings)",
         "config": {"workload": wl["desc"], "layout": "VideoCoF (src|ground|tgt)" if cof else "T2V",

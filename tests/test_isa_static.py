@@ -85,3 +85,21 @@ def test_attention_qk8_main_loop_is_clean(attn_asm, mangled, what):
     assert sum(c for k, c in h.items() if k.startswith("v_")) <= 420, what
     loop = [l for l in body if "v_mfma_scale" in l and "a[0x" in l.replace("a[22", "a[0x").replace("a[23", "a[0x").replace("a[24", "a[0x")]
     assert loop, "the loop's fp8 MFMAs read their K fragments from the fixed AGPR range"
+
+
+def test_attention_f8_main_loop_is_clean(attn_asm):
+    """fp8 QK^T + fp8 P.V: 16 scaled fp8 MFMAs per tile, 64 exponentials, 32 P conversions (two values each), 16 fragment reads (K and V^T
+    in the fixed registers a[192:255]), no copies between the register files, no scratch."""
+    mangled = "attn_fwd_f8_kernel"
+    body = _kernel(attn_asm, mangled)
+    meta = "\n".join(attn_asm)
+    priv = re.search(re.escape(mangled) + r"\w*\.private_seg_size, (\d+)", meta)
+    assert priv and int(priv.group(1)) == 0, priv and priv.group(1)
+    h = _main_loop_histogram(body)                      # two KV-tile intervals
+    assert h.get("v_mfma_scale_f32_32x32x64_f8f6f4") == 32 and h.get("v_mfma_f32_32x32x16_bf16", 0) == 0, h
+    assert h.get("v_exp_f32_e32") == 128 and h.get("v_cvt_scalef32_pk_fp8_f32") == 64 and h.get("ds_read_b128") == 32
+    assert h.get("v_permlane32_swap_b32") == 8 and h.get("buffer_load_dwordx4") == 8 and h.get("buffer_load_dword") == 2
+    for bad in ("scratch_load_dword", "scratch_load_dwordx4", "scratch_store_dword", "v_accvgpr_read_b32", "v_accvgpr_write_b32",
+                "v_accvgpr_mov_b32", "v_readlane_b32", "v_writelane_b32"):
+        assert h.get(bad, 0) == 0, (bad, h.get(bad))
+    assert sum(c for k, c in h.items() if k.startswith("v_")) <= 420

@@ -20,7 +20,9 @@ LOG2E = 1.4426950408889634
 ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax reference)",
                       2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free attempt) + attn_fwd_w4_kernel<.,false,1,true> (lazy-reference fix-up of flagged workgroups)",
                       3: "attn_fwd_v2_kernel (8-wave, running max)",
-                      4: "attn_fwd_w4_kernel<0,.,1,false,true> (4-wave, lazy softmax reference, QK^T on the fp8 matrix pipe)"}
+                      4: "attn_fwd_w4_kernel<0,.,1,false,true> (4-wave, lazy softmax reference, QK^T on the fp8 matrix pipe)",
+                      5: "attn_fwd_f8_kernel (4-wave, QK^T and P.V on the fp8 matrix pipe, checked max-free softmax) + "
+                         "attn_fwd_w4_kernel<0,false,1,true,true> (fp8-QK^T lazy-reference fix-up of flagged workgroups)"}
 ATTN_VARIANT_XCD_PINNED, ATTN_VARIANT_SPLIT_TAIL = 16, 32
 GEMM_VARIANT_KERNELS = {0: "gemm_bf16_kernel", 1: "gemm256_kernel", 2: "gemm_w4_kernel"}      # wan_gemm_plan (WAN_GEMM_VARIANT_*)
 
@@ -115,6 +117,11 @@ SIGNATURES = {
     "wan_rmsnorm_rope_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                      c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_float, c_void_p, c_void_p,
                                      c_void_p]),
+    "wan_attention_fwd_f8": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int,
+                                     c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_vt_mx_scale_bytes": (c_int64, [c_int, c_int, c_int]),
+    "wan_vt_quantize_mx": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "wan_col_mean_workspace_bytes": (c_int64, [c_int, c_int]),
     "wan_col_mean_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wan_qk_quantize_fp8": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p,

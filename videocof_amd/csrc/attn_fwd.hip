@@ -528,7 +528,8 @@ constexpr float kW4Trigger = 0x1p40f;
 //      instead of 32 x 8-pass), from e4m3 copies of q and k that the RMSNorm+RoPE kernel writes (wan_rmsnorm_rope_fp8); softmax,
 //      P and the P.V product are the bf16 / fp32 ones of the REF = 1 form.  LOSSY (3 mantissa bits on q and k), opt-in.
 //      K tile image: [64 keys][128 B], chunk' = chunk ^ ((row >> 1) & 7) (the V^T image's swizzle), 2 DMA pieces per wave; a lane's
-//      A fragment (kt, dh) = 32 bytes d = 64 dh + 32 hi .. + 31 of key pi(lane & 31) + 32 kt, read as two ds_read_b128.
+//      A fragment (kt, dh) = the 32 bytes d = 64 dh + 32 hi .. + 31 of key pi(lane & 31) + 32 kt, read as two ds_read_b128 (which k of
+//      the MFMA a byte lands on does not matter here: q and k use the same order and the operand scales are uniform).
 template <int VARIANT, bool SPLIT, int REF, bool FIX = false, bool QK8 = false>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {

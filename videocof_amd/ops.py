@@ -453,6 +453,67 @@ def rmsnorm_rope_fp8(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tens
 
 
 @_on_tensor_device
+def vt_quantize_mx(vt: torch.Tensor, num_heads: int, k_len: int, v8: Optional[torch.Tensor] = None,
+                   scales: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """V^T bf16 [B, H*128, ldvt] -> (MX e4m3 [B, H*128, ldvt] with the keys of every 64-tile in the attention kernel's register order,
+    uint8 E8M0 scales, one per channel row and 32 consecutive keys): the V operand of ``attention_fwd_f8`` (include/wan_hip.h a9'')."""
+    _need(vt, torch.bfloat16, "vt_quantize_mx.vt")
+    if vt.dim() != 3:
+        raise ValueError("vt_quantize_mx.vt must be [B, H*128, ldvt]")
+    B, C, ld = vt.shape
+    lib = _lib.load()
+    nsc = int(lib.wan_vt_mx_scale_bytes(B, num_heads, int(k_len)))
+    if v8 is None:
+        v8 = torch.empty(B, C, ld, device=vt.device, dtype=FP8)
+    if scales is None:
+        scales = torch.empty(nsc, device=vt.device, dtype=torch.uint8)
+    _need(v8, FP8, "vt_quantize_mx.v8")
+    _need(scales, torch.uint8, "vt_quantize_mx.scales")
+    if v8.shape != vt.shape or scales.numel() < nsc or not scales.is_contiguous():
+        raise ValueError("vt_quantize_mx: v8 must have vt's shape and scales wan_vt_mx_scale_bytes() contiguous bytes")
+    _lib.check(lib.wan_vt_quantize_mx(_p(vt), vt.stride(1), vt.stride(0), B, int(num_heads), int(k_len), _p(v8), v8.stride(1), v8.stride(0),
+                                      _p(scales), _stream()), "wan_vt_quantize_mx")
+    return v8, scales
+
+
+@_on_tensor_device
+def attention_fwd_f8(q8: torch.Tensor, k8: torch.Tensor, v8: torch.Tensor, v8_scales: torch.Tensor, vt: torch.Tensor, num_heads: int,
+                     q_exp: int, k_exp: int, k_len: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                     workspace: Optional[AttentionWorkspace] = None) -> torch.Tensor:
+    """Self-attention with BOTH products on the fp8 matrix pipe (LOSSY, opt-in; include/wan_hip.h a9'').  q8 / k8 as
+    ``attention_fwd_qk8``; v8 / v8_scales from ``vt_quantize_mx(vt, ...)``; the bf16 ``vt`` serves the workgroups whose max-free
+    softmax check fails (and the split-KV tail round)."""
+    for nm, t, dt in (("q8", q8, FP8), ("k8", k8, FP8), ("v8", v8, FP8), ("vt", vt, torch.bfloat16)):
+        _need(t, dt, "attention_f8." + nm)
+        if t.dim() != 3:
+            raise ValueError(f"attention_f8.{nm} must be 3-D [B, rows, cols]")
+    _need(v8_scales, torch.uint8, "attention_f8.v8_scales")
+    B, Lq, C = q8.shape
+    Lk = k8.shape[1] if k_len is None else int(k_len)
+    if Lk > k8.shape[1] or Lk <= 0:
+        raise ValueError(f"attention_f8: k_len={Lk} outside (0, {k8.shape[1]}]")
+    head_dim = C // num_heads
+    if out is None:
+        out = torch.empty(B, Lq, C, device=q8.device, dtype=torch.bfloat16)
+    _need(out, torch.bfloat16, "attention_f8.out")
+    if vt.shape[1] != C or v8.shape != vt.shape or k8.shape[2] != C or k8.shape[0] != B or vt.shape[0] != B:
+        raise ValueError("attention_f8: q8/k8/v8/vt shapes disagree")
+    lib = _lib.load()
+    ws_bytes = max(int(lib.wan_attention_workspace_bytes(B, Lq, Lk, num_heads, head_dim)), 16)
+    if workspace is None:
+        key = (q8.device, _stream())
+        workspace = _ATTN_WS.get(key)
+        if workspace is None:
+            workspace = _ATTN_WS[key] = AttentionWorkspace()
+    ws = workspace.get(q8.device, ws_bytes)
+    _lib.check(lib.wan_attention_fwd_f8(_p(q8), q8.stride(1), q8.stride(0), int(q_exp), _p(k8), k8.stride(1), k8.stride(0), int(k_exp),
+                                        _p(v8), v8.stride(1), v8.stride(0), _p(v8_scales), _p(vt), vt.stride(1), vt.stride(0),
+                                        _p(out), out.stride(1), out.stride(0), B, Lq, Lk, num_heads, head_dim, _p(ws), ws_bytes, _stream()),
+               "wan_attention_fwd_f8")
+    return out
+
+
+@_on_tensor_device
 def col_mean(x: torch.Tensor, rows_per_batch: int, valid_rows: int, batch: int, out: Optional[torch.Tensor] = None,
              workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 [batch, dim]: mean over the first ``valid_rows`` rows of every sample of bf16 x [batch * rows_per_batch, dim] (row

@@ -346,12 +346,16 @@ class WanTransformer3DModel(nn.Module):
         ``attention_type = "SAGE_ATTENTION"``: 8-bit QK^T, 16-bit P.V); single-device path only.  ``attn_smooth_k`` (default on, as
         ``sageattn``'s ``smooth_k``): the e4m3 copy of k is taken of k minus its per-sample mean over the tokens, which the softmax
         cannot see and which keeps a channel with a large common offset from eating the 3 mantissa bits (one extra 0.5 ms pass
-        per layer at the 14B shape); off: the RMSNorm+RoPE kernel writes the e4m3 operands directly.
+        per layer at the 14B shape); off: the RMSNorm+RoPE kernel writes the e4m3 operands directly.  "attn_pv" (with "attn"): the
+        P.V product as well -- V^T is re-quantised per layer into MX e4m3 blocks of 32 keys (``wan_vt_quantize_mx``, 0.23 ms), P inside
+        the kernel; SageAttention-2's operating point (``wan_attention_fwd_f8``, include/wan_hip.h a9'').
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
-        if not set(layers) <= {"qkv", "ffn", "o", "cross", "attn"} or not layers:
-            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn', 'o', 'cross', 'attn'), got {layers}")
+        if not set(layers) <= {"qkv", "ffn", "o", "cross", "attn", "attn_pv"} or not layers:
+            raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn', 'o', 'cross', 'attn', 'attn_pv'), got {layers}")
+        if "attn_pv" in layers and "attn" not in layers:
+            raise ValueError("enable_fp8_linear: 'attn_pv' (fp8 P.V) extends 'attn' (fp8 QK^T): name both")
         if "attn" in layers and self.d != 128:
             raise NotImplementedError("the fp8 QK^T attention kernel is built for head_dim 128")
         if self.dim % 128 or self.ffn_dim % 128:
@@ -369,6 +373,8 @@ class WanTransformer3DModel(nn.Module):
                 blk.f8["cq"] = ops.quantize_weight_fp8(blk.w_cq)
             if "attn" in layers:
                 blk.f8["attn"] = True
+            if "attn_pv" in layers:
+                blk.f8["attn_pv"] = True
         self._fp8 = layers
         self._bufs, self._bufs_last = {}, None
         self._graph_epoch += 1              # new e4m3 tensors: a graph captured before must not replay the old ones
@@ -569,6 +575,9 @@ class WanTransformer3DModel(nn.Module):
                 b.kmean = torch.empty(B, C, device=dev, dtype=torch.float32)
                 from ._lib import load
                 b.kmean_ws = torch.empty(int(load().wan_col_mean_workspace_bytes(B, C)) // 4, device=dev, dtype=torch.float32)
+                if "attn_pv" in self._fp8:
+                    b.v8 = torch.empty_like(b.vt, dtype=ops.FP8)
+                    b.v8s = torch.empty(int(load().wan_vt_mx_scale_bytes(B, self.num_heads, L)), device=dev, dtype=torch.uint8)
         b.pinned = False
         self._bufs[key] = b
         self._bufs_last = key
@@ -631,7 +640,11 @@ class WanTransformer3DModel(nn.Module):
                 ops.gemm(h[b * Ll:(b + 1) * Ll][:L], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vt[b])
         if not usp:
             ev = self._event_pair()
-            if a8:
+            if a8 and "attn_pv" in f8:
+                ops.vt_quantize_mx(vt, H, L, v8=bufs.v8, scales=bufs.v8s)
+                ops.attention_fwd_f8(bufs.q8.view(B, Ll, C), bufs.k8.view(B, Ll, C), bufs.v8, bufs.v8s, vt, H, qe, ke, k_len=L,
+                                     out=att.view(B, Ll, C), workspace=self._ws_self)
+            elif a8:
                 ops.attention_fwd_qk8(bufs.q8.view(B, Ll, C), bufs.k8.view(B, Ll, C), vt, H, qe, ke, k_len=L, out=att.view(B, Ll, C),
                                       workspace=self._ws_self)
             else:
