@@ -106,16 +106,16 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
         assert seen(sub), (sub, paths[-1])
     vc = lib.wan_attention_plan(1, L, 512, H, 128, _lib.ATTN_Q_PRESCALED, lib.wan_attention_workspace_bytes(1, L, 512, H, 128))
     assert vc & 15 == 1 and seen("attn_fwd_w4_kernel<1, false, 1, false, false>")        # cross-attention: one lazy-reference launch
-    # the lossy mode's profile (bench.py --fp8 --fp8-layers qkv,ffn,o,cross,attn): the fp8 QK^T form of the 4-wave kernel, its split tail,
-    # the fp8 instantiation of the 256^2 GEMM and the K-smoothing kernels
+    # the lossy mode's profile (bench.py --fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv): the all-fp8 attention kernel and its fix-up launch
+    # (the fp8-QK^T lazy form), the split tail, the V^T MX quantiser, the fp8 instantiation of the 256^2 GEMM and the K-smoothing kernels
     v8 = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED | 2, ws)
     assert v8 & 15 == 4 and v8 & _lib.ATTN_VARIANT_SPLIT_TAIL
     p8 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench14b_fp8_all_attn_kernel_stats.csv")))
     assert p8
     with open(p8[-1]) as f:
         names8 = [row["Name"] for row in csv.DictReader(f)]
-    for sub in ("attn_fwd_w4_kernel<0, false, 1, false, true>", "attn_fwd_w4_kernel<0, true, 1, false, true>", "gemm256_kernel<3, 2, true>",
-                "col_partial_sums_kernel", "qk_quantize_fp8_kernel"):
+    for sub in ("attn_fwd_f8_kernel", "attn_fwd_w4_kernel<0, false, 1, true, true>", "attn_fwd_w4_kernel<0, true, 1, false, true>",
+                "vt_quantize_mx_kernel", "gemm256_kernel<3, 2, true>", "col_partial_sums_kernel", "qk_quantize_fp8_kernel"):
         assert any(sub in n for n in names8), (sub, p8[-1])
     # without scratch, or with plain q: one lazy launch (the packed-shift form for plain q)
     assert lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED, 0) & 15 == 1
