@@ -110,7 +110,7 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     # (the fp8-QK^T lazy form), the split tail, the V^T MX quantiser, the fp8 instantiation of the 256^2 GEMM and the K-smoothing kernels
     v8 = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED | 2, ws)
     assert v8 & 15 == 4 and v8 & _lib.ATTN_VARIANT_SPLIT_TAIL
-    p8 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench14b_fp8_all_attn_kernel_stats.csv")))
+    p8 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench14b_fp8_everything_kernel_stats.csv")))
     assert p8
     with open(p8[-1]) as f:
         names8 = [row["Name"] for row in csv.DictReader(f)]
