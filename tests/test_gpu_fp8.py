@@ -385,3 +385,26 @@ def test_attention_f8_error_statement(Lq, Lk, H, qstd):
         assert e16 < 6e-2 and redone == 0
     else:
         assert redone > 0
+
+
+def test_fp8_attention_kernels_batch_strides():
+    """B = 2 (the CFG batch): the e4m3 q / k, the MX V^T and its scales are indexed per sample -- a batched call equals two single calls bit
+    for bit, for the fp8-QK^T kernel and for the all-fp8 one."""
+    g = torch.Generator(device=DEV).manual_seed(12)
+    B, L, H, qe, ke = 2, 700, 2, 5, 2
+    C = H * 128
+    q = (torch.randn(B, L, C, device=DEV, generator=g) * ops.q_prescale(128)).bfloat16()
+    k = torch.randn(B, L, C, device=DEV, generator=g).bfloat16()
+    q8 = (q.float() * 2.0 ** qe).clamp(-448, 448).to(ops.FP8)
+    k8 = (k.float() * 2.0 ** ke).clamp(-448, 448).to(ops.FP8)
+    vt = torch.stack([ops.transpose_pad((torch.randn(L, C, device=DEV, generator=g) * (b + 1)).bfloat16()) for b in range(B)])
+    v8, vs = ops.vt_quantize_mx(vt, H, L)
+    both_qk8 = ops.attention_fwd_qk8(q8, k8, vt, H, qe, ke, k_len=L)
+    both_f8 = ops.attention_fwd_f8(q8, k8, v8, vs, vt, H, qe, ke, k_len=L)
+    for b in range(B):
+        v8b, vsb = ops.vt_quantize_mx(vt[b:b + 1], H, L)
+        assert torch.equal(v8b[0], v8[b])
+        assert torch.equal(ops.attention_fwd_qk8(q8[b:b + 1], k8[b:b + 1], vt[b:b + 1], H, qe, ke, k_len=L)[0], both_qk8[b])
+        assert torch.equal(ops.attention_fwd_f8(q8[b:b + 1], k8[b:b + 1], v8b, vsb, vt[b:b + 1], H, qe, ke, k_len=L)[0], both_f8[b])
+    ref = ops.attention_fwd(q, k, vt, H, k_len=L, q_prescaled=True)
+    assert rel_l2(both_f8, ref) < 3e-2 and rel_l2(both_qk8, ref) < 2e-2
