@@ -42,7 +42,27 @@ if len(sys.argv) > 4:
 
 def take(ops, s):
     """micro-ops of slot s (0..31) out of an 80-op segment stream: 5 per slot pair, split 3 + 2 or 2 + 3
-    (PK: 96 ops, 3 per slot)"""
+    (PK: 96 ops, 3 per slot).  BAL = 2 balances CYCLES instead of counts: v_exp_f32 issues at the quarter rate (16 cycles for a
+    wave64, against 4 for an add or a pack), so a slot with three exponentials keeps the wave 48+ cycles under a 32-cycle MFMA while
+    its neighbour idles -- exactly ONE exponential per slot, its add one slot later, a pack every other slot."""
+    if BAL == 3 and not PK and not Q8:      # as BAL = 2 with the packs on the odd slots (which also carry the fragment read)
+        es = [o for o in ops if o.startswith("E(")]
+        as_ = [o for o in ops if o.startswith("A(")]
+        cs = [o for o in ops if o.startswith("C(")]
+        line = [es[s]] + ([as_[s - 1]] if s >= 1 else []) + ([cs[(s - 3) // 2]] if s >= 3 and s % 2 == 1 else [])
+        if s == 31:
+            line += [as_[31], cs[15]]
+        return line
+    if BAL == 2 and not PK and not Q8:
+        es = [o for o in ops if o.startswith("E(")]
+        as_ = [o for o in ops if o.startswith("A(")]
+        cs = [o for o in ops if o.startswith("C(")]
+        assert len(es) == 32 and len(as_) == 32 and len(cs) == 16
+        # group order of E / A / C is the same, C_k packs E_2k, E_2k+1
+        line = [es[s]] + ([as_[s - 1]] if s >= 1 else []) + ([cs[(s - 2) // 2]] if s >= 2 and s % 2 == 0 else [])
+        if s == 31:
+            line += [as_[31], cs[15]]
+        return line
     if PK:
         return ops[3 * s:3 * s + 3]
     a = (s >> 1) * 5

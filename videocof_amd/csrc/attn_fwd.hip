@@ -899,7 +899,11 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         } else if constexpr (PKSUB) {
 #include "attn_w4_sched_pk.inc"
         } else {
+#ifdef WAN_ATTN_SCHED_ALT       // developer A/B builds only (a second library next to the product one); never defined by the Makefile
+#include WAN_ATTN_SCHED_ALT
+#else
 #include "attn_w4_sched.inc"
+#endif
         }
 #undef RDK
 #undef RDK8
