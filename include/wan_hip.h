@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 4
+#define WAN_ABI_VERSION 5      /* 5: the fp8 attention family (wan_attention_fwd_qk8 / _f8, wan_rmsnorm_rope_fp8, wan_col_mean_bf16, wan_qk_quantize_fp8, wan_vt_quantize_mx) */
 
 typedef enum {
     WAN_OK = 0,
