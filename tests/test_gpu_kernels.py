@@ -37,7 +37,7 @@ def rope_dev():
 
 def test_extension_is_loaded():
     lib = _lib.load()
-    assert lib.wan_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.wan_abi_version() == _lib.ABI_VERSION            # (the number itself is pinned by tests/test_abi.py)
     maps = open("/proc/self/maps").read()
     assert "libwan_hip.so" in maps
 
