@@ -42,9 +42,10 @@ if len(sys.argv) > 4:
 
 def take(ops, s):
     """micro-ops of slot s (0..31) out of an 80-op segment stream: 5 per slot pair, split 3 + 2 or 2 + 3
-    (PK: 96 ops, 3 per slot).  BAL = 2 balances CYCLES instead of counts: v_exp_f32 issues at the quarter rate (16 cycles for a
-    wave64, against 4 for an add or a pack), so a slot with three exponentials keeps the wave 48+ cycles under a 32-cycle MFMA while
-    its neighbour idles -- exactly ONE exponential per slot, its add one slot later, a pack every other slot."""
+    (PK: 96 ops, 3 per slot).  BAL = 2 balances COST instead of counts: a v_exp_f32 costs 1.6 adds (tools/probe/valu_rates.hip), and
+    the count-balanced stream puts three of them under one 32-cycle MFMA and none under the next -- here exactly ONE exponential per slot,
+    its add one slot later, a pack every other slot.  Measured: no change for the power-limited bf16 kernel
+    (profiles/r03/attn_cycle_balanced_sched_ab.log); the product files are BAL = 0."""
     if BAL == 3 and not PK and not Q8:      # as BAL = 2 with the packs on the odd slots (which also carry the fragment read)
         es = [o for o in ops if o.startswith("E(")]
         as_ = [o for o in ops if o.startswith("A(")]
