@@ -413,3 +413,25 @@ def test_fp8_attention_kernels_batch_strides():
     e_f8, e_qk8 = rel_l2(both_f8, ref), rel_l2(both_qk8, ref)
     print(f"zero-mean V, L = {L}: all-fp8 kernel vs bf16 kernel rel-L2 {e_f8:.2e}, fp8 QK^T only {e_qk8:.2e}")
     assert e_qk8 < 6e-2 and e_f8 < 8e-2
+
+
+def test_fp8_attention_modes_replay_from_a_graph():
+    """hipGraph replay of the forward with the fp8 attention paths on (K smoothing's column mean, the V^T quantiser, both attention
+    launches and the fix-up are all enqueued on the capture stream): bit-identical to the eager call, and the entry follows a change of
+    the mode (the graph key carries the fp8 layer set and options)."""
+    from videocof_amd.graph import GraphedForward
+    tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**tiny), device=DEV)
+    lat = det_uniform("fp8.lat", (1, 16, 7, 12, 20), 1.0).to(DEV)
+    ctx = [det_uniform("fp8.ctx", (37, 64), 1.0).to(DEV)]
+    t = torch.tensor([899], device=DEV)
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    gf = GraphedForward(m)
+    for layers in (("attn",), ("attn", "attn_pv"), ("qkv", "ffn", "o", "cross", "attn", "attn_pv")):
+        m.enable_fp8_linear(layers)
+        eager = m(lat, t, ctx, 420, **kw)
+        outs = [gf(lat, t, ctx, 420, **kw) for _ in range(3)]          # eager warm-up, capture + replay, replay
+        assert all(torch.equal(o, eager) for o in outs), layers
+    assert gf.replays >= 6
+    m.disable_fp8_linear()
