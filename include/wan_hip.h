@@ -203,6 +203,7 @@ int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, 
 int wan_attention_plan(int batch, int Lq, int Lk, int num_heads, int head_dim, int flags, int64_t workspace_bytes);
 #define WAN_ATTN_Q_PRESCALED 1
 #define WAN_ATTN_QK_FP8 2                   /* wan_attention_plan only: plan for wan_attention_fwd_qk8 */
+#define WAN_ATTN_PV_FP8 4                   /* wan_attention_plan only, with WAN_ATTN_QK_FP8: plan for wan_attention_fwd_f8 */
 #define WAN_ATTN_QSCALE(softmax_scale) ((softmax_scale) * 1.4426950408889634f)
 
 /* a9' Self-attention with the QK^T product on the fp8 matrix pipe (LOSSY, opt-in; the role of the reference's

@@ -110,6 +110,8 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     # (the fp8-QK^T lazy form), the split tail, the V^T MX quantiser, the fp8 instantiation of the 256^2 GEMM and the K-smoothing kernels
     v8 = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED | 2, ws)
     assert v8 & 15 == 4 and v8 & _lib.ATTN_VARIANT_SPLIT_TAIL
+    vf8 = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED | 2 | 4, ws)        # WAN_ATTN_QK_FP8 | WAN_ATTN_PV_FP8
+    assert vf8 & 15 == 5 and vf8 & _lib.ATTN_VARIANT_SPLIT_TAIL and vf8 & _lib.ATTN_VARIANT_XCD_PINNED
     p8 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench14b_fp8_everything_kernel_stats.csv")))
     assert p8
     with open(p8[-1]) as f:

@@ -1568,7 +1568,7 @@ namespace {
 // The dispatch decision of wan_attention_fwd as host arithmetic (shared by the launcher and wan_attention_plan).
 struct AttnPlan { TailPlan tail; bool fast = false, w4 = true, ref2 = false, xcd = false; int variant = 0; };
 
-AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int64_t workspace_bytes, bool qk8 = false) {
+AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int64_t workspace_bytes, bool qk8 = false, bool pv8 = false) {
     AttnPlan p;
     const bool self = Lk > 1024;
     const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
@@ -1590,7 +1590,7 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
     // heads pinned to XCDs: only worth it (and only balanced) when the (batch, head) pairs split evenly over the 8 XCDs
     p.xcd = wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && (num_heads * batch) % 8 == 0;
     if (qk8) p.ref2 = false;
-    p.variant = qk8 ? WAN_ATTN_VARIANT_W4_LAZY_QK8      // (the fp8 P.V form reports WAN_ATTN_VARIANT_W4_F8 from the launcher)
+    p.variant = (qk8 && pv8 && workspace_bytes >= fb) ? WAN_ATTN_VARIANT_W4_F8 : qk8 ? WAN_ATTN_VARIANT_W4_LAZY_QK8
                     : (!p.w4 ? WAN_ATTN_VARIANT_W8_RUNNING_MAX : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY));
     if (p.xcd) p.variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (p.tail.tq > 0) p.variant |= WAN_ATTN_VARIANT_SPLIT_TAIL;
@@ -1600,7 +1600,8 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
 
 extern "C" int wan_attention_plan(int batch, int Lq, int Lk, int num_heads, int head_dim, int flags, int64_t workspace_bytes) {
     if (batch <= 0 || Lq <= 0 || Lk <= 0 || num_heads <= 0 || head_dim != kD) return 0;
-    return plan_attention(batch, Lq, Lk, num_heads, (flags & WAN_ATTN_Q_PRESCALED) != 0, workspace_bytes, (flags & WAN_ATTN_QK_FP8) != 0).variant;
+    return plan_attention(batch, Lq, Lk, num_heads, (flags & WAN_ATTN_Q_PRESCALED) != 0, workspace_bytes, (flags & WAN_ATTN_QK_FP8) != 0,
+                          (flags & WAN_ATTN_PV_FP8) != 0).variant;
 }
 
 extern "C" int64_t wan_attention_workspace_bytes(int batch, int Lq, int Lk, int num_heads, int head_dim) {
@@ -1728,7 +1729,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
             ws_tail = (char*)workspace + fb;
         }
     }
-    const AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable, qk8 != nullptr);
+    const AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable, qk8 != nullptr, qk8 != nullptr && qk8->v8 != nullptr);
     const TailPlan& tp = plan.tail;
     const bool fast = plan.fast;
     a.nqb = tp.tq > 0 ? tp.main_qb : nqb_all;
