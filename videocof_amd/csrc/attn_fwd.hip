@@ -1288,8 +1288,12 @@ void attn_fwd_f8_kernel(AttnArgs a) {
                             else { const i32x8 p_ = F8_PBLOCK(p8b); F8V_MFMA(o[1][dt], dt, p_, vsc, psb); } SB(); } while (0)
 #define G8F(j) do { if ((j) < 2) stage_k(rk, 1 - kslot_next, (j)); else if ((j) < 4) stage_v(rv, 1 - vslot, (j) - 2); else stage_s(rs, 1 - vslot); } while (0)
 // block 1 reads S(t) of query block 1, block 0 reads S(t+1) of query block 0; score i of a block = key-half kt = i >> 4, register i & 15
-#define E8(blk, i) do { e[i] = __builtin_amdgcn_exp2f((blk) ? sc[1][(i) >> 4][(i) & 15] : sn[0][(i) >> 4][(i) & 15]); } while (0)
-#define A8(blk, i) do { if (blk) { if ((i) < 16) s1k0 += e[i]; else s1k1 += e[i]; } else { if ((i) < 16) s0k0 += e[i]; else s0k1 += e[i]; } } while (0)
+#ifndef F8_TIMING
+#define F8_TIMING 0      // developer timing builds only (-DF8_TIMING=bits: 1 no row-sum adds, 2 no conversions, 4 no exponentials, 8 no scale chain); results are garbage
+#endif
+#define E8(blk, i) do { if constexpr ((F8_TIMING & 4) != 0) e[i] = (blk) ? sc[1][(i) >> 4][(i) & 15] : sn[0][(i) >> 4][(i) & 15]; \
+                        else e[i] = __builtin_amdgcn_exp2f((blk) ? sc[1][(i) >> 4][(i) & 15] : sn[0][(i) >> 4][(i) & 15]); } while (0)
+#define A8(blk, i) do { if constexpr ((F8_TIMING & 1) == 0 || (i) % 16 == 0) { if (blk) { if ((i) < 16) s1k0 += e[i]; else s1k1 += e[i]; } else { if ((i) < 16) s0k0 += e[i]; else s0k1 += e[i]; } } } while (0)
 // the six steps of block_scales() as single instructions: exchange | total | * 2^-7 | keep the exponent | its byte for the MFMA | broadcast both
 #define F8_SC(k, SK0, SK1, XA, XB, C0, C1, PS) do { \
         if ((k) == 0) { XA = SK0; XB = SK1; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(XA), "+v"(XB)); } \
@@ -1298,8 +1302,9 @@ void attn_fwd_f8_kernel(AttnArgs a) {
         else if ((k) == 3) C0 = __uint_as_float(__float_as_uint(XA) & 0x7f800000u); \
         else if ((k) == 4) PS = __float_as_uint(C0) >> 23; \
         else { C1 = C0; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(C0), "+v"(C1)); } } while (0)
-#define SC8(blk, k) do { if (blk) F8_SC(k, s1k0, s1k1, x1a, x1b, sc1k0, sc1k1, psb); else F8_SC(k, s0k0, s0k1, x0a, x0b, sc0k0, sc0k1, psa_next); } while (0)
-#define C8(blk, w) do { if (blk) p8b[(w) >> 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8b[(w) >> 1], e[2 * (w)], e[2 * (w) + 1], (w) < 8 ? sc1k0 : sc1k1, ((w) & 1) != 0); \
+#define SC8(blk, k) do { if constexpr ((F8_TIMING & 8) != 0) { if ((k) == 0) { if (blk) { sc1k0 = s1k0; sc1k1 = s1k1; psb = 127; } else { sc0k0 = s0k0; sc0k1 = s0k1; psa_next = 127; } } } \
+                         else if (blk) F8_SC(k, s1k0, s1k1, x1a, x1b, sc1k0, sc1k1, psb); else F8_SC(k, s0k0, s0k1, x0a, x0b, sc0k0, sc0k1, psa_next); } while (0)
+#define C8(blk, w) do { if constexpr ((F8_TIMING & 2) != 0 && (w) % 8 != 0) break; if (blk) p8b[(w) >> 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8b[(w) >> 1], e[2 * (w)], e[2 * (w) + 1], (w) < 8 ? sc1k0 : sc1k1, ((w) & 1) != 0); \
                         else pa_next[(w) >> 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(pa_next[(w) >> 1], e[2 * (w)], e[2 * (w) + 1], (w) < 8 ? sc0k0 : sc0k1, ((w) & 1) != 0); } while (0)
 #define MIDPOINT() do { l_run[1] += s1k0 + s1k1; } while (0)
 #include "attn_f8_sched.inc"
