@@ -181,6 +181,109 @@ def test_sp_async_path_over_rccl_on_one_gpu():
     print(f"rccl world_size=1: rel={rel:.2e} bitwise_vs_single={bitwise_single} exposed_comm={ms:.2f} ms over {n_ev} windows")
 
 
+def _fp8_attn_sp_worker(port, q_out):
+    """The fp8 attention options under the Ulysses branch (RCCL, one rank, force_ulysses): the e4m3 q / k (K smoothing over the
+    arrived tokens), the MX V^T and both fp8 kernels run on the arrived wire operands."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from videocof_amd import WanTransformer3DModel, ops
+        from videocof_amd import dist as vdist
+        from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+        heads, layers = 4, 3
+        cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=layers, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+        m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=layers, text_dim=64)
+        m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+        lat = det_uniform("sp.lat", (1, 16, 7, 12, 20), 1.0).cuda()
+        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda()]
+        t = torch.tensor([749], device="cuda:0")
+        kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+        bf16 = m(lat, t, ctx, 420, **kw)
+        vdist.init_sequence_parallel()
+        m.enable_multi_gpus_inference()
+        res = []
+        for layers_ in (("attn",), ("attn", "attn_pv")):
+            m.enable_fp8_linear(layers_)
+            m.force_ulysses = False
+            single = m(lat, t, ctx, 420, **kw)
+            m.force_ulysses = True
+            sharded = m(lat, t, ctx, 420, **kw)
+            variant = ops.get_tuning("last_attn_variant")        # the last attention call of a forward is the bf16 cross-attention
+            again = m(lat, t, ctx, 420, **kw)
+            wb = m._bufs[m._bufs_last]
+            used = m._usp and wb.vt is None and hasattr(wb, "q8") and (("attn_pv" not in layers_) or hasattr(wb, "v8"))
+            torch.cuda.synchronize()
+            res.append((float((sharded - single).norm() / single.norm()), float((sharded - bf16).norm() / bf16.norm()),
+                        bool(torch.equal(again, sharded)), bool(used), bool(torch.equal(sharded, bf16)), variant))
+        q_out.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp8_attention_options_under_ulysses():
+    """`enable_fp8_linear(("attn",))` / `(("attn", "attn_pv"))` with sequence parallelism on: same result as the single-device fp8 forward
+    up to the different q | k projection split, repeatable bitwise, and really different from the bf16 forward (the fp8 kernels ran)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_fp8_attn_sp_worker, args=(_free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    for rel_single, rel_bf16, again, used, same_as_bf16, _ in q.get(timeout=5):
+        assert used and again and not same_as_bf16
+        assert rel_single < 5e-3 and 0 < rel_bf16 < 3e-2, (rel_single, rel_bf16)
+
+
+def _fp8_attn_gloo_worker(rank, world, port, q_out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videocof_amd import WanTransformer3DModel
+        from videocof_amd import dist as vdist
+        from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+        heads = 4
+        cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+        m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=2, text_dim=64)
+        m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+        lat = det_uniform("sp.lat", (1, 16, 7, 12, 20), 1.0).cuda()
+        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda()]
+        t = torch.tensor([749], device="cuda:0")
+        kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+        m.enable_fp8_linear(("attn", "attn_pv"))
+        single = m(lat, t, ctx, 420, **kw)
+        vdist.init_sequence_parallel()
+        m.enable_multi_gpus_inference()
+        sharded = m(lat, t, ctx, 420, **kw)
+        torch.cuda.synchronize()
+        q_out.put((rank, float((sharded - single).norm() / single.norm())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp8_attention_sharded_over_two_ranks_equals_single_device():
+    """All-fp8 attention with the heads REALLY split (2 ranks, gloo, shared GPU): each rank quantises its arrived heads (K mean over all
+    tokens, MX V^T) -- same numbers as the single-device fp8 forward up to the projection split."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fp8_attn_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(r[1] < 5e-3 for r in res), res
+    assert len({round(r[1], 9) for r in res}) == 1
+
+
 def _library_comm_worker(q_out):
     """The Ulysses branch over the communicator the LIBRARY owns (wan_sp_*: RCCL bound by dlopen, one side stream, two events),
     one rank, no torch.distributed at all."""

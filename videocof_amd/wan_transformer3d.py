@@ -343,12 +343,13 @@ class WanTransformer3DModel(nn.Module):
         K / V projections stay bf16.  "attn" is not a Linear: it moves the self-attention QK^T product to the fp8 matrix pipe
         (e4m3 q and k with static power-of-two scales ``fp8_attn_exponents``, written by the RMSNorm+RoPE kernel; softmax and
         P.V stay bf16 / fp32) -- the role of the reference's ``sageattn`` branch (attention_utils.py:152-211,
-        ``attention_type = "SAGE_ATTENTION"``: 8-bit QK^T, 16-bit P.V); single-device path only.  ``attn_smooth_k`` (default on, as
+        ``attention_type = "SAGE_ATTENTION"``: 8-bit QK^T, 16-bit P.V).  ``attn_smooth_k`` (default on, as
         ``sageattn``'s ``smooth_k``): the e4m3 copy of k is taken of k minus its per-sample mean over the tokens, which the softmax
         cannot see and which keeps a channel with a large common offset from eating the 3 mantissa bits (one extra 0.5 ms pass
         per layer at the 14B shape); off: the RMSNorm+RoPE kernel writes the e4m3 operands directly.  "attn_pv" (with "attn"): the
         P.V product as well -- V^T is re-quantised per layer into MX e4m3 blocks of 32 keys (``wan_vt_quantize_mx``, 0.23 ms), P inside
-        the kernel; SageAttention-2's operating point (``wan_attention_fwd_f8``, include/wan_hip.h a9'').
+        the kernel; SageAttention-2's operating point (``wan_attention_fwd_f8``, include/wan_hip.h a9'').  Under Ulysses sequence
+        parallelism the Linears stay bf16 and the two attention options run on each rank's arrived (bf16-wire) operands, batch 1 only.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
@@ -576,8 +577,9 @@ class WanTransformer3DModel(nn.Module):
                 from ._lib import load
                 b.kmean_ws = torch.empty(int(load().wan_col_mean_workspace_bytes(B, C)) // 4, device=dev, dtype=torch.float32)
                 if "attn_pv" in self._fp8:
-                    b.v8 = torch.empty_like(b.vt, dtype=ops.FP8)
-                    b.v8s = torch.empty(int(load().wan_vt_mx_scale_bytes(B, self.num_heads, L)), device=dev, dtype=torch.uint8)
+                    b.v8 = torch.empty_like(b.vt_full if self._usp else b.vt, dtype=ops.FP8)
+                    b.v8s = torch.empty(int(load().wan_vt_mx_scale_bytes(B, self.num_heads // (P if self._usp else 1), L)), device=dev,
+                                        dtype=torch.uint8)
         b.pinned = False
         self._bufs[key] = b
         self._bufs_last = key
@@ -602,7 +604,8 @@ class WanTransformer3DModel(nn.Module):
         C, H, P, M = self.dim, self.num_heads, self.sp_world_size, B * Ll
         h, qk, att, cq, ff, vt, qk3 = bufs.h, bufs.qk, bufs.att, bufs.cq, bufs.ff, bufs.vt, bufs.qk3
         usp = self._usp
-        f8 = blk.f8 if (blk.f8 and not usp) else {}
+        f8 = blk.f8 if (blk.f8 and not usp) else {}            # fp8 Linears: single-device path only (the bf16 weights serve Ulysses)
+        a8_sp = usp and bool(blk.f8) and "attn" in blk.f8       # the fp8 attention products also run on the arrived Ulysses operands
         if not usp and not f8 and self._attn_events is None and self.use_block_composite:
             # the same launch sequence as below, enqueued by ONE C call (wan_dit_block_forward): 1 FFI crossing instead of 15
             self._block_composite(blk, em, xs, bufs, ctx_kv, rp, B, Ll, L)
@@ -679,8 +682,26 @@ class WanTransformer3DModel(nn.Module):
             self._comm_done(cev)
             as_bld = lambda w: w.view(Lt, B, Cl).permute(1, 0, 2)          # [B, P*Ll, Cl] view: row stride B*Cl, sample stride Cl
             ev = self._event_pair()
-            ops.attention_fwd(as_bld(bufs.qw_r), as_bld(bufs.kw_r), bufs.vt_full, H // P, k_len=L, out=as_bld(bufs.ow_s),
-                              q_prescaled=True, workspace=self._ws_self)
+            if a8_sp:
+                # fp8 attention on the arrived operands (bf16 wires; every rank holds all tokens of its heads, so the K mean is local)
+                if B != 1:
+                    raise NotImplementedError("fp8 attention under sequence parallelism covers batch 1 (no CFG batch)")
+                q_arr, k_arr = bufs.qw_r.view(Lt, Cl), bufs.kw_r.view(Lt, Cl)
+                q8v, k8v = bufs.q8.view(-1)[:Lt * Cl].view(Lt, Cl), bufs.k8.view(-1)[:Lt * Cl].view(Lt, Cl)
+                mean = None
+                if self.fp8_attn_smooth_k:
+                    mean = ops.col_mean(k_arr, Lt, L, 1, out=bufs.kmean.view(-1)[:Cl].view(1, Cl), workspace=bufs.kmean_ws)
+                ops.qk_quantize_fp8(q_arr, k_arr, Lt, mean, 2.0 ** qe, 2.0 ** ke, q8v, k8v)
+                if "attn_pv" in blk.f8:
+                    ops.vt_quantize_mx(bufs.vt_full, H // P, L, v8=bufs.v8, scales=bufs.v8s)
+                    ops.attention_fwd_f8(q8v.view(1, Lt, Cl), k8v.view(1, Lt, Cl), bufs.v8, bufs.v8s, bufs.vt_full, H // P, qe, ke, k_len=L,
+                                         out=as_bld(bufs.ow_s), workspace=self._ws_self)
+                else:
+                    ops.attention_fwd_qk8(q8v.view(1, Lt, Cl), k8v.view(1, Lt, Cl), bufs.vt_full, H // P, qe, ke, k_len=L,
+                                          out=as_bld(bufs.ow_s), workspace=self._ws_self)
+            else:
+                ops.attention_fwd(as_bld(bufs.qw_r), as_bld(bufs.kw_r), bufs.vt_full, H // P, k_len=L, out=as_bld(bufs.ow_s),
+                                  q_prescaled=True, workspace=self._ws_self)
             self._event_done(ev, B * seq_len)
             cev = self._comm_pair()             # exposed: the inverse exchange sits between attention and the o projection
             sp.exchange(bufs.ow_r, bufs.ow_s)
