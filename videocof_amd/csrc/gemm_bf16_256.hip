@@ -846,6 +846,18 @@ wan_status_t launch256_fp8(const GemmArgs& g, hipStream_t s) {
         return WAN_OK;
     });
     if (st != WAN_OK) return st;
+#if WAN_DEV_EXPERIMENTS      // `make EXPERIMENTS=1`: the 4-phase form of the fp8 instantiation for A/B timing (gemm_phases = 4)
+    if (wan_tune(WAN_TUNE_GEMM_PHASES) == 4) {
+        static std::atomic<uint64_t> attr4{0};
+        const wan_status_t st4 = wan_once_per_device(attr4, +[]() -> wan_status_t {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) == hipSuccess ? WAN_OK : WAN_ERR_LAUNCH;
+        });
+        if (st4 != WAN_OK) return st4;
+        hipLaunchKernelGGL((gemm256_kernel<EPI, 4, true>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), kLdsBytes, s, g);
+        WAN_CHECK_LAUNCH("wan_gemm_fp8");
+        return WAN_OK;
+    }
+#endif
     hipLaunchKernelGGL((gemm256_kernel<EPI, 2, true>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kThreads), kLdsBytes, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_fp8");
     return WAN_OK;
