@@ -24,8 +24,9 @@ Tunables: PDK / PDV = fragments kept in flight ahead of their first use; BAL = 1
 usage: gen_attn_w4_sched.py PDK PDV BAL [PK [Q8]] > attn_w4_sched.inc
 
 Q8 = 1 (attn_w4_sched_q8.inc): the QK^T product runs on the fp8 matrix pipe -- segment B is 8 slots of one 16-pass
-v_mfma_scale_f32_32x32x64_f8f6f4 each (chains (qb, kt) of two links: d halves dh = 0, 1) instead of 32 8-pass slots, every slot
-carrying 10 softmax micro-ops (the same 80-op stream); K fragment f = 2 dh + kt is TWO ds_read_b128 (32 fp8 per lane) into its
+v_mfma_scale_f32_32x32x64_f8f6f4 each (chains (qb, kt) of two links: d halves dh = 0, 1) instead of 32 8-pass slots; the softmax
+stream is split 40 : 120 between the segments (5 micro-ops per B slot, 3.75 per C slot): tt = 3 of the tile in B, tt = 0, 1, 2 of the
+next tile in C; K fragment f = 2 dh + kt is TWO ds_read_b128 (32 fp8 per lane) into its
 own registers (RDK8), the wave stages 2 K pieces + 4 V^T pieces (G8(0..5)).  Segment C is unchanged.
 """
 import sys
@@ -87,9 +88,16 @@ def group(tt, qb):
             A(6), A(7), C(3)]
 
 
-ops_b = sum((group(tt, qb) for tt in (2, 3) for qb in (0, 1)), [])      # current tile, key half kt = 1
-ops_c = sum((group(tt, qb) for tt in (0, 1) for qb in (0, 1)), [])      # next tile, key half kt = 0
-assert len(ops_b) == len(ops_c) == (96 if PK else 80)
+if Q8:
+    # segment B is 8 slots x 64 cycles, segment C 32 x 32: the stream is split 40 : 120 like the MFMA time -- only tt = 3 of the
+    # current tile in B, tt = 0, 1, 2 of the NEXT tile in C (its tt = 2 scores sit in the kt = 1 chains that end in B06 / B07)
+    ops_b = sum((group(3, qb) for qb in (0, 1)), [])
+    ops_c = sum((group(tt, qb) for tt in (0, 1, 2) for qb in (0, 1)), [])
+    assert len(ops_b) == 40 and len(ops_c) == 120
+else:
+    ops_b = sum((group(tt, qb) for tt in (2, 3) for qb in (0, 1)), [])      # current tile, key half kt = 1
+    ops_c = sum((group(tt, qb) for tt in (0, 1) for qb in (0, 1)), [])      # next tile, key half kt = 0
+    assert len(ops_b) == len(ops_c) == (96 if PK else 80)
 
 out = [f"// generated by tools/gen_attn_w4_sched.py {PDK} {PDV} {BAL}{' 1' if PK else (' 0' if Q8 else '')}{' 1' if Q8 else ''} -- do not edit by hand"]
 if Q8:
@@ -112,7 +120,7 @@ for s in range(8 if Q8 else 0):                          # ---- segment B, fp8 f
         line.append(f"G8({s});")
     if s >= 8 - (PDV + 1):
         line.append(f"RDV({s - (8 - (PDV + 1))});")
-    line += [o + ";" for o in ops_b[10 * s:10 * s + 10]]
+    line += [o + ";" for o in ops_b[5 * s:5 * s + 5]]
     out.append(" ".join(line) + " SB();" + f"   // B{s:02d}")
 for s in range(0 if Q8 else 32):                         # ---- segment B: S(t+1); 4 accumulate chains (qb, kt) interleaved
     ks, kt, qb = s >> 2, (s >> 1) & 1, s & 1
@@ -143,7 +151,10 @@ for s in range(32):                                      # ---- segment C: O += 
         g += 1
     if PIPE == 1 and s >= 32 - (PDK + 1):
         line.append(f"RDKN({s - (32 - (PDK + 1))});")
-    line += [o + ";" for o in take(ops_c, s)]
+    if Q8:
+        line += [o + ";" for o in ops_c[(120 * s) // 32:(120 * (s + 1)) // 32]]
+    else:
+        line += [o + ";" for o in take(ops_c, s)]
     out.append(" ".join(line) + " SB();" + f"   // C{s:02d}")
 assert g == (0 if Q8 else 8)
 # ---- s_waitcnt lgkmcnt counts for the kernel form whose ds_reads are inline asm (fragments land in AGPRs; hipcc does not
@@ -176,7 +187,7 @@ for line in out:
 out = new_out
 text = "\n".join(out) + "\n"
 # P fragments tt = 2, 3 of the current tile are complete at least one slot before the PV step that reads them
-for tt in (2, 3):
+for tt in ((3,) if Q8 else (2, 3)):           # (Q8: tt = 2 was produced in the previous interval's segment C)
     for qb in range(2):
         last_c = f"C({qb * 16 + tt * 4 + 3});"
         first_pv = f"PV(0,0,{tt},"

@@ -784,15 +784,19 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     // the PV segment of the PREVIOUS interval (P fragments tt = 0, 1 -> `pn`, their row sums -> `carry`) and ends in the S
     // segment of the tile's own interval (tt = 2, 3 -> `pf23`).  pa / pb ping-pong between "consumed now" and "produced for
     // the next tile"; tile 0's first half is produced here.
-    u32x4 pa[2][2], pb[2][2], pf23[2][2];
+    // QK8: segment B is only 8 (double-length) MFMA slots, so THREE of a tile's four P fragments are produced one interval ahead
+    // (tt = 0, 1, 2 -> pn[.][0..2], in the 32 slots of segment C, which have room) and only tt = 3 in the tile's own segment B:
+    // the stream is split 120 : 40 like the MFMA time of the two segments (1 024 : 512 cycles) instead of 80 : 80.
+    constexpr int kAhead = QK8 ? 3 : 2;         // P fragments of a tile produced in the previous interval
+    u32x4 pa[2][3], pb[2][3], pf23[2][2];       // ([.][2] and pf23[.][0]: one of the two is dead, depending on QK8)
     float carry[2] = {0.f, 0.f};
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < kAhead; ++tt) {
             float p[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(rel(s0[qb][0][8 * tt + j], qb)); carry[qb] += p[j]; }
+            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(rel(s0[qb][tt >> 1][8 * (tt & 1) + j], qb)); carry[qb] += p[j]; }
             u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
             pa[qb][tt] = w;
         }
@@ -800,7 +804,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     // ---- the repair path of the lazy reference (wave-uniform, rare): called at MIDCHECK of the interval of tile t when a
     // row sum of that tile left the window.  `sc` = S(t) (both key halves intact), `sn` = S(t+1) (complete, accumulated on the
     // OLD reference), `pc` / pf23 = the four P fragments of tile t, not yet consumed.
-    auto repair = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], float& ps0, float& ps1) __attribute__((always_inline)) {
+    auto repair = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][3], float& ps0, float& ps1) __attribute__((always_inline)) {
         // straight-line and cut into small steps by sched_barriers: at this point ~225 VGPRs are live, and a scheduler that
         // overlaps the steps for latency (as it would by default) spills
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // sn's accumulate chains ended in the last MFMA slots
@@ -837,7 +841,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(PKSUB ? __builtin_fmaf(sc[qb][tt >> 1][8 * (tt & 1) + j], a.scale_log2e, sh) : sc[qb][tt >> 1][8 * (tt & 1) + j] + sh); psum += p[j]; }
                 const u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
-                if (tt < 2) pc[qb][tt] = w; else pf23[qb][tt - 2] = w;
+                if (tt < kAhead) pc[qb][tt] = w; else pf23[qb][tt - 2] = w;
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (qb == 0) ps0 = psum; else ps1 = psum;
@@ -849,7 +853,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     // MAXFREE = false: the K / V^T fragments are read by inline-asm ds_read_b128 straight into AGPRs (they are MFMA A operands
     // only), which frees the 32 VGPRs the two -m splats need; hipcc does not track asm LDS reads, so the generated schedule
     // carries the s_waitcnt lgkmcnt count of every first use (LDS reads return in order).
-    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][2], u32x4 (&pn)[2][2], auto kslot_c, auto vslot_c,
+    auto interval = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pc)[2][3], u32x4 (&pn)[2][3], auto kslot_c, auto vslot_c,
                         int t) __attribute__((always_inline)) {
         constexpr int kslot_next = decltype(kslot_c)::value, vslot = decltype(vslot_c)::value;
         u32x4 kfr[4], vfr[4];          // MAXFREE (VGPRs, hipcc's own ds_reads)
@@ -882,18 +886,19 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #define G8(j) do { if ((j) < 2) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 2); } while (0)
 #define MIDCHECK() do { if constexpr (!MAXFREE) { if (a.exp_nocheck == 0) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } } while (0)
 #define PV(qb, dt, tt, f, w) do { if constexpr (MAXFREE) { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } \
-                                  else { W4_LGKM(w); if ((tt) < 2) W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pc[qb][(tt) & 1]); else W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pf23[qb][(tt) & 1]); } SB(); } while (0)
+                                  else { W4_LGKM(w); if ((tt) < kAhead) W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pc[qb][tt]); else W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pf23[qb][(tt) & 1]); } SB(); } while (0)
 #define G(j) do { if ((j) < 4) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 4); } while (0)
-// score i = 32 qb + 8 tt + j: tt >= 2 reads the current tile (key half kt = 1), tt < 2 the next tile (kt = 0)
-#define SRC(i) ((((i) >> 4) & 1) ? sc[(i) >> 5][1][(i) & 15] : sn[(i) >> 5][0][(i) & 15])
+// score i = 32 qb + 8 tt + j: tt >= kAhead reads the current tile (key half kt = 1), tt < kAhead the next tile
+#define TT_(i) (((i) >> 3) & 3)
+#define SRC(i) (TT_(i) >= kAhead ? sc[(i) >> 5][1][(i) & 15] : sn[(i) >> 5][TT_(i) >> 1][(i) & 15])
 // PKSUB: scores leave the accumulator raw; D(p) turns the pair (2p, 2p + 1) into exponent arguments s * c - m with one v_pk_fma_f32
 // (c = softmax_scale * log2(e) for plain q, exactly 1 for pre-scaled q), scheduled >= 1 op ahead of the first exp that reads it
 #define D(p) do { const f32x2 s2_ = {SRC(2 * (p)), SRC(2 * (p) + 1)}; dd[p] = __builtin_elementwise_fma(s2_, cpk, nmp[(p) >> 4]); } while (0)
 #define E(i) do { if constexpr (PKSUB) e[i] = __builtin_amdgcn_exp2f(dd[(i) >> 1][(i) & 1]); else e[i] = __builtin_amdgcn_exp2f(SRC(i)); } while (0)
-#define A(i) do { if (((i) >> 4) & 1) { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } else { if ((i) < 32) cn0 += e[i]; else cn1 += e[i]; } } while (0)
+#define A(i) do { if (TT_(i) >= kAhead) { if ((i) < 32) ps0 += e[i]; else ps1 += e[i]; } else { if ((i) < 32) cn0 += e[i]; else cn1 += e[i]; } } while (0)
 #define C(w) do { const unsigned pk_ = pack_bf16x2(e[((w) >> 4) * 32 + ((w) & 15) * 2], e[((w) >> 4) * 32 + ((w) & 15) * 2 + 1]); \
-                  if (((w) >> 3) & 1) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; \
-                  else pn[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; } while (0)
+                  if ((((w) >> 2) & 3) >= kAhead) pf23[(w) >> 4][((w) >> 2) & 1][(w) & 3] = pk_; \
+                  else pn[(w) >> 4][((w) >> 2) & 3][(w) & 3] = pk_; } while (0)
         if constexpr (QK8) {
 #include "attn_w4_sched_q8.inc"
         } else if constexpr (PKSUB) {
@@ -919,6 +924,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #undef E
 #undef D
 #undef SRC
+#undef TT_
 #undef A
 #undef C
         l_run[0] += ps0;
