@@ -541,6 +541,48 @@ def test_from_pretrained_safetensors_and_lora(tmp_path, model):
     assert rel_l2(out, ref) < 1e-2 and not torch.equal(out, model(lat, t, ctx, 48))
 
 
+def test_from_pretrained_mismatched_checkpoint_like_the_reference(tmp_path, model, capsys):
+    """A checkpoint that does not fit the config, loaded the way the reference loads it (wan_transformer3d.py:1259-1290):
+    torch-pickle file, 20-channel patch embedding truncated to 16, a wrong-size matrix and an unknown key skipped with the
+    reference's message, what is then missing REPORTED and filled with a fresh model's initial values -- and the forward of
+    the result equals the oracle on the state dict those rules produce."""
+    import json
+    sd = deterministic_dit_state_dict(**TINY)
+    ckpt = {k: v.clone() for k, v in sd.items()}
+    wide = det_uniform("mm.pe", (256, 20, 1, 2, 2), 0.05)
+    ckpt["patch_embedding.weight"] = wide
+    ckpt["blocks.1.ffn.2.weight"] = torch.zeros(256, 1024)          # size mismatch -> skipped -> fresh xavier values
+    ckpt["blocks.0.cross_attn.norm_q.weight"] = torch.zeros(128)     # size mismatch -> skipped -> ones
+    ckpt["img_emb.proj.0.weight"] = torch.zeros(4)                   # another family's key -> skipped
+    del ckpt["blocks.1.self_attn.o.bias"]                            # absent -> zeros
+    torch.save(ckpt, str(tmp_path / "diffusion_pytorch_model.bin"))
+    json.dump(dict(model_type="t2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, in_dim=16,
+                   out_dim=16, freq_dim=256, eps=1e-6, _class_name="WanTransformer3DModel"), open(tmp_path / "config.json", "w"))
+    m = WanTransformer3DModel.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16)
+    out = capsys.readouterr().out
+    for key in ("blocks.1.ffn.2.weight", "blocks.0.cross_attn.norm_q.weight", "img_emb.proj.0.weight"):
+        assert f"{key} Size don't match, skip" in out
+    assert "### missing keys: 3;" in out and "blocks.1.self_attn.o.bias" in out
+    got = m.state_dict()
+    assert torch.equal(got["patch_embedding.weight"].cpu().float(), wide[:, :16].bfloat16().float())
+    assert torch.equal(got["blocks.0.cross_attn.norm_q.weight"].cpu(), torch.ones(256))
+    assert float(got["blocks.1.self_attn.o.bias"].abs().max()) == 0.0
+    w = got["blocks.1.ffn.2.weight"].float()
+    assert 0 < float(w.abs().max()) <= (6.0 / (256 + 512)) ** 0.5 + 1e-3
+    eff = {k: v.detach().cpu().float() for k, v in got.items()}
+    lat = det_uniform("mm.lat", (1, 16, 3, 8, 8), 1.0).to(DEV)
+    ctx = [det_uniform("mm.ctx", (9, 64), 1.0).to(DEV)]
+    t = torch.tensor([500], device=DEV)
+    ref = O.dit_forward(eff, CFG, lat.cpu(), t.cpu(), [c.cpu() for c in ctx], 48)
+    assert rel_l2(m(lat, t, ctx, 48), ref) < 1e-2
+    # the strict loader refuses the same tensors, naming the key
+    m2 = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    with pytest.raises(ValueError, match="size mismatch for patch_embedding.weight"):
+        m2.load_state_dict(ckpt, device=DEV)
+    with pytest.raises(NotImplementedError, match="bfloat16"):
+        WanTransformer3DModel.from_pretrained(str(tmp_path), torch_dtype=torch.float16)
+
+
 def test_skip_source_prediction_is_parity_neutral(golden, model):
     """The last block may skip the query rows of the source frames whose prediction the pipeline
     zeroes (pipeline_wan.py:736): the denoised latents must not change."""

@@ -222,3 +222,94 @@ def test_transformer_surface_the_reference_pipeline_touches():
     for name in ("enable_teacache", "disable_teacache", "share_teacache", "enable_cfg_skip", "disable_cfg_skip",
                  "enable_multi_gpus_inference", "load_state_dict", "state_dict", "from_pretrained"):
         assert callable(getattr(m, name)), name
+
+
+# ------------------------------------------------------------------ checkpoint loader rules (wan_transformer3d.py:1259-1288)
+def _tiny_model():
+    return WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+
+
+def test_expected_shapes_are_the_reference_modules_shapes():
+    """``expected_shapes`` == the key -> shape table the fixtures' weight fill uses (captured against the reference's
+    ``state_dict()`` when the goldens were generated)."""
+    assert _tiny_model().expected_shapes() == {k: tuple(v) for k, v in dit_param_shapes(**TINY).items()}
+
+
+def test_load_state_dict_validates_every_shape_before_touching_the_device():
+    from videocof_amd.wan_transformer3d import StateDictShapeError
+    m = _tiny_model()
+    sd = deterministic_dit_state_dict(**TINY)
+    bad = dict(sd)
+    bad["blocks.1.ffn.0.weight"] = torch.zeros(512, 128)
+    for strict in (True, False):
+        with pytest.raises(ValueError, match=r"size mismatch for blocks\.1\.ffn\.0\.weight.*\[512, 128\].*\[512, 256\]"):
+            m.load_state_dict(bad, strict=strict, device="cpu")
+    with pytest.raises(RuntimeError, match="size mismatch"):          # what nn.Module raises
+        m.load_state_dict(bad, device="cpu")
+    assert issubclass(StateDictShapeError, ValueError) and issubclass(StateDictShapeError, RuntimeError)
+    short = {k: v for k, v in sd.items() if k != "head.head.bias"}
+    with pytest.raises(KeyError, match="missing key in state_dict: head.head.bias"):
+        m.load_state_dict(short, device="cpu")
+    with pytest.raises(KeyError, match="unexpected keys"):
+        m.load_state_dict(dict(sd, extra=torch.zeros(1)), device="cpu")
+    assert m.state_dict() == {}                                       # nothing was packed by the failed calls
+
+
+def test_read_checkpoint_file_and_shape_rules(tmp_path):
+    """File precedence (.bin pickle > single safetensors > shards > loose pickles), the patch-embedding channel pad /
+    truncate and the "Size don't match, skip" filter of the reference loader (wan_transformer3d.py:1259-1286)."""
+    from safetensors.torch import save_file
+    m = _tiny_model()
+    expect = m.expected_shapes()
+    sd = deterministic_dit_state_dict(**TINY)
+    # (1) shards, with a wrong-size tensor, an unknown key and a 20-channel patch embedding (truncate to 16)
+    d1 = tmp_path / "shards"; d1.mkdir()
+    mod = dict(sd)
+    mod["blocks.0.ffn.2.weight"] = torch.zeros(256, 1024)
+    mod["not.a.key"] = torch.zeros(3)
+    wide = det_uniform("pe.wide", (256, 20, 1, 2, 2), 0.1)
+    mod["patch_embedding.weight"] = wide
+    keys = sorted(mod)
+    save_file({k: mod[k].contiguous() for k in keys[::2]}, str(d1 / "a-00001-of-00002.safetensors"))
+    save_file({k: mod[k].contiguous() for k in keys[1::2]}, str(d1 / "a-00002-of-00002.safetensors"))
+    kept, skipped = WanTransformer3DModel.read_checkpoint(str(d1), expect)
+    assert sorted(skipped) == ["blocks.0.ffn.2.weight", "not.a.key"]
+    assert set(kept) == set(sd) - {"blocks.0.ffn.2.weight"}
+    assert torch.equal(kept["patch_embedding.weight"], wide[:, :16])
+    # (2) a 12-channel patch embedding is zero-padded to 16
+    d2 = tmp_path / "single"; d2.mkdir()
+    narrow = det_uniform("pe.narrow", (256, 12, 1, 2, 2), 0.1)
+    save_file({**{k: v.contiguous() for k, v in sd.items()}, "patch_embedding.weight": narrow}, str(d2 / "diffusion_pytorch_model.safetensors"))
+    save_file({"blocks.0.ffn.2.bias": torch.full((256,), 7.0)}, str(d2 / "other.safetensors"))     # ignored: the single file wins
+    kept, skipped = WanTransformer3DModel.read_checkpoint(str(d2), expect)
+    assert skipped == [] and torch.equal(kept["patch_embedding.weight"][:, :12], narrow)
+    assert float(kept["patch_embedding.weight"][:, 12:].abs().max()) == 0.0
+    assert float(kept["blocks.0.ffn.2.bias"][0]) != 7.0
+    # (3) the torch-pickle file wins over safetensors next to it
+    torch.save({k: v * 2 for k, v in sd.items()}, str(d2 / "diffusion_pytorch_model.bin"))
+    kept, _ = WanTransformer3DModel.read_checkpoint(str(d2), expect)
+    assert torch.equal(kept["head.head.weight"], sd["head.head.weight"] * 2)
+    # (4) loose .pth with a {"state_dict": ...} wrapper (fast_infer.py:286-295)
+    d3 = tmp_path / "pth"; d3.mkdir()
+    torch.save({"state_dict": sd}, str(d3 / "finetuned.pth"))
+    kept, skipped = WanTransformer3DModel.read_checkpoint(str(d3), expect)
+    assert set(kept) == set(sd) and skipped == []
+    with pytest.raises(FileNotFoundError):
+        WanTransformer3DModel.read_checkpoint(str(tmp_path), expect)
+    with pytest.raises(RuntimeError, match="config.json does not exist"):
+        WanTransformer3DModel.from_pretrained(str(d3))
+
+
+def test_fresh_values_follow_the_reference_init_rules():
+    """Keys a checkpoint lacks get what a fresh reference model holds after ``init_weights`` (:1133-1155)."""
+    m = _tiny_model()
+    g = torch.Generator().manual_seed(0)
+    assert float(m._fresh_value("blocks.0.self_attn.q.bias", (256,), g).abs().max()) == 0.0
+    assert float(m._fresh_value("head.head.weight", (64, 256), g).abs().max()) == 0.0
+    assert torch.equal(m._fresh_value("blocks.1.cross_attn.norm_k.weight", (256,), g), torch.ones(256))
+    assert float(m._fresh_value("blocks.1.norm3.bias", (256,), g).abs().max()) == 0.0
+    w = m._fresh_value("blocks.0.ffn.0.weight", (512, 256), g)
+    bound = math.sqrt(6.0 / (512 + 256))
+    assert float(w.abs().max()) <= bound and float(w.std()) == pytest.approx(bound / math.sqrt(3), rel=0.05)
+    assert float(m._fresh_value("text_embedding.0.weight", (256, 64), g).std()) == pytest.approx(0.02, rel=0.1)
+    assert float(m._fresh_value("blocks.0.modulation", (1, 6, 256), g).std()) == pytest.approx(1 / 16, rel=0.15)

@@ -63,6 +63,11 @@ def rope_params(max_seq_len: int, dim: int, theta: float = 10000.0) -> torch.Ten
 IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 
+class StateDictShapeError(ValueError, RuntimeError):
+    """A checkpoint tensor whose shape does not fit the configured model.  ValueError for callers that validate inputs,
+    RuntimeError because that is what ``nn.Module.load_state_dict`` raises for "size mismatch for <key>"."""
+
+
 class _Block:
     """Packed weights of one WanAttentionBlock (device tensors; bf16 matrices, fp32 vectors)."""
     __slots__ = ("w_qk", "b_qk", "w_v", "b_v", "w_o", "b_o", "nq", "nk",
@@ -165,20 +170,85 @@ class WanTransformer3DModel(nn.Module):
         return self._device
 
     # ------------------------------------------------------------------ weights
+    def expected_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Reference state-dict key -> shape for this configuration (the parameters of the modules built in
+        wan_transformer3d.py:633-690 / WanAttentionBlock :425-470 / Head :530-545): what ``load_state_dict`` checks every
+        tensor against and what ``from_pretrained``'s "Size don't match, skip" rule (:1279-1286) compares with."""
+        C, F, T = self.dim, self.ffn_dim, self.text_dim
+        pt, ph, pw = self.patch_size
+        sh = {"patch_embedding.weight": (C, self.in_dim, pt, ph, pw), "patch_embedding.bias": (C,),
+              "text_embedding.0.weight": (C, T), "text_embedding.0.bias": (C,),
+              "text_embedding.2.weight": (C, C), "text_embedding.2.bias": (C,),
+              "time_embedding.0.weight": (C, self.freq_dim), "time_embedding.0.bias": (C,),
+              "time_embedding.2.weight": (C, C), "time_embedding.2.bias": (C,),
+              "time_projection.1.weight": (6 * C, C), "time_projection.1.bias": (6 * C,),
+              "head.head.weight": (self.out_dim * pt * ph * pw, C), "head.head.bias": (self.out_dim * pt * ph * pw,),
+              "head.modulation": (1, 2, C)}
+        for i in range(self.num_layers):
+            p = f"blocks.{i}."
+            sh[p + "modulation"] = (1, 6, C)
+            for a in ("self_attn", "cross_attn"):
+                for l in ("q", "k", "v", "o"):
+                    sh[f"{p}{a}.{l}.weight"], sh[f"{p}{a}.{l}.bias"] = (C, C), (C,)
+                sh[f"{p}{a}.norm_q.weight"] = sh[f"{p}{a}.norm_k.weight"] = (C,)
+            sh[p + "norm3.weight"] = sh[p + "norm3.bias"] = (C,)
+            sh[p + "ffn.0.weight"], sh[p + "ffn.0.bias"] = (F, C), (F,)
+            sh[p + "ffn.2.weight"], sh[p + "ffn.2.bias"] = (C, F), (C,)
+        return sh
+
+    def _fresh_value(self, key: str, shape: Tuple[int, ...], gen: torch.Generator) -> torch.Tensor:
+        """The value a parameter the checkpoint lacks has on a FRESH reference model: its constructor defaults followed by
+        ``init_weights`` (wan_transformer3d.py:1133-1155) -- xavier-uniform Linears and patch embedding with zero biases,
+        N(0, 0.02) text / time embedding matrices, a zero head matrix, unit norm gains, zero norm3 bias, modulation
+        ~ N(0, 1) / sqrt(dim) (:462, :533).  Same distributions; the random draws are this package's own."""
+        if key.endswith("modulation"):
+            return torch.randn(shape, generator=gen) / self.dim ** 0.5
+        if key.endswith(".bias") or key == "head.head.weight":
+            return torch.zeros(shape)
+        if "norm" in key:
+            return torch.ones(shape)
+        if key.startswith(("text_embedding", "time_embedding")):
+            return torch.randn(shape, generator=gen) * 0.02
+        fan_out, fan_in = shape[0], int(math.prod(shape[1:]))
+        bound = math.sqrt(6.0 / (fan_in + fan_out))
+        return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
     def load_state_dict(self, state_dict, strict: bool = True, device=None):  # type: ignore[override]
         """Pack a REFERENCE-format state dict (keys as in wan_transformer3d.py's modules) for the
-        kernels: bf16 [N,K] matrices (q|k fused), fp32 bias / norm / modulation vectors."""
+        kernels: bf16 [N,K] matrices (q|k fused), fp32 bias / norm / modulation vectors.
+
+        Every tensor's shape is checked against the configuration (``expected_shapes``) BEFORE anything is packed:
+        a mismatch raises ``StateDictShapeError`` (a ValueError and, like nn.Module's "size mismatch for ...", a
+        RuntimeError) naming the key -- strict or not, as ``nn.Module.load_state_dict`` does.  ``strict=True``: missing or
+        unexpected keys raise KeyError.  ``strict=False``: unexpected keys are reported; missing keys keep their current
+        values on a loaded model (fast_infer.py:286-295) and get a fresh model's initial values on an empty one
+        (wan_transformer3d.py:1288), and are reported in ``missing_keys`` either way."""
+        sd = state_dict
+        expect = self.expected_shapes()
+        bad = [(k, tuple(v.shape), expect[k]) for k, v in sd.items() if k in expect and tuple(v.shape) != expect[k]]
+        if bad:
+            k, got, want = bad[0]
+            raise StateDictShapeError(f"size mismatch for {k}: checkpoint tensor is {list(got)}, the model "
+                                      f"(dim={self.dim}, ffn_dim={self.ffn_dim}, in_dim={self.in_dim}, text_dim={self.text_dim}) "
+                                      f"expects {list(want)}" + (f" (+{len(bad) - 1} more)" if len(bad) > 1 else ""))
+        missing = [k for k in expect if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing key in state_dict: {missing[0]}" + (f" (+{len(missing) - 1} more)" if len(missing) > 1 else ""))
+        if strict and any(k not in expect for k in sd):
+            extra = [k for k in sd if k not in expect]
+            raise KeyError(f"unexpected keys in state_dict: {extra[:5]}{'...' if len(extra) > 5 else ''}")
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if dev.type != "cuda":
             raise RuntimeError("WanTransformer3DModel runs on a HIP device only (no CPU fallback)")
-        sd = state_dict
-        missing = []
-        if not strict and getattr(self, "_w", None):
-            # nn.Module semantics of strict=False on a loaded model (fast_infer.py:286-295: a fine-tuned checkpoint on
-            # top of from_pretrained): keys that are absent keep their current values
-            current = self.state_dict()
-            missing = [k for k in current if k not in sd]
-            sd = {**current, **sd}
+        if missing:
+            if getattr(self, "_w", None):
+                # nn.Module semantics of strict=False on a loaded model (fast_infer.py:286-295: a fine-tuned checkpoint on
+                # top of from_pretrained): keys that are absent keep their current values
+                current = self.state_dict()
+                sd = {**{k: current[k] for k in missing}, **sd}
+            else:
+                gen = torch.Generator().manual_seed(0)
+                sd = {**{k: self._fresh_value(k, expect[k], gen) for k in missing}, **sd}
         used = set()
 
         def get(k):
@@ -237,8 +307,6 @@ class WanTransformer3DModel(nn.Module):
         w["mod_all"] = torch.stack([b.modulation for b in self.blocks])        # [layers, 6, C]
         self._cdw = None
         extra = [k for k in sd.keys() if k not in used]
-        if strict and extra:
-            raise KeyError(f"unexpected keys in state_dict: {extra[:5]}{'...' if len(extra) > 5 else ''}")
         ang = torch.view_as_real(self.freqs)          # [1024, 64, 2] = (cos, sin) of the fp64 angles
         self._rope_dev = (ang[..., 0].to(torch.float32).contiguous().to(dev),
                           ang[..., 1].to(torch.float32).contiguous().to(dev))
@@ -297,26 +365,100 @@ class WanTransformer3DModel(nn.Module):
                         p + "cross_attn.v": b.w_cv, p + "cross_attn.o": b.w_co, p + "ffn.0": b.w1, p + "ffn.2": b.w2})
         return out
 
+    @staticmethod
+    def read_checkpoint(path: str, expect: Dict[str, Tuple[int, ...]]):
+        """The file and shape rules of the reference loader (wan_transformer3d.py:1259-1286), host only: returns
+        ``(kept, skipped)`` -- the tensors that will be loaded and the keys dropped by the "Size don't match, skip" rule
+        (not a key of the model, or another size) -- after the ``patch_embedding.weight`` channel pad / truncate."""
+        def pickle_file(fpath):
+            obj = torch.load(fpath, map_location="cpu")
+            return obj["state_dict"] if isinstance(obj, dict) and "state_dict" in obj else obj
+
+        model_file = os.path.join(path, "diffusion_pytorch_model.bin")
+        model_file_safetensors = model_file.replace(".bin", ".safetensors")
+        if os.path.exists(model_file):
+            sd = pickle_file(model_file)
+        elif os.path.exists(model_file_safetensors):
+            from safetensors.torch import load_file
+            sd = load_file(model_file_safetensors)
+        else:
+            from safetensors.torch import load_file
+            files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+            sd = {}
+            for fpath in files:
+                sd.update(load_file(fpath))
+            if not files:
+                pickles = sorted(f for ext in ("*.pth", "*.pt", "*.ckpt", "*.bin") for f in glob.glob(os.path.join(path, ext)))
+                if not pickles:
+                    raise FileNotFoundError(f"no diffusion_pytorch_model.bin, *.safetensors or *.pth under {path}")
+                for fpath in pickles:
+                    sd.update(pickle_file(fpath))
+        sd = dict(sd)
+        want = expect["patch_embedding.weight"]
+        pe = sd.get("patch_embedding.weight")
+        if pe is not None and tuple(pe.shape) != want and pe.dim() == 5 and (pe.shape[0],) + tuple(pe.shape[2:]) == (want[0],) + want[2:]:
+            # :1274-1277 -- the checkpoint's input channels land in the leading channels, the rest (if any) is zero
+            cin = min(pe.shape[1], want[1])
+            fresh = torch.zeros(want, dtype=pe.dtype)
+            fresh[:, :cin] = pe[:, :cin]
+            sd["patch_embedding.weight"] = fresh
+        kept, skipped = {}, []
+        for key, val in sd.items():
+            if key in expect and tuple(val.shape) == expect[key]:
+                kept[key] = val
+            else:
+                skipped.append(key)
+        return kept, skipped
+
     @classmethod
     def from_pretrained(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
                         low_cpu_mem_usage=False, torch_dtype=torch.bfloat16):
-        """config.json + *.safetensors loader (wan_transformer3d.py:1157-1299); shards are merged."""
-        from safetensors.torch import load_file
+        """The reference's checkpoint loader (wan_transformer3d.py:1157-1299), rule by rule:
+
+        * ``config.json`` must exist (RuntimeError otherwise, :1166-1168); ``transformer_additional_kwargs`` override it,
+          incl. the ``dict_mapping`` indirection (:1176-1178);
+        * weights: ``diffusion_pytorch_model.bin`` (torch pickle, :1260-1261) if present, else
+          ``diffusion_pytorch_model.safetensors`` (:1262-1264), else every ``*.safetensors`` shard merged (:1265-1272);
+          a ``.pth`` / ``.pt`` / ``.ckpt`` pickle directly under the directory is accepted last (fast_infer.py:286-295 loads
+          such files; a ``state_dict`` wrapper key is unwrapped as there);
+        * ``patch_embedding.weight`` with another input-channel count is padded with zeros / truncated along dim 1 into
+          the fresh model's tensor (:1274-1277);
+        * keys the model does not have, or whose size differs, are dropped with the reference's message
+          ``<key> Size don't match, skip`` (:1279-1286);
+        * what is then missing keeps a fresh model's initial values and is REPORTED, not raised (``strict=False``, :1288-1290).
+
+        ``low_cpu_mem_usage`` only changes how the reference materialises parameters (meta device); any failure there falls
+        back to the path above (:1250-1253), so the loaded model is the same and the flag is accepted and ignored.  The
+        kernels compute in bf16 (the reference CLI's ``weight_dtype``, fast_infer.py:282): other ``torch_dtype`` values raise."""
         path = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
-        with open(os.path.join(path, "config.json")) as f:
+        print(f"loaded 3D transformer's pretrained weights from {path} ...")
+        config_file = os.path.join(path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file) as f:
             cfg = json.load(f)
+        if torch_dtype not in (None, torch.bfloat16):
+            raise NotImplementedError(f"torch_dtype={torch_dtype}: the gfx950 kernels compute in bfloat16 (fast_infer.py:282)")
+        extra_kw = dict(transformer_additional_kwargs)
+        for key, target in dict(extra_kw.get("dict_mapping", {})).items():
+            extra_kw[target] = cfg[key]
         import inspect
         ok = inspect.signature(cls.__init__).parameters
         kw = {k: v for k, v in cfg.items() if k in ok}
-        kw.update({k: v for k, v in dict(transformer_additional_kwargs).items() if k in ok})
+        kw.update({k: v for k, v in extra_kw.items() if k in ok})
         model = cls(**kw)
-        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
-        if not files:
-            raise FileNotFoundError(f"no *.safetensors under {path}")
-        sd = {}
-        for fpath in files:
-            sd.update(load_file(fpath))
-        model.load_state_dict(sd, strict=False)
+
+        expect = model.expected_shapes()
+        kept, skipped = cls.read_checkpoint(path, expect)
+        for key in skipped:
+            print(key, "Size don't match, skip")
+        m, u = model.load_state_dict(kept, strict=False)
+        print(f"### missing keys: {len(m)}; \n### unexpected keys: {len(u)};")
+        print(m)
+        n_all = sum(int(math.prod(s_)) for s_ in expect.values())
+        n_attn = sum(int(math.prod(s_)) for k_, s_ in expect.items() if "self_attn." in k_)
+        print(f"### All Parameters: {n_all / 1e6} M")
+        print(f"### self-attention Parameters: {n_attn / 1e6} M")
         return model
 
     # ------------------------------------------------------------------ reference API surface
