@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 5      /* 5: the fp8 attention family (wan_attention_fwd_qk8 / _f8, wan_rmsnorm_rope_fp8, wan_col_mean_bf16, wan_qk_quantize_fp8, wan_vt_quantize_mx) */
+#define WAN_ABI_VERSION 6      /* 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -140,6 +140,28 @@ int wan_gemm_plan(int M, int N, int K);
 #define WAN_GEMM_VARIANT_128 0      /* gemm_bf16_kernel: 128 x 128 x 64 tile, 4 waves, two workgroups per CU (small / under-filled shapes) */
 #define WAN_GEMM_VARIANT_256_W8 1   /* gemm256_kernel: 256 x 256 x 64 tile, 8 waves, phased K loop */
 #define WAN_GEMM_VARIANT_256_W4 2   /* gemm_w4_kernel: the same tile, 4 waves of 128 x 128 outputs (K >= 4096 by default) */
+#define WAN_GEMM_VARIANT_256_PK 3   /* gemm_pk_kernel: the 4-wave tile as ONE persistent workgroup per CU, stream-K remainder (wan_gemm_bf16_ws) */
+
+/* The same product with a caller-provided workspace: every nn.Linear of the DiT blocks on the path
+ * (wan_transformer3d.py:264-267 q/k/v/o, :457-459 ffn) runs through this entry in the Python host and in wan_dit_block_forward.
+ *     With a workspace, shapes the 4-wave 256^2 kernel would take run on its PERSISTENT form: one resident workgroup per CU walks
+ *     whole output tiles as one continuous K-tile stream (no per-tile pipeline fill) and the remainder tiles are cut stream-K
+ *     fashion so that every CU does the same amount of work (no tail round); split tiles are combined in K order by the last
+ *     arriver (bitwise reproducible, no spin waits).  Everything else -- and workspace == NULL -- is wan_gemm_bf16.
+ *     workspace: >= wan_gemm_workspace_bytes(M, N, K) bytes (0 when the shape would not use one), 16-byte aligned, owned by the
+ *     caller, not shared by launches that may run concurrently (one per stream); its contents need not survive between calls.
+ *     wan_gemm_ws_plan: the kernel family wan_gemm_bf16_ws picks when given a workspace (host arithmetic only). */
+wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                              void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                              const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t wan_gemm_workspace_bytes(int M, int N, int K);
+int wan_gemm_ws_plan(int M, int N, int K);
+/* Host arithmetic only (tests, curious hosts): the persistent kernel's plan.  wan_gemm_pk_grid: its grid (workers = one per CU,
+ * a multiple of 8).  wan_gemm_pk_segment: segment `index` of worker `worker` -- evaluated by the SAME functions the kernel runs;
+ * out[11] = tile m, tile n, first K tile, end K tile, partial?, workspace slot, arrival counter, first / last lane holding a piece of
+ * the tile, my lane, stream-K tile index; returns 1 while the segment exists. */
+int wan_gemm_pk_grid(int M, int N);
+int wan_gemm_pk_segment(int M, int N, int K, int worker, int index, int* out);
 
 /* ---------------------------------------------------------------------------
  * 8f-4  FP8 (OCP e4m3) projections -- an explicit, lossy option of the host model (`enable_fp8_linear`); never the default.

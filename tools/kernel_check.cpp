@@ -444,6 +444,76 @@ int main(int argc, char** argv) {
             WAN(wan_set_tuning("gemm_exp", 0));
         }
     }
+    if (mode == "gemmpk") {       // the persistent stream-K GEMM (wan_gemm_bf16_ws): numerics vs the one-tile-per-workgroup kernels, repro, in-process A/B
+        WAN(wan_set_tuning("gemm_pk", 2));
+        for (int i = 2; i < argc; ++i) {                       // extra "key=value" tuning arguments
+            const char* eq = strchr(argv[i], '=');
+            if (eq && argv[i][0] != '-') { std::string k(argv[i], eq - argv[i]); WAN(wan_set_tuning(k.c_str(), atoi(eq + 1))); printf("tuning %s=%d\n", k.c_str(), atoi(eq + 1)); }
+        }
+        struct Shape { int M, N, K; };
+        const int epis[5] = {WAN_EPI_BF16, WAN_EPI_GELU_BF16, WAN_EPI_F32, WAN_EPI_RESID_F32, WAN_EPI_BF16_T};
+        const char* en[5] = {"bf16", "gelu", "f32", "resid*gate", "transposed"};
+        for (Shape sh : {Shape{1100, 520, 512}, Shape{2304, 1536, 896}, Shape{700, 1300, 1024}, Shape{4100, 2100, 256}, Shape{9000, 5120, 640}, Shape{16776, 5120, 128}}) {
+            const int M = sh.M, N = sh.N, K = sh.K;
+            auto hA = to_bf(randn((size_t)M * K)), hW = to_bf(randn((size_t)N * K, 0.1f));
+            Dev<bf16> dA(hA), dW(hW); Dev<float> dB(randn(N, 0.5f)), dG(randn(2 * (size_t)N));
+            const int64_t wsb = wan_gemm_workspace_bytes(M, N, K);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16));
+            HIP(hipMemset(ws.p, 0xff, ws.n));                  // garbage in the workspace: the kernel must not depend on its contents
+            printf("M=%d N=%d K=%d: plan %d, workspace %lld bytes\n", M, N, K, wan_gemm_ws_plan(M, N, K), (long long)wsb);
+            const auto x0 = randn((size_t)M * N);
+            for (int e = 0; e < 5; ++e) {
+                const bool f32o = epis[e] == WAN_EPI_F32 || epis[e] == WAN_EPI_RESID_F32;
+                const int64_t ldo = epis[e] == WAN_EPI_BF16_T ? (M + 63) / 64 * 64 : N;
+                const size_t on = (size_t)(epis[e] == WAN_EPI_BF16_T ? N : M) * ldo;
+                std::vector<float> res[3];
+                for (int arm = 0; arm < 3; ++arm) {            // 0: reference kernels (no workspace), 1 and 2: persistent, twice
+                    Dev<char> out(on * (f32o ? 4 : 2));
+                    if (epis[e] == WAN_EPI_RESID_F32) HIP(hipMemcpy(out.p, x0.data(), on * 4, hipMemcpyHostToDevice)); else out.zero();
+                    const float* gate = epis[e] == WAN_EPI_RESID_F32 ? dG.p : nullptr;
+                    const int64_t rpb = (M + 1) / 2;
+                    if (arm == 0) WAN(wan_gemm_bf16(dA.p, K, dW.p, K, dB.p, out.p, ldo, M, N, K, epis[e], gate, rpb, nullptr));
+                    else WAN(wan_gemm_bf16_ws(dA.p, K, dW.p, K, dB.p, out.p, ldo, M, N, K, epis[e], gate, rpb, ws.p, wsb, nullptr));
+                    HIP(hipDeviceSynchronize());
+                    res[arm].resize(on);
+                    if (f32o) HIP(hipMemcpy(res[arm].data(), out.p, on * 4, hipMemcpyDeviceToHost));
+                    else { std::vector<bf16> h(on); HIP(hipMemcpy(h.data(), out.p, on * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < on; ++i) res[arm][i] = bf2f(h[i]); }
+                }
+                std::vector<double> ref(res[0].begin(), res[0].end());
+                char nm[96];
+                snprintf(nm, sizeof nm, "%s: persistent vs per-tile kernel", en[e]); report(nm, rel_l2(ref, res[1]), f32o ? 2e-6 : 2e-3);
+                snprintf(nm, sizeof nm, "%s: persistent, run to run", en[e]); report(nm, res[1] == res[2] ? 0.0 : 1.0, 0.0, "mismatch");
+            }
+        }
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+        // ---- in-process A/B on the 14B shapes: w4 (one workgroup per tile) vs persistent
+        WAN(wan_set_tuning("gemm_pk", 1));
+        const int L = 67080;
+        struct G { int M, N, K; int epi; const char* what; };
+        std::vector<G> gs = {{L, 5120, 5120, WAN_EPI_BF16, "o/q proj"}, {L, 10240, 5120, WAN_EPI_BF16, "qk proj"},
+                             {L, 5120, 5120, WAN_EPI_BF16_T, "v proj (T)"}, {L, 5120, 5120, WAN_EPI_RESID_F32, "o proj+gate+resid"},
+                             {L, 13824, 5120, WAN_EPI_GELU_BF16, "ffn.0+gelu"}, {L, 5120, 13824, WAN_EPI_RESID_F32, "ffn.2+resid"},
+                             {8392, 5120, 5120, WAN_EPI_BF16, "SP8 o/q proj"}, {8392, 10240, 5120, WAN_EPI_BF16, "SP8 qk proj"},
+                             {8392, 13824, 5120, WAN_EPI_GELU_BF16, "SP8 ffn.0"}, {8392, 5120, 13824, WAN_EPI_RESID_F32, "SP8 ffn.2"}};
+        for (auto g : gs) {
+            auto hA = to_bf(randn((size_t)4096 * 64));
+            Dev<bf16> A((size_t)g.M * g.K), W((size_t)g.N * g.K);
+            for (size_t off = 0; off < A.n; off += hA.size()) HIP(hipMemcpy(A.p + off, hA.data(), std::min(hA.size(), A.n - off) * 2, hipMemcpyHostToDevice));
+            for (size_t off = 0; off < W.n; off += hA.size()) HIP(hipMemcpy(W.p + off, hA.data(), std::min(hA.size(), W.n - off) * 2, hipMemcpyHostToDevice));
+            Dev<float> bias(g.N), gate(g.N); bias.zero(); gate.zero();
+            const int64_t ldo = g.epi == WAN_EPI_BF16_T ? (g.M + 63) / 64 * 64 : g.N;
+            const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
+            Dev<char> out(osz); out.zero();
+            const int64_t wsb = wan_gemm_workspace_bytes(g.M, g.N, g.K);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            for (int round = 0; round < 2; ++round)
+                for (int arm = 0; arm < 2; ++arm) {
+                    double ms = time_ms([&] { WAN(wan_gemm_bf16_ws(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
+                                                                   g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, arm ? ws.p : nullptr, wsb, nullptr)); }, 5, 1);
+                    printf("  gemm[%s] %-18s M=%d N=%d K=%d: %.3f ms  %.0f TFLOP/s\n", arm ? "persistent" : "per-tile  ", g.what, g.M, g.N, g.K, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
+                }
+        }
+    }
     if (mode == "sp") {           // the library-owned communicator from a C host: one rank, a pattern through both collectives
         unsigned char uid[WAN_SP_UNIQUE_ID_BYTES];
         WAN(wan_sp_unique_id(uid));

@@ -1,0 +1,84 @@
+// Probe: what the matrix pipes sustain CHIP-WIDE (256 CUs x 4 waves, ~ms-long launches, i.e. at the power limit) for the two bf16
+// MFMA shapes a 128 x 128 wave tile can be built from, on random and on zero operands, alone and beside the LDS fragment reads a
+// GEMM main loop issues (one ds_read_b128 per 2 MFMAs of 32x32x16 / per 4 of 16x16x32).  HIP events; TFLOP/s = issued MFMA FLOPs / time.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int SHAPE, int LDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k(const u32x4* src, float* out, int iters) {
+    __shared__ u32x4 sm[4096];                               // 64 KiB of operand data
+    for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = src[i];
+    __syncthreads();
+    u32x4 a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = sm[(threadIdx.x * 8 + i) & 4095]; b[i] = sm[(threadIdx.x * 8 + i + 1024) & 4095]; }
+    const u32x4* lp = sm + (threadIdx.x & 63);
+    if constexpr (SHAPE == 32) {
+        f32x16 acc[16];
+        for (int i = 0; i < 16; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i * 4 + j]) : "v"(a[i]), "v"(b[j]));
+                    if (LDS && ((i * 4 + j) & 1) == 0) { const int f = (i * 4 + j) / 2; if (f < 4) a[4 + f] = lp[(f * 64 + it * 7) & 4032]; else b[f] = lp[(f * 64 + it * 5) & 4032]; }
+                }
+            if (LDS) for (int f = 0; f < 4; ++f) { a[f] = a[4 + f]; }
+        }
+        float s = 0; for (int i = 0; i < 16; ++i) s += acc[i][0];
+        out[blockIdx.x * 256 + threadIdx.x] = s;
+    } else {
+        f32x4 acc[64];
+        for (int i = 0; i < 64; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i * 8 + j]) : "v"(a[i]), "v"(b[j]));
+                    if (LDS && ((i * 8 + j) & 3) == 0) { const int f = (i * 8 + j) / 4; if (f < 8) a[f] = lp[(f * 64 + it * 7) & 4032]; else b[f - 8] = lp[(f * 64 + it * 5) & 4032]; }
+                }
+        }
+        float s = 0; for (int i = 0; i < 64; ++i) s += acc[i][0];
+        out[blockIdx.x * 256 + threadIdx.x] = s;
+    }
+}
+
+template <int SHAPE, int LDS> void run(const char* name, const u32x4* src, float* out) {
+    const int iters = SHAPE == 32 ? 40000 : 10000;           // 640 000 MFMAs of either shape's flop count ratio 2:1 -> equal FLOPs
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<SHAPE, LDS>), dim3(256), dim3(256), 0, 0, src, out, iters / 10);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<SHAPE, LDS>), dim3(256), dim3(256), 0, 0, src, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 256.0 * 4 * iters * (SHAPE == 32 ? 16 * 32.0 * 32 * 16 * 2 : 64 * 16.0 * 16 * 32 * 2);
+        printf("%-58s %8.3f ms  %7.0f TFLOP/s\n", name, ms, fl / ms / 1e9);
+    }
+}
+int main() {
+    std::vector<unsigned> h(4096 * 4);
+    u32x4* src; float* out; hipMalloc(&src, 65536); hipMalloc(&out, 256 * 256 * 4);
+    for (int pass = 0; pass < 2; ++pass) {
+        srand(1);
+        for (auto& x : h) {                                   // two bf16 values ~ U(-1, 1) per word, or zeros
+            auto bf = [] { float f = (rand() / (float)RAND_MAX) * 2 - 1; unsigned u; __builtin_memcpy(&u, &f, 4); return u >> 16; };
+            x = pass == 0 ? (bf() | (bf() << 16)) : 0u;
+        }
+        hipMemcpy(src, h.data(), 65536, hipMemcpyHostToDevice);
+        const char* d = pass == 0 ? "random" : "zeros ";
+        char nm[128];
+        snprintf(nm, sizeof nm, "32x32x16, %s operands, MFMA only", d); run<32, 0>(nm, src, out);
+        snprintf(nm, sizeof nm, "16x16x32, %s operands, MFMA only", d); run<16, 0>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s operands, + ds_read_b128 per 2 MFMA", d); run<32, 1>(nm, src, out);
+        snprintf(nm, sizeof nm, "16x16x32, %s operands, + ds_read_b128 per 4 MFMA", d); run<16, 1>(nm, src, out);
+    }
+    return 0;
+}

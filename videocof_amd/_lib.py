@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
@@ -24,7 +24,7 @@ ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax refe
                       5: "attn_fwd_f8_kernel (4-wave, QK^T and P.V on the fp8 matrix pipe, checked max-free softmax) + "
                          "attn_fwd_w4_kernel<0,false,1,true,true> (fp8-QK^T lazy-reference fix-up of flagged workgroups)"}
 ATTN_VARIANT_XCD_PINNED, ATTN_VARIANT_SPLIT_TAIL = 16, 32
-GEMM_VARIANT_KERNELS = {0: "gemm_bf16_kernel", 1: "gemm256_kernel", 2: "gemm_w4_kernel"}      # wan_gemm_plan (WAN_GEMM_VARIANT_*)
+GEMM_VARIANT_KERNELS = {0: "gemm_bf16_kernel", 1: "gemm256_kernel", 2: "gemm_w4_kernel", 3: "gemm_pk_kernel"}      # wan_gemm_plan / wan_gemm_ws_plan (WAN_GEMM_VARIANT_*)
 
 
 def attn_variant_name(code: int) -> str:
@@ -139,6 +139,12 @@ SIGNATURES = {
     "wan_sp_destroy": (c_int, [c_void_p]),
     "wan_attention_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "wan_gemm_plan": (c_int, [c_int, c_int, c_int]),
+    "wan_gemm_ws_plan": (c_int, [c_int, c_int, c_int]),
+    "wan_gemm_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "wan_gemm_pk_grid": (c_int, [c_int, c_int]),
+    "wan_gemm_pk_segment": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "wan_gemm_bf16_ws": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                 c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "wan_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "wan_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_void_p]),

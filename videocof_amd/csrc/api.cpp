@@ -64,6 +64,10 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"conv_head", "WAN_CONV_HEAD", 1},          // causal 3x3x3 convs with <= 4 output channels on the direct (vector-ALU) kernel (0 = the gather kernel)
     {"gemm_exp", "WAN_GEMM_EXP", 0},            // TIMING-ONLY experiment of the 4-wave GEMM: bit 0 / 1 = skip the W / A tile DMA of the main loop (results are garbage)
     {"gemm_ring", "WAN_GEMM_RING", 0},          // `make EXPERIMENTS=1` builds only: 4-wave GEMM over a four-stage ring of 32-k tiles (measured 5-9 % slower than two 64-k stages)
+    {"gemm_pk", "WAN_GEMM_PK", 1},              // persistent stream-K form of the 4-wave 256^2 GEMM for callers that bring a workspace: 0 never, 1 where the 4-wave kernel would run, 2 whenever K % 128 == 0
+    {"gemm_pk_workers", "WAN_GEMM_PK_WORKERS", 0},      // its grid (0 = one workgroup per CU); developer A/B
+    {"gemm_pk_min_units", "WAN_GEMM_PK_MIN_UNITS", 0},  // smallest stream-K range in units of two K tiles (0 = a quarter of the tile's K range)
+    {"gemm_pk_order", "WAN_GEMM_PK_ORDER", 0},          // 1 = stream-K ranges BEFORE the whole-tile rounds (developer A/B)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

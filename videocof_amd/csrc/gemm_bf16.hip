@@ -21,6 +21,11 @@
 
 #include "common.hpp"
 
+// gemm_bf16_pk.hip: the persistent stream-K form of the 4-wave 256 x 256 kernel (callers that bring a workspace)
+wan_status_t wan_gemm_bf16_pk(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                              void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                              const float* gate, int64_t rows_per_batch, void* workspace, hipStream_t s);
+int64_t wan_gemm_pk_workspace_bytes(int M, int N);
 // gemm_bf16_256.hip: the 256 x 256 phased kernel used for large shapes
 wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                void* out, int64_t ldo, int M, int N, int K, int epilogue,
@@ -271,6 +276,45 @@ extern "C" int wan_gemm_plan(int M, int N, int K) {
     const bool big = M >= 1024 && N >= 256 && 2 * tiles256 > wan_cu_count();
     if (!(variant == 2 || (variant == 0 && big))) return WAN_GEMM_VARIANT_128;
     return wan_gemm256_uses_w4(K) ? WAN_GEMM_VARIANT_256_W4 : WAN_GEMM_VARIANT_256_W8;
+}
+
+// The persistent stream-K form (gemm_bf16_pk.hip) takes a product when the caller brought a workspace and the 4-wave 256^2
+// kernel would have run it (gemm_pk = 1, default); gemm_pk = 2: whenever its shape rules allow (K % 128 == 0, at least one 256^2
+// tile each way); 0: never.
+extern "C" int wan_gemm_ws_plan(int M, int N, int K) {
+    const int pk = wan_tune(WAN_TUNE_GEMM_PK);
+    const int base = wan_gemm_plan(M, N, K);
+    if (pk == 1 && base == WAN_GEMM_VARIANT_256_W4) return WAN_GEMM_VARIANT_256_PK;
+    if (pk == 2 && K % 128 == 0 && M >= 256 && N >= 256) return WAN_GEMM_VARIANT_256_PK;
+    return base;
+}
+
+extern "C" int64_t wan_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return wan_gemm_ws_plan(M, N, K) == WAN_GEMM_VARIANT_256_PK ? wan_gemm_pk_workspace_bytes(M, N) : 0;
+}
+
+extern "C" wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                         void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                                         const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
+    if (workspace == nullptr || M <= 0 || N <= 0 || K <= 0 || wan_gemm_ws_plan(M, N, K) != WAN_GEMM_VARIANT_256_PK)
+        return wan_gemm_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, stream);
+    WAN_REQUIRE(A && W && out, WAN_ERR_INVALID, "wan_gemm_bf16_ws: null tensor");
+    WAN_REQUIRE(N % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_bf16_ws: N=%d must be a multiple of 4", N);
+    WAN_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, WAN_ERR_INVALID,
+                "wan_gemm_bf16_ws: lda=%lld ldw=%lld must be multiples of 8 and >= K", (long long)lda, (long long)ldw);
+    if (epilogue == WAN_EPI_BF16_T)
+        WAN_REQUIRE(ldo >= M && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_bf16_ws: transposed ldo=%lld < M=%d or not a multiple of 4", (long long)ldo, M);
+    else
+        WAN_REQUIRE(ldo >= N && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_bf16_ws: ldo=%lld < N=%d or not a multiple of 4", (long long)ldo, N);
+    WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
+                "wan_gemm_bf16_ws: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
+    WAN_REQUIRE(workspace_bytes >= wan_gemm_pk_workspace_bytes(M, N), WAN_ERR_INVALID,
+                "wan_gemm_bf16_ws: workspace of %lld bytes, wan_gemm_workspace_bytes(%d, %d, %d) = %lld", (long long)workspace_bytes, M, N, K,
+                (long long)wan_gemm_pk_workspace_bytes(M, N));
+    WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_gemm_bf16_ws: workspace must be 16-byte aligned");
+    return wan_gemm_bf16_pk(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, workspace, (hipStream_t)stream);
 }
 
 extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

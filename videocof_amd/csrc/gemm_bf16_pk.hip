@@ -1,0 +1,630 @@
+// Persistent stream-K form of the 4-wave 256 x 256 x 64 bf16 GEMM (round 4).
+//
+// Same wave tiles, MFMA order, LDS image, staging and epilogues as gemm_w4_kernel (gemm_bf16_256.hip); what changes is who
+// walks the output tiles.  There, one workgroup per tile: every tile pays its own pipeline fill (K tile 0 requested, waited for,
+// published) and its own ramp-down, a launch is ceil(tiles / CUs) rounds of identical length whatever the remainder, and the
+// workgroups of a round reach their (HBM-bound) epilogues together.  Here ONE workgroup per CU stays resident and consumes a
+// sequence of SEGMENTS -- (tile, K range) pairs -- as one continuous stream of K tiles:
+//
+//   * the DMA pipeline never drains: the last K tiles of a segment request the first K tiles of the next one (other A / W panel,
+//     same LDS ring), which land under the epilogue;
+//   * work is cut per XCD (worker w = blockIdx: XCD w % 8, lane c = w / 8 of W = grid / 8): each XCD owns a contiguous slab of the
+//     XCD-rasterised tile sequence (GM x all-N groups, as before); lane c takes tiles c, c + W, c + 2W, ... of the slab whole
+//     ("data-parallel" rounds) and the remainder S = slab mod W tiles are cut STREAM-K fashion: their S * K/128 units (a unit =
+//     two K tiles, so that every segment starts on LDS buffer 0) are dealt to the lanes in W_sk equal contiguous ranges.  A range
+//     covers the tail of one tile and/or the head of the next; every worker does the same amount of work and there is no tail round
+//     (5260 tiles on 256 CUs: 20.55 rounds instead of 21; the 8-way Ulysses shard's 660 tiles: 2.58 instead of 3);
+//   * a partial segment stores its fp32 accumulators to the workspace (register-major, 16 B per lane and instruction: fully
+//     coalesced), releases them at agent scope and takes a ticket on the tile's arrival counter; the LAST arriver acquires, adds
+//     the pieces IN K ORDER (its own from registers) -- so the result does not depend on who arrived last: bitwise reproducible --
+//     and runs the normal epilogue.  No workgroup ever waits for another one (no spin loops: nothing to dead-lock, whatever the
+//     dispatch order or residency), and a full tile never touches the workspace.
+//
+// Contract differences to wan_gemm_bf16: the caller passes a workspace (wan_gemm_workspace_bytes) that no other stream uses
+// concurrently; its first 4 KiB (arrival counters) are zeroed by a memset node ahead of the launch.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kOperandBytes = BM * BK * 2;     // 32 KiB
+constexpr int kBufBytes = 2 * kOperandBytes;   // A + W: 64 KiB
+constexpr int kLdsBytes = 2 * kBufBytes;       // 128 KiB
+constexpr int kLdsFlag = kLdsBytes;            // three ints behind the ring: the arrival ticket and the tile tickets, broadcast to the workgroup
+constexpr int kCounterBytes = 4096;            // arrival counters (one int per stream-K tile) at the head of the workspace
+constexpr int64_t kSlotBytes = (int64_t)BM * BN * 4;
+
+struct PkArgs {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    const float* bias;
+    void* out; int64_t ldo;
+    const float* gate; int64_t rows_per_batch;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int gm;               // M tiles per rasterisation group
+    int nworkers;         // grid size (multiple of 8)
+    int min_units;        // smallest stream-K range worth a worker (units of two K tiles)
+    int dynamic;          // whole tiles by ticket from the per-XCD counters (1) or in lockstep order (0: developer A/B)
+    int* counters;        // workspace head: [0, nworkers) arrival counters of the split tiles, [512 + 16 x] the ticket counter of XCD x
+    char* slots;          // workspace + kCounterBytes: 2 slots of 256 KiB per worker
+};
+
+// One worker's view of its XCD slab: pure integer functions of (problem, grid, blockIdx) -- the host computes nothing per tile.
+struct Slab {
+    int start, n;         // first tile (in the XCD-rasterised sequence) and tile count of this XCD's slab
+    int W, c, x;          // lanes per XCD, my lane, my XCD
+    int rounds;           // whole-tile rounds
+    int S, n2;            // stream-K tiles of the slab, units (two K tiles) per tile
+    int U, Wsk;           // stream-K units, lanes that take a range
+    int nk;
+};
+// (j * U and u * Wsk stay far below 2^31: U <= lanes * K/128, lanes <= 128)
+__host__ __device__ __forceinline__ int range_begin(const Slab& s, int j) { return (int)((unsigned)(j * s.U) / (unsigned)s.Wsk); }
+__host__ __device__ __forceinline__ int find_range(const Slab& s, int u) {       // the range that contains unit u
+    int p = (int)((unsigned)(u * s.Wsk) / (unsigned)s.U);
+    while (p + 1 < s.Wsk && range_begin(s, p + 1) <= u) ++p;
+    while (p > 0 && range_begin(s, p) > u) --p;
+    return p;
+}
+
+struct Seg {
+    int valid;
+    int tm, tn;
+    int kb, ke;           // K tiles [kb, ke), both even
+    int partial;          // 0: the whole K range of the tile (direct epilogue); 1: a piece
+    int slot, cnt;        // partial: my workspace slot, the tile's arrival counter
+    int j_lo, j_hi, me;   // partial: lanes holding the tile's pieces in K order, and mine
+    int tau;              // partial: stream-K tile index inside the slab
+};
+
+__host__ __device__ __forceinline__ void tile_of(const PkArgs& g, int t, int& tm, int& tn) {
+    const int per_group = g.gm * g.tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * g.gm;
+    const int gm = min(g.gm, g.tiles_m - first_m);
+    const int in = t - grp * per_group;
+    tm = first_m + in % gm;
+    tn = in / gm;
+}
+
+__host__ __device__ __forceinline__ Slab make_slab(const PkArgs& g, int worker) {
+    Slab s;
+    const int nt = g.tiles_m * g.tiles_n;
+    s.x = worker & 7; s.c = worker >> 3; s.W = g.nworkers >> 3;
+    const int q = nt >> 3, r = nt & 7;
+    s.start = s.x < r ? s.x * (q + 1) : r * (q + 1) + (s.x - r) * q;
+    s.n = q + (s.x < r ? 1 : 0);
+    s.nk = g.K / BK;
+    s.n2 = s.nk >> 1;
+    s.rounds = s.n / s.W;
+    s.S = s.n - s.rounds * s.W;
+    s.U = s.S * s.n2;
+    s.Wsk = s.U > 0 ? max(1, min(s.W, s.U / max(1, g.min_units))) : 0;
+    return s;
+}
+
+__host__ __device__ __forceinline__ Seg no_seg(const Slab& s) {
+    Seg e;
+    e.valid = 0; e.tm = e.tn = 0; e.kb = 0; e.ke = s.nk; e.partial = 0; e.slot = e.cnt = 0; e.j_lo = e.j_hi = e.me = 0; e.tau = 0;
+    return e;
+}
+// whole tile `ticket` (0 .. rounds * W - 1) of the slab's data-parallel part
+__host__ __device__ __forceinline__ Seg dp_seg(const PkArgs& g, const Slab& s, int ticket) {
+    Seg e = no_seg(s);
+    if (ticket < 0 || ticket >= s.rounds * s.W) return e;
+    e.valid = 1;
+    tile_of(g, s.start + ticket, e.tm, e.tn);
+    return e;
+}
+// segment k (0, 1, ...) of my stream-K range; valid = 0 past its end (or when my lane has no range)
+__host__ __device__ __forceinline__ Seg sk_seg(const PkArgs& g, const Slab& s, int k) {
+    Seg e = no_seg(s);
+    if (s.c >= s.Wsk) return e;
+    const int u0 = range_begin(s, s.c), u1 = range_begin(s, s.c + 1);
+    if (u1 <= u0) return e;
+    const int tau0 = u0 / s.n2, nseg = (u1 - 1) / s.n2 - tau0 + 1;
+    if (k >= nseg) return e;
+    const int tau = tau0 + k;
+    const int b = max(u0, tau * s.n2), en = min(u1, (tau + 1) * s.n2);
+    e.valid = 1;
+    tile_of(g, s.start + s.rounds * s.W + tau, e.tm, e.tn);
+    e.kb = 2 * (b - tau * s.n2); e.ke = 2 * (en - tau * s.n2);
+    e.partial = !(e.kb == 0 && e.ke == s.nk);
+    e.tau = tau;
+    if (e.partial) {
+        e.slot = 2 * (s.x * s.W + s.c) + (k == 0 ? 0 : 1);
+        e.cnt = s.x * s.W + tau;
+        e.j_lo = find_range(s, tau * s.n2);
+        e.j_hi = find_range(s, (tau + 1) * s.n2 - 1);
+        e.me = s.c;
+    }
+    return e;
+}
+// The schedule when every lane draws its tickets in lockstep (lane c gets c, c + W, c + 2W, ...): what wan_gemm_pk_segment reports.
+// On the device the whole-tile tickets are drawn from a per-XCD counter (whoever is free takes the next tile of the slab, so the
+// tiles in flight on an XCD stay neighbours); the stream-K ranges are fixed per lane.
+__host__ __device__ __forceinline__ Seg get_seg(const PkArgs& g, const Slab& s, int i) {
+    return i < s.rounds ? dp_seg(g, s, i * s.W + s.c) : sk_seg(g, s, i - s.rounds);
+}
+
+__device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// The matrix instruction is v_mfma_f32_16x16x32_bf16 (a 128 x 128 wave tile = 8 x 8 tiles, 64 accumulators of 4 registers), not the
+// 32x32x16 form of gemm_w4_kernel: on random operands, with every CU busy, the chip sustains 1.99-2.05 PFLOP/s of bare 16x16x32 MFMAs
+// against 1.59-1.78 of 32x32x16 (2.45 either way on zeros: tools/probe/mfma_power.hip, profiles/r04/mfma_power.log) -- twice the K depth
+// per accumulator update is half the accumulator traffic, and the power that saves comes back as clock.
+template <int EPI>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(PkArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const Slab slab = make_slab(g, (int)blockIdx.x);
+
+    // ---- LDS-DMA lane offsets (see gemm_w4_kernel): piece j of wave w covers rows 64 w + 8 j + lane / 8 of an operand tile
+    int a_voff[2], w_voff[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = wid * 64 + p * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        a_voff[p] = (int)(((int64_t)row * g.lda + c * 8) * 2);
+        w_voff[p] = (int)(((int64_t)row * g.ldw + c * 8) * 2);
+    }
+    // ---- fragment reads: 16 rows x 32 k per fragment; lane = (row l15, k group kg); logical chunk 4 h + kg of a 128-B row (h = k half)
+    const int swz = (lane >> 1) & 7;
+    int koff[2][2];                          // [LDS buffer][k half]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) koff[b][h] = b * kBufBytes + l15 * 128 + (((4 * h + kg) ^ swz) << 4);
+    const int a_base = wr * 128 * 128, w_base = kOperandBytes + wc * 128 * 128;
+
+    // ---- the stream: the current segment and the one behind it.  Whole tiles come by ticket from the XCD's counter (one returning
+    // atomic per tile, drawn by thread 0 a whole segment before the ticket is needed and handed to the workgroup through LDS at the
+    // segment switch); once the tickets run out a lane walks the segments of its stream-K range.
+    int* const ticket_counter = g.counters + 512 + 16 * slab.x;
+    volatile int* const lds_ticket = reinterpret_cast<volatile int*>(smem + kLdsFlag);
+    bool dp_done = false;
+    int sk_k = 0, lock_i = 0;
+    auto draw = [&]() -> int {                 // thread 0 only
+        return g.dynamic ? __hip_atomic_fetch_add(ticket_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    };
+    auto produce = [&](int ticket) {           // the next segment of my sequence, given the ticket drawn for it (uniform)
+        if (!dp_done) {
+            const Seg e = g.dynamic ? dp_seg(g, slab, ticket) : (lock_i < slab.rounds ? dp_seg(g, slab, lock_i * slab.W + slab.c) : no_seg(slab));
+            ++lock_i;
+            if (e.valid) return e;
+            dp_done = true;
+        }
+        return sk_seg(g, slab, sk_k++);
+    };
+    // every field of a segment is wave-uniform by construction; say so (the tickets travel through LDS, which the compiler's
+    // uniformity analysis cannot see through -- without this the descriptors end up in VGPRs and every DMA in a waterfall loop)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uniform = [&](Seg e) {
+        e.valid = uni(e.valid); e.tm = uni(e.tm); e.tn = uni(e.tn); e.kb = uni(e.kb); e.ke = uni(e.ke); e.partial = uni(e.partial);
+        e.slot = uni(e.slot); e.cnt = uni(e.cnt); e.j_lo = uni(e.j_lo); e.j_hi = uni(e.j_hi); e.me = uni(e.me); e.tau = uni(e.tau);
+        return e;
+    };
+    int pending = 0;                           // thread 0: the ticket drawn for the segment after `nxt`
+    if (tid == 0) {
+        lds_ticket[1] = draw(); lds_ticket[2] = draw();
+        pending = draw();
+    }
+    __syncthreads();
+    const int t0 = __builtin_amdgcn_readfirstlane(lds_ticket[1]), t1 = __builtin_amdgcn_readfirstlane(lds_ticket[2]);
+    Seg cur = uniform(produce(t0));
+    if (!cur.valid) return;
+    Seg nxt = uniform(produce(t1));
+
+    // A panel = the rows of one output tile in A and in W: origin pointers and the byte distance from the origin (row m0 / n0,
+    // column 0) to the end of the last valid row (the descriptors' range check zero-fills rows past M / N)
+    struct Panel { const char* a; const char* w; int ab, wb; };
+    auto panel = [&](const Seg& e) {
+        Panel p;
+        const int m0 = e.tm * BM, n0 = e.tn * BN;
+        p.a = (const char*)(g.A + (int64_t)m0 * g.lda);
+        p.w = (const char*)(g.W + (int64_t)n0 * g.ldw);
+        p.ab = (int)min(((int64_t)(min(g.M - m0, BM) - 1) * g.lda + g.K) * 2, (int64_t)0x7fffffff);
+        p.wb = (int)min(((int64_t)(min(g.N - n0, BN) - 1) * g.ldw + g.K) * 2, (int64_t)0x7fffffff);
+        return p;
+    };
+    Panel pc = panel(cur), pn = panel(nxt);
+    // The two request streams.  A descriptor = (address of the K tile inside the panel, bytes left from there); it advances by one K
+    // tile (128 B) per request and jumps to the next segment's panel when the position passes the end of the current segment --
+    // a handful of SALU instructions, issued in MFMA shadows.
+    struct Stream { const char* base; int left; };
+    auto stream_at = [&](int op, int pos) {                  // pos: a K tile index of the current segment
+        Stream st;
+        st.base = (op ? pc.w : pc.a) + (int64_t)pos * (BK * 2);
+        st.left = (op ? pc.wb : pc.ab) - pos * (BK * 2);
+        return st;
+    };
+    // the request after this one: the first K tile of the next segment (`jump`), or 128 bytes further in the same panel
+    auto advance = [&](Stream& st, int op, bool jump) {
+        const char* nb = (op ? pn.w : pn.a) + (int64_t)nxt.kb * (BK * 2);
+        const int nl = nxt.valid ? (op ? pn.wb : pn.ab) - nxt.kb * (BK * 2) : 0;
+        st.base = jump ? nb : st.base + BK * 2;
+        st.left = jump ? nl : st.left - BK * 2;
+    };
+    auto rsrc_of = [&](const Stream& st) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)st.base, 0, st.left, 0x00020000);
+    };
+    auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
+            operand ? w_voff[j & 1] : a_voff[j & 1], (int)((j >> 1) * 16 * ld * 2), 0, 0);
+    };
+
+    f32x4 acc[8][8];                         // [m tile][n tile]
+    u32x4 af[2][8], wf[2][8];                // [k half][tile]: the fragments of a whole K tile live in registers
+
+#define GP_SB() __builtin_amdgcn_sched_barrier(0)
+// m tiles 0..5 (48 accumulators, 192 registers) are pinned to AGPRs, m tiles 6, 7 to VGPRs: with all 256 AGPRs claimed by "+a"
+// operands hipcc's allocator has no slack left and shuffles tiles through scratch (gemm_w4_kernel)
+#define GP_MFMA_A(ACC, X, Y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(X), "v"(Y))
+#define GP_MFMA_V(ACC, X, Y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(X), "v"(Y))
+#define GP_MFMA(ACC, X, Y) do { if (i < 6) GP_MFMA_A(ACC, X, Y); else GP_MFMA_V(ACC, X, Y); } while (0)
+    Stream sa, sq;
+    // fragment f of a k half in fetch order = first-use order of the MFMA sequence below: A 0, W 0..7, A 1..7
+    auto fetch = [&](int h, int f, int buf) __attribute__((always_inline)) {
+        if (f == 0) af[h][0] = lds16(smem + a_base + koff[buf][h]);
+        else if (f <= 8) wf[h][f - 1] = lds16(smem + w_base + (f - 1) * 16 * 128 + koff[buf][h]);
+        else af[h][f - 8] = lds16(smem + a_base + (f - 8) * 16 * 128 + koff[buf][h]);
+    };
+    // One k half H (32 of the K tile's 64) of the K tile in LDS buffer b = 64 MFMAs.  FETCH_ selects what the gaps carry:
+    //   0: k half 0 -- the 16 fragments of k half 1 (buffer b), one per 4 MFMAs, and the 8 W pieces of stream position kt + 1 -> buffer 1 - b
+    //   1: k half 1 -- slots 0..31 move the request streams on; `mid` (the tile's barrier) runs before slot 32; slots 32..63 carry the
+    //      16 fragments of k half 0 of the NEXT position (buffer 1 - b) and the 8 A pieces of position kt + 2 -> buffer b
+    auto khalf = [&](auto H_, int b, bool jump, auto&& mid) __attribute__((always_inline)) {
+        constexpr int H = decltype(H_)::value;
+        __amdgpu_buffer_rsrc_t r;
+        if constexpr (H == 0) r = rsrc_of(sq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int slot = i * 8 + j;
+                if constexpr (H == 1) {
+                    if (slot == 32) { mid(); r = rsrc_of(sa); }
+                }
+                if constexpr (kTransposed) GP_MFMA(acc[i][j], af[H][i], wf[H][j]);
+                else GP_MFMA(acc[i][j], wf[H][j], af[H][i]);
+                GP_SB();
+                if constexpr (H == 0) {
+                    if (slot % 4 == 0) fetch(1, slot / 4, b);
+                    else if (slot % 8 == 2) stage_piece(r, 1 - b, 1, slot / 8, g.ldw);
+                } else {
+                    if (slot == 1) advance(sa, 0, jump);         // -> position kt + 2: requested in the second half of this k half
+                    else if (slot == 3) advance(sq, 1, jump);    // -> position kt + 2: requested in k half 0 of the next K tile
+                    else if (slot >= 32 && slot % 2 == 0) fetch(0, (slot - 32) / 2, 1 - b);
+                    else if (slot >= 32 && slot % 4 == 1) stage_piece(r, b, 0, (slot - 32) / 4, g.lda);
+                }
+                GP_SB();
+            }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    // K tile kt (stream position) in buffer b: W of position kt+1 -> buffer 1-b during k half 0, A of position kt+2 -> buffer b in the
+    // last quarter (right behind the barrier that frees it); both are waited for at the barrier of position kt+1.
+    auto ktile = [&](int kt, int b) __attribute__((always_inline)) {
+        const bool jump = kt + 2 == cur.ke;      // position kt + 2 is the first K tile of the next segment
+        khalf(I0{}, b, jump, [] {});
+        khalf(I1{}, b, jump, [&] {
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my pieces of position kt+1 have landed ...
+            __builtin_amdgcn_s_barrier();            // ... everybody's have, and every wave has read the last fragment of position kt
+            GP_SB();
+        });
+    };
+
+    // ---- stream prologue: position cur.kb -> buffer 0 (waited for), the A half of position cur.kb + 1 -> buffer 1 (in flight)
+    {
+        sa = stream_at(0, cur.kb); sq = stream_at(1, cur.kb);
+        const __amdgpu_buffer_rsrc_t ra = rsrc_of(sa), rw = rsrc_of(sq);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { stage_piece(ra, 0, 0, j, g.lda); stage_piece(rw, 0, 1, j, g.ldw); }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        sa = stream_at(0, cur.kb + 1); sq = stream_at(1, cur.kb + 1);       // a segment has at least two K tiles
+        const __amdgpu_buffer_rsrc_t ra1 = rsrc_of(sa);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage_piece(ra1, 1, 0, j, g.lda);
+    }
+
+    for (;;) {
+        // ---- segment start: K tile cur.kb sits in buffer 0 (published), the A half of cur.kb + 1 is in flight
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 16; ++f) fetch(0, f, 0);
+        for (int kt = cur.kb; kt < cur.ke; kt += 2) {
+            ktile(kt, 0);
+            ktile(kt + 1, 1);
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads below
+
+        // ---- partial segment: publish my piece, take a ticket; only the last arriver goes on to the epilogue
+        bool reduce = false;
+        if (cur.partial) {
+            // write-through (sc1) stores: the piece goes to memory past the XCD's L2, so publishing it needs no L2 write-back (a release
+            // fence would flush everybody's dirty lines of this XCD: CDNA4 guide, "publish-large") -- drain my stores, then the ticket
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.slots + (int64_t)cur.slot * kSlotBytes), 0, (int)kSlotBytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, ((i * 8 + j) * kThreads + tid) * 16, 0, /*sc1*/ 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(g.counters + cur.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lds_ticket[0] = old;
+            }
+            __syncthreads();
+            const int old = lds_ticket[0];
+            reduce = __builtin_amdgcn_readfirstlane(old) == cur.j_hi - cur.j_lo;
+            if (reduce) {
+                if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+            }
+        }
+
+        if (!cur.partial || reduce) {
+            const int m0 = cur.tm * BM, n0 = cur.tn * BN;
+            // last arriver of a split tile: the pieces added IN K ORDER (mine from registers), tile by tile, back into my
+            // accumulators -- the epilogue below is then the same code for whole and for split tiles
+            if (reduce) {
+                // 16 tiles (64 registers) at a time: the 16 loads of a piece's chunk are in flight together -- one memory round trip per
+                // (chunk, piece) instead of one per tile (64 x pieces dependent round trips cost more than the K loop of the piece itself)
+                auto reduce_chunk = [&](auto CH_) {
+                    constexpr int CH = decltype(CH_)::value;
+                    f32x4 v[16];
+                    for (int p = cur.j_lo; p <= cur.j_hi; ++p) {
+                        f32x4 t[16];
+                        if (p == cur.me) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) t[k] = acc[(CH * 16 + k) >> 3][(CH * 16 + k) & 7];
+                        } else {
+                            // lane p's segment in this tile sits in its slot 0 when the tile is the first one of its range, else slot 1
+                            const int first_tau = range_begin(slab, p) / slab.n2;
+                            const f32x4* src = reinterpret_cast<const f32x4*>(
+                                g.slots + (int64_t)(2 * (slab.x * slab.W + p) + (first_tau == cur.tau ? 0 : 1)) * kSlotBytes);
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) t[k] = src[(CH * 16 + k) * kThreads + tid];
+                        }
+                        if (p == cur.j_lo) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) v[k] = t[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) v[k] += t[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[(CH * 16 + k) >> 3][(CH * 16 + k) & 7] = v[k];
+                };
+                reduce_chunk(std::integral_constant<int, 0>{}); reduce_chunk(std::integral_constant<int, 1>{});
+                reduce_chunk(std::integral_constant<int, 2>{}); reduce_chunk(std::integral_constant<int, 3>{});
+            }
+            const int l4 = kg * 4;
+            if constexpr (!kTransposed) {
+                // Swapped product (W fragment as A operand): lane (l15, kg) holds output row m = .. + l15 and, per tile, the 4 consecutive
+                // columns n = .. + 4 kg .. + 3.  A batch = one m tile x four n tiles (one row, four float4 per lane): bias, residual stream and
+                // gate rows of a batch are loaded back to back, one batch ahead of their use.  Out-of-range rows / columns read a clamped
+                // address and are not stored.  (The wave-uniform options -- bias? gate? -- select straight-line copies.)
+                auto epilogue_rows = [&](auto has_bias, auto has_gate) {
+                    constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_GATE = decltype(has_gate)::value;
+                    const int rpb = HAS_GATE ? (int)g.rows_per_batch : 1;
+                    struct Batch {
+                        float4 bq[4], xr[4], gq[4];
+                        int nn[4], mm;
+                        bool nok[4], mok;
+                    };
+                    auto load_batch = [&](int bi, Batch& B) {          // batch bi = m tile bi >> 1, n tiles 4 (bi & 1) .. + 3
+                        const int m = m0 + wr * 128 + (bi >> 1) * 16 + l15;
+                        B.mok = m < g.M;
+                        B.mm = B.mok ? m : g.M - 1;
+                        const int64_t brow = HAS_GATE ? (int64_t)(B.mm / rpb) * g.N : 0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int n = n0 + wc * 128 + ((bi & 1) * 4 + t) * 16 + l4;
+                            B.nok[t] = n < g.N;
+                            B.nn[t] = B.nok[t] ? n : 0;
+                            if constexpr (HAS_BIAS) B.bq[t] = *reinterpret_cast<const float4*>(g.bias + B.nn[t]);
+                            else B.bq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if constexpr (EPI == WAN_EPI_RESID_F32) {
+                                B.xr[t] = *reinterpret_cast<const float4*>((const float*)g.out + (int64_t)B.mm * g.ldo + B.nn[t]);
+                                if constexpr (HAS_GATE) B.gq[t] = *reinterpret_cast<const float4*>(g.gate + brow + B.nn[t]);
+                                else B.gq[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            }
+                        }
+                    };
+                    auto store_batch = [&](int bi, const Batch& B) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 a = acc[bi >> 1][(bi & 1) * 4 + q];
+                            f32x4 v = {a[0] + B.bq[q].x, a[1] + B.bq[q].y, a[2] + B.bq[q].z, a[3] + B.bq[q].w};
+                            if constexpr (EPI == WAN_EPI_GELU_BF16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
+                            }
+                            if (!(B.mok && B.nok[q])) continue;
+                            const int64_t off = (int64_t)B.mm * g.ldo + B.nn[q];
+                            if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
+                                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                                *reinterpret_cast<u32x2*>((bf16_t*)g.out + off) = o;
+                            } else if constexpr (EPI == WAN_EPI_F32) {
+                                *reinterpret_cast<float4*>((float*)g.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+                                *reinterpret_cast<float4*>((float*)g.out + off) =
+                                    make_float4(B.xr[q].x + v[0] * B.gq[q].x, B.xr[q].y + v[1] * B.gq[q].y, B.xr[q].z + v[2] * B.gq[q].z,
+                                                B.xr[q].w + v[3] * B.gq[q].w);
+                            }
+                        }
+                    };
+                    // two batches in flight: the loads of batch b + 1 are issued before batch b is combined and stored
+                    Batch B[2];
+                    load_batch(0, B[0]);
+#pragma unroll
+                    for (int bi = 0; bi < 16; ++bi) {
+                        if (bi + 1 < 16) load_batch(bi + 1, B[(bi + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_batch(bi, B[bi & 1]);
+                    }
+                };
+                if constexpr (EPI == WAN_EPI_RESID_F32) {
+                    if (g.bias) {
+                        if (g.gate) epilogue_rows(std::true_type{}, std::true_type{});
+                        else epilogue_rows(std::true_type{}, std::false_type{});
+                    } else {
+                        if (g.gate) epilogue_rows(std::false_type{}, std::true_type{});
+                        else epilogue_rows(std::false_type{}, std::false_type{});
+                    }
+                } else {         // the gate belongs to the residual epilogue only (wan_gemm_bf16_ws refuses it elsewhere)
+                    if (g.bias) epilogue_rows(std::true_type{}, std::false_type{});
+                    else epilogue_rows(std::false_type{}, std::false_type{});
+                }
+            } else {
+                // Transposed store: D = mfma(A fragment, W fragment): lane (l15, kg) holds output column n = .. + l15 and the 4 consecutive
+                // rows m = .. + 4 kg .. + 3 of every tile
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + wc * 128 + j * 16 + l15;
+                    const bool nok = n < g.N;
+                    const float bv = (g.bias && nok) ? g.bias[n] : 0.f;
+                    if (!nok) continue;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = m0 + wr * 128 + i * 16 + l4;
+                        if (m >= g.M) continue;
+                        const f32x4 a = acc[i][j];
+                        bf16_t* p = (bf16_t*)g.out + (int64_t)n * g.ldo + m;
+                        const float v0 = a[0] + bv, v1 = a[1] + bv, v2 = a[2] + bv, v3 = a[3] + bv;
+                        if (m + 3 < g.M) {
+                            u32x2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                            *reinterpret_cast<u32x2*>(p) = o;
+                        } else {
+                            const float vv[4] = {v0, v1, v2, v3};
+                            for (int r = 0; r < 4 && m + r < g.M; ++r) p[r] = (bf16_t)vv[r];
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- advance the stream
+        if (!nxt.valid) break;
+        cur = nxt; pc = pn;
+        if (!dp_done && g.dynamic) {           // hand the pending ticket round, draw the one after it
+            if (tid == 0) lds_ticket[1] = pending;
+            __syncthreads();
+            const int tk = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
+            __syncthreads();                   // everybody has read it before thread 0 may overwrite it at the next switch
+            nxt = uniform(produce(tk));
+            if (tid == 0) pending = draw();     // (a draw past the end is harmless; testing dp_done here makes hipcc treat the whole segment state as divergent)
+        } else {
+            nxt = uniform(produce(0));
+        }
+        pn = panel(nxt);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // zero-length requests past the last segment still write LDS: let them finish
+#undef GP_MFMA
+#undef GP_MFMA_A
+#undef GP_MFMA_V
+#undef GP_SB
+}
+
+template <int EPI>
+wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 64);
+        if (e != hipSuccess) {
+            wan_set_error("wan_gemm_bf16_ws: cannot reserve %d B of LDS: %s", kLdsBytes + 64, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
+    if (hipMemsetAsync(g.counters, 0, kCounterBytes, s) != hipSuccess) {
+        wan_set_error("wan_gemm_bf16_ws: cannot clear the arrival counters: %s", hipGetErrorString(hipGetLastError()));
+        return WAN_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((gemm_pk_kernel<EPI>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
+    WAN_CHECK_LAUNCH("wan_gemm_bf16_ws");
+    return WAN_OK;
+}
+
+}  // namespace
+
+// grid of the persistent form: one workgroup per CU, a multiple of 8 (one lane set per XCD), never more than the tile count / 1
+int wan_gemm_pk_workers(int M, int N) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int w = wan_cu_count() & ~7;
+    if (const int t = wan_tune(WAN_TUNE_GEMM_PK_WORKERS); t > 0) w = t & ~7;
+    (void)tiles;
+    return w < 8 ? 8 : w;
+}
+
+int64_t wan_gemm_pk_workspace_bytes(int M, int N) {
+    return kCounterBytes + (int64_t)wan_gemm_pk_workers(M, N) * 2 * kSlotBytes;
+}
+
+static void pk_plan_args(PkArgs& g, int M, int N, int K) {
+    g.M = M; g.N = N; g.K = K;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    g.gm = g.tiles_n >= 40 ? 2 : 3;
+    if (const int gm = wan_tune(WAN_TUNE_GEMM_GM); gm > 0) g.gm = gm;
+    g.nworkers = wan_gemm_pk_workers(M, N);
+    // smallest range worth a worker: a quarter of a tile's K range (a tile is then cut into at most ~5 pieces), at least one unit
+    g.min_units = (K / BK / 2 + 3) / 4;
+    if (const int mu = wan_tune(WAN_TUNE_GEMM_PK_MIN_UNITS); mu > 0) g.min_units = mu;
+    g.dynamic = wan_tune(WAN_TUNE_GEMM_PK_ORDER) != 1;
+}
+
+// Host arithmetic only: segment `index` of worker `worker` of the persistent GEMM's plan for this shape -- the SAME functions the
+// kernel evaluates (tests: every (tile, K tile) is covered exactly once, pieces and slots are consistent).
+// out[11] = tm, tn, kb, ke, partial, slot, counter, j_lo, j_hi, me, tau; returns 1 when the segment exists, 0 past the end.
+extern "C" int wan_gemm_pk_segment(int M, int N, int K, int worker, int index, int* out) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0 || worker < 0 || index < 0 || out == nullptr) return 0;
+    PkArgs g;
+    pk_plan_args(g, M, N, K);
+    if (worker >= g.nworkers) return 0;
+    const Slab slab = make_slab(g, worker);
+    const Seg e = get_seg(g, slab, index);
+    const int v[11] = {e.tm, e.tn, e.kb, e.ke, e.partial, e.slot, e.cnt, e.j_lo, e.j_hi, e.me, e.tau};
+    for (int i = 0; i < 11; ++i) out[i] = v[i];
+    return e.valid;
+}
+
+extern "C" int wan_gemm_pk_grid(int M, int N) { return wan_gemm_pk_workers(M, N); }
+
+// called by wan_gemm_bf16_ws (gemm_bf16.hip) for shapes the 4-wave 256^2 kernel takes; arguments already validated there
+wan_status_t wan_gemm_bf16_pk(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                              void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                              const float* gate, int64_t rows_per_batch, void* workspace, hipStream_t s) {
+    PkArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    pk_plan_args(g, M, N, K);
+    g.counters = (int*)workspace;
+    g.slots = (char*)workspace + kCounterBytes;
+    switch (epilogue) {
+        case WAN_EPI_BF16: return launch_pk<WAN_EPI_BF16>(g, s);
+        case WAN_EPI_GELU_BF16: return launch_pk<WAN_EPI_GELU_BF16>(g, s);
+        case WAN_EPI_F32: return launch_pk<WAN_EPI_F32>(g, s);
+        case WAN_EPI_RESID_F32: return launch_pk<WAN_EPI_RESID_F32>(g, s);
+        case WAN_EPI_BF16_T: return launch_pk<WAN_EPI_BF16_T>(g, s);
+        default: wan_set_error("wan_gemm_bf16_ws: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
+    }
+}

@@ -240,9 +240,34 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     if epilogue != EPI_BF16_T and tuple(out.shape) != (M, N):
         raise ValueError(f"gemm: out shape {tuple(out.shape)} != ({M},{N})")
     lib = _lib.load()
-    _lib.check(lib.wan_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
-                                 M, N, K, epilogue, _p(gate), int(rows_per_batch), _stream()), "wan_gemm_bf16")
+    ws = gemm_workspace(dev, M, N, K)
+    _lib.check(lib.wan_gemm_bf16_ws(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
+                                    M, N, K, epilogue, _p(gate), int(rows_per_batch), _p(ws), ws.numel() if ws is not None else 0,
+                                    _stream()), "wan_gemm_bf16_ws")
     return out
+
+
+_GEMM_WS = {}
+
+
+def gemm_workspace(dev: torch.device, M: int, N: int, K: int) -> Optional[torch.Tensor]:
+    """The caller-owned workspace of ``wan_gemm_bf16_ws`` (the persistent stream-K GEMM's partial tiles and arrival
+    counters): ONE buffer per device, grown to the largest request and then kept for the life of the process, so that its
+    address is stable under hipGraph capture.  The package issues all its GEMMs of a device on one stream (the Ulysses side
+    stream carries collectives only); a host that runs GEMMs of one device on several streams CONCURRENTLY must give each
+    stream its own workspace through the C entry point.  None when the shape does not use a workspace
+    (``wan_gemm_workspace_bytes`` == 0)."""
+    need = int(_lib.load().wan_gemm_workspace_bytes(M, N, K))
+    if need <= 0:
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the GEMM workspace would have to be (re)allocated during graph capture; run the shape eagerly once first")
+        ws = torch.zeros(need, device=dev, dtype=torch.uint8)
+        _GEMM_WS[key] = ws
+    return ws
 
 
 class AttentionWorkspace:
