@@ -384,6 +384,8 @@ typedef struct {
     int64_t ldvt;
     void* attn_ws_self; int64_t attn_ws_self_bytes;
     void* attn_ws_cross; int64_t attn_ws_cross_bytes;
+    void* gemm_ws; int64_t gemm_ws_bytes;      /* wan_gemm_bf16_ws workspace shared by the block's Linears (wan_gemm_workspace_bytes of the
+                                                  largest one; NULL = the one-workgroup-per-tile kernels) */
 } wan_block_workspace;
 
 wan_status_t wan_dit_block_forward(float* x, const float* emod, const void* ctx_k, const void* ctx_vt,

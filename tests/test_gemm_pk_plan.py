@@ -1,0 +1,70 @@
+"""The persistent stream-K GEMM's work decomposition (videocof_amd/csrc/gemm_bf16_pk.hip), checked on the HOST: the library exports the
+very functions its kernel evaluates (``wan_gemm_pk_segment``), so no GPU is needed to know that every (output tile, K tile) pair is
+computed exactly once, that the pieces of a split tile chain up in K order under the lanes the combiner will read them from, that no two
+pieces share a workspace slot, and that every worker gets the same amount of work."""
+import collections
+import ctypes
+
+import pytest
+
+from videocof_amd import _lib
+
+SHAPES = [(67080, 5120, 5120), (67080, 10240, 5120), (67080, 13824, 5120), (67080, 5120, 13824),      # the 14B Linears at L = 67 080
+          (8392, 5120, 5120), (8392, 10240, 5120), (8392, 13824, 5120), (8392, 5120, 13824),         # ... on an 8-way Ulysses shard
+          (16776, 5120, 5120), (1024, 512, 4096), (300, 300, 128), (2304, 1536, 8960), (2304, 8960, 1536), (75600 * 2, 5120, 5120)]
+
+
+def plan(lib, M, N, K):
+    G = lib.wan_gemm_pk_grid(M, N)
+    out = (ctypes.c_int * 11)()
+    segs = []
+    for w in range(G):
+        i = 0
+        while lib.wan_gemm_pk_segment(M, N, K, w, i, out):
+            segs.append((w, i) + tuple(out))
+            i += 1
+    return G, segs
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_every_k_tile_of_every_output_tile_is_computed_exactly_once(M, N, K):
+    lib = _lib.load()
+    G, segs = plan(lib, M, N, K)
+    assert G % 8 == 0 and G >= 8
+    nk, tiles_m, tiles_n = K // 64, (M + 255) // 256, (N + 255) // 256
+    cover, work, pieces, slots = collections.Counter(), collections.Counter(), collections.defaultdict(list), set()
+    for (w, i, tm, tn, kb, ke, partial, slot, cnt, jlo, jhi, me, tau) in segs:
+        assert 0 <= tm < tiles_m and 0 <= tn < tiles_n and 0 <= kb < ke <= nk
+        assert kb % 2 == 0 and ke % 2 == 0           # a segment starts on LDS buffer 0 and keeps two K tiles in flight
+        for k in range(kb, ke, 2):
+            cover[(tm, tn, k)] += 1
+        work[w] += ke - kb
+        assert bool(partial) == (not (kb == 0 and ke == nk))
+        if partial:
+            assert slot not in slots and slot // 2 == (w % 8) * (G // 8) + w // 8 and me == w // 8
+            slots.add(slot)
+            assert 0 <= cnt < 512                    # the arrival counters live below the ticket counters in the workspace head
+            pieces[(w % 8, cnt)].append((kb, ke, me, jlo, jhi, tm, tn))
+    assert len(cover) == tiles_m * tiles_n * nk // 2 and set(cover.values()) == {1}
+    for ps in pieces.values():
+        ps.sort()
+        assert ps[0][0] == 0 and ps[-1][1] == nk and all(a[1] == b[0] for a, b in zip(ps, ps[1:]))      # a K-ordered chain ...
+        assert len({(p[5], p[6]) for p in ps}) == 1                                                    # ... of ONE tile ...
+        assert [p[2] for p in ps] == list(range(ps[0][3], ps[0][4] + 1)) and len({(p[3], p[4]) for p in ps}) == 1   # ... under lanes j_lo..j_hi
+        assert len(ps) >= 2
+    if tiles_m * tiles_n * nk // 2 >= 4 * G:         # enough work to balance: no worker waits for a tail round
+        assert max(work.values()) - min(work.values()) <= max(2 * 24, nk // 2 + 2)
+    assert int(lib.wan_gemm_workspace_bytes(M, N, K)) in (0, 4096 + G * 2 * 256 * 256 * 4)
+
+
+def test_workspace_entry_falls_back_and_validates():
+    lib = _lib.load()
+    # no workspace, or a shape the persistent kernel does not take: wan_gemm_bf16's own validation answers
+    assert lib.wan_gemm_bf16_ws(None, 64, None, 64, None, None, 64, 4, 64, 64, 0, None, 0, None, 0, None) == _lib.WAN_ERR_INVALID
+    assert lib.wan_gemm_ws_plan(515, 64, 1024) == lib.wan_gemm_plan(515, 64, 1024)
+    assert lib.wan_gemm_workspace_bytes(515, 64, 1024) == 0
+    assert lib.wan_gemm_ws_plan(67080, 5120, 5120) == 3 and _lib.GEMM_VARIANT_KERNELS[3] == "gemm_pk_kernel"
+    assert lib.wan_gemm_ws_plan(67080, 5120, 1536) == lib.wan_gemm_plan(67080, 5120, 1536) == 1          # shallow K stays on the 8-wave kernel
+    need = int(lib.wan_gemm_workspace_bytes(67080, 5120, 5120))
+    st = lib.wan_gemm_bf16_ws(16, 5120, 16, 5120, None, 16, 5120, 67080, 5120, 5120, 0, None, 0, 16, need - 1, None)
+    assert st == _lib.WAN_ERR_INVALID and b"workspace" in lib.wan_last_error()

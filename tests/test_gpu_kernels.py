@@ -645,6 +645,49 @@ def test_gemm_256_tile_kernels_all_epilogues(M, N, K, w4):
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
 
 
+@pytest.mark.parametrize("sched", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(1100, 520, 512), (2304, 1536, 896), (4100, 2100, 256), (9000, 5120, 640)])
+def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
+    """wan_gemm_bf16_ws (gemm_pk_kernel: one resident workgroup per CU, 16x16x32 MFMAs, continuous K-tile stream, tiles by
+    per-XCD ticket, stream-K remainder combined in K order) at shapes that are mostly or partly SPLIT tiles (15 .. 720 tiles on 256
+    workers), ragged M / N: every epilogue against an fp64 product of the same bf16 operands; bitwise run-to-run (the combine
+    order does not depend on who arrives last); garbage in the workspace does not matter."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g) * 0.5
+    gate = torch.randn(2, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    acc = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    rpb = (M + 1) // 2
+    ops.set_tuning("gemm_pk", 2)                       # 2 = whenever K % 128 == 0 (the default takes shapes the 4-wave kernel would)
+    ops.set_tuning("gemm_pk_sched", sched)
+    try:
+        from videocof_amd import _lib
+        assert _lib.load().wan_gemm_ws_plan(M, N, K) == 3
+        ws = ops.gemm_workspace(ad.device, M, N, K)
+        assert ws is not None and ws.numel() == _lib.load().wan_gemm_workspace_bytes(M, N, K)
+        runs = []
+        for rep in range(2):
+            ws.fill_(0xA5 if rep else 0xFF)            # the kernel must not depend on what the workspace holds
+            o_res = resid.to(DEV).clone()
+            ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=o_res, gate=gate.to(DEV), rows_per_batch=rpb)
+            runs.append((ops.gemm(ad, wd, bd, ops.EPI_BF16), ops.gemm(ad, wd, bd, ops.EPI_GELU_BF16), ops.gemm(ad, wd, bd, ops.EPI_F32),
+                         o_res, ops.gemm(ad, wd, None, ops.EPI_BF16_T)))
+    finally:
+        ops.set_tuning("gemm_pk", 1)
+        ops.set_tuning("gemm_pk_sched", 1)
+    o_bf, o_ge, o_f32, o_res, o_t = runs[0]
+    assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
+    assert rel_l2(o_bf, acc) < 4e-3 and rel_l2(o_f32, acc) < 1e-5
+    x = acc.float().double()
+    assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3
+    gsel = gate.double()[torch.arange(M) // rpb]
+    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
+    assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc - bias.double()) < 4e-3
+    assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
+
+
 @pytest.mark.parametrize("P,T,B,Cl", [(2, 24, 2, 128), (8, 56, 1, 640), (4, 8, 3, 8)])
 def test_sp_wire_layout_kernels(rope_dev, P, T, B, Cl):
     """wan_sp_pack_heads / wan_sp_unpack_heads / wan_sp_unpack_vt move bytes exactly like the torch statements of the

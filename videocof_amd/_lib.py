@@ -65,7 +65,8 @@ class BlockWorkspace(Structure):
     """``wan_block_workspace`` of include/wan_hip.h."""
     _fields_ = ([(n, c_void_p) for n in ("h", "qk", "att", "cq", "ff", "vt")] + [("ldvt", c_int64)] +
                 [("attn_ws_self", c_void_p), ("attn_ws_self_bytes", c_int64),
-                 ("attn_ws_cross", c_void_p), ("attn_ws_cross_bytes", c_int64)])
+                 ("attn_ws_cross", c_void_p), ("attn_ws_cross_bytes", c_int64),
+                 ("gemm_ws", c_void_p), ("gemm_ws_bytes", c_int64)])
 
 
 class DitWeights(Structure):

@@ -67,7 +67,8 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"gemm_pk", "WAN_GEMM_PK", 1},              // persistent stream-K form of the 4-wave 256^2 GEMM for callers that bring a workspace: 0 never, 1 where the 4-wave kernel would run, 2 whenever K % 128 == 0
     {"gemm_pk_workers", "WAN_GEMM_PK_WORKERS", 0},      // its grid (0 = one workgroup per CU); developer A/B
     {"gemm_pk_min_units", "WAN_GEMM_PK_MIN_UNITS", 0},  // smallest stream-K range in units of two K tiles (0 = a quarter of the tile's K range)
-    {"gemm_pk_order", "WAN_GEMM_PK_ORDER", 0},          // 1 = stream-K ranges BEFORE the whole-tile rounds (developer A/B)
+    {"gemm_pk_order", "WAN_GEMM_PK_ORDER", 0},          // 1 = whole tiles in lockstep order instead of by per-XCD ticket (developer A/B)
+    {"gemm_pk_sched", "WAN_GEMM_PK_SCHED", 1},          // main-loop schedule of the persistent GEMM: 0 = one barrier per K tile, 1 = schedule D (requests spread over 3/4 of the K tile)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

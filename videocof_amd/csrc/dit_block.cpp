@@ -28,6 +28,8 @@ extern "C" wan_status_t wan_dit_block_forward(float* x, const float* emod, const
     WAN_REQUIRE(C > 0 && H > 0 && C == H * 128 && F > 0 && T > 0, WAN_ERR_UNSUPPORTED,
                 "wan_dit_block_forward: dim=%d heads=%d (head_dim must be 128) ffn=%d text_len=%d", C, H, F, T);
     WAN_REQUIRE(ws->h && ws->qk && ws->att && ws->cq && ws->ff && ws->vt, WAN_ERR_INVALID, "wan_dit_block_forward: null workspace");
+    void* const GWS = ws->gemm_ws;                                // every Linear of the block shares one GEMM workspace (they run back to back)
+    const int64_t GWSB = ws->gemm_ws_bytes;
     const int64_t Ll = rows_per_batch, M = (int64_t)batch * Ll;
     WAN_REQUIRE(M <= 0x7fffffff && valid_tokens <= 0x7fffffff, WAN_ERR_UNSUPPORTED, "wan_dit_block_forward: too many rows");
     const int64_t lk_pad = (valid_tokens + 63) / 64 * 64;
@@ -46,26 +48,26 @@ extern "C" wan_status_t wan_dit_block_forward(float* x, const float* emod, const
 
     // ---- self-attention (:495-499)
     WAN_TRY(wan_ln_modulate(x, scale_msa, shift_msa, 1, ws->h, M, C, Ll, eps, stream));
-    WAN_TRY(wan_gemm_bf16(ws->h, C, w->w_qk, C, w->b_qk, qk, 2 * C, (int)M, 2 * C, C, WAN_EPI_BF16, nullptr, 0, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->h, C, w->w_qk, C, w->b_qk, qk, 2 * C, (int)M, 2 * C, C, WAN_EPI_BF16, nullptr, 0, GWS, GWSB, stream));
     WAN_TRY(wan_rmsnorm_rope(qk, w->norm_q, kpart, w->norm_k, 2 * C, M, C, 128, eps, rope_cos, rope_sin, &rope, qs, stream));
     for (int b = 0; b < batch; ++b)
-        WAN_TRY(wan_gemm_bf16(at(ws->h, (int64_t)b * Ll * C * 2), C, w->w_v, C, w->b_v, at(ws->vt, (int64_t)b * C * ws->ldvt * 2),
-                              ws->ldvt, (int)valid_tokens, C, C, WAN_EPI_BF16_T, nullptr, 0, stream));
+        WAN_TRY(wan_gemm_bf16_ws(at(ws->h, (int64_t)b * Ll * C * 2), C, w->w_v, C, w->b_v, at(ws->vt, (int64_t)b * C * ws->ldvt * 2),
+                              ws->ldvt, (int)valid_tokens, C, C, WAN_EPI_BF16_T, nullptr, 0, GWS, GWSB, stream));
     WAN_TRY(wan_attention_fwd(qk, 2 * C, Ll * 2 * C, kpart, 2 * C, Ll * 2 * C, ws->vt, ws->ldvt, (int64_t)C * ws->ldvt, ws->att, C, Ll * C,
                               batch, (int)Ll, (int)valid_tokens, H, 128, 0.f, WAN_ATTN_Q_PRESCALED, ws->attn_ws_self,
                               ws->attn_ws_self_bytes, stream));
-    WAN_TRY(wan_gemm_bf16(ws->att, C, w->w_o, C, w->b_o, x, C, (int)M, C, C, WAN_EPI_RESID_F32, gate_msa, Ll, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->att, C, w->w_o, C, w->b_o, x, C, (int)M, C, C, WAN_EPI_RESID_F32, gate_msa, Ll, GWS, GWSB, stream));
     // ---- cross-attention over the text tokens (:504; rows are not masked, context_lens = None)
     WAN_TRY(wan_ln_modulate(x, w->norm3_w, w->norm3_b, 0, ws->h, M, C, M, eps, stream));
-    WAN_TRY(wan_gemm_bf16(ws->h, C, w->w_cq, C, w->b_cq, ws->cq, C, (int)M, C, C, WAN_EPI_BF16, nullptr, 0, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->h, C, w->w_cq, C, w->b_cq, ws->cq, C, (int)M, C, C, WAN_EPI_BF16, nullptr, 0, GWS, GWSB, stream));
     WAN_TRY(wan_rmsnorm_rope(ws->cq, w->norm_cq, nullptr, nullptr, C, M, C, 128, eps, nullptr, nullptr, nullptr, qs, stream));
     WAN_TRY(wan_attention_fwd(ws->cq, C, Ll * C, ctx_k, C, (int64_t)T * C, ctx_vt, T, (int64_t)C * T, ws->att, C, Ll * C, batch, (int)Ll,
                               T, H, 128, 0.f, WAN_ATTN_Q_PRESCALED, ws->attn_ws_cross, ws->attn_ws_cross_bytes, stream));
-    WAN_TRY(wan_gemm_bf16(ws->att, C, w->w_co, C, w->b_co, x, C, (int)M, C, C, WAN_EPI_RESID_F32, nullptr, 0, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->att, C, w->w_co, C, w->b_co, x, C, (int)M, C, C, WAN_EPI_RESID_F32, nullptr, 0, GWS, GWSB, stream));
     // ---- FFN (:507-511)
     WAN_TRY(wan_ln_modulate(x, scale_mlp, shift_mlp, 1, ws->h, M, C, Ll, eps, stream));
-    WAN_TRY(wan_gemm_bf16(ws->h, C, w->w_ffn0, C, w->b_ffn0, ws->ff, F, (int)M, F, C, WAN_EPI_GELU_BF16, nullptr, 0, stream));
-    WAN_TRY(wan_gemm_bf16(ws->ff, F, w->w_ffn2, F, w->b_ffn2, x, C, (int)M, C, F, WAN_EPI_RESID_F32, gate_mlp, Ll, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->h, C, w->w_ffn0, C, w->b_ffn0, ws->ff, F, (int)M, F, C, WAN_EPI_GELU_BF16, nullptr, 0, GWS, GWSB, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->ff, F, w->w_ffn2, F, w->b_ffn2, x, C, (int)M, C, F, WAN_EPI_RESID_F32, gate_mlp, Ll, GWS, GWSB, stream));
     return WAN_OK;
 }
 
@@ -94,6 +96,8 @@ extern "C" wan_status_t wan_dit_forward(const void* latent, int latent_dtype, vo
     WAN_REQUIRE(w->num_layers > 0 && w->blocks && w->pe_w && w->pe_b && w->head_w && w->head_b, WAN_ERR_INVALID,
                 "wan_dit_forward: incomplete weights");
     WAN_REQUIRE(ws->x && ws->tokens && ws->head_out, WAN_ERR_INVALID, "wan_dit_forward: null workspace");
+    void* const GWS = ws->block.gemm_ws;
+    const int64_t GWSB = ws->block.gemm_ws_bytes;
     const int pt = w->pt, ph = w->ph, pw = w->pw;
     WAN_REQUIRE(pt > 0 && ph > 0 && pw > 0 && F > 0 && H > 0 && W > 0 && F % pt == 0 && H % ph == 0 && W % pw == 0, WAN_ERR_INVALID,
                 "wan_dit_forward: latent (%d,%d,%d) is not a multiple of the patch (%d,%d,%d)", F, H, W, pt, ph, pw);
@@ -116,8 +120,8 @@ extern "C" wan_status_t wan_dit_forward(const void* latent, int latent_dtype, vo
     for (int b = 0; b < batch; ++b) {
         WAN_TRY(wan_patchify(at(latent, (int64_t)b * w->in_dim * F * H * W * lat_el), latent_dtype, ws->tokens, Kpe, w->in_dim, F, H, W,
                              pt, ph, pw, stream));
-        WAN_TRY(wan_gemm_bf16(ws->tokens, Kpe, w->pe_w, Kpe, w->pe_b, ws->x + (int64_t)b * Ll * C, C, (int)L, C, Kpe, WAN_EPI_F32,
-                              nullptr, 0, stream));
+        WAN_TRY(wan_gemm_bf16_ws(ws->tokens, Kpe, w->pe_w, Kpe, w->pe_b, ws->x + (int64_t)b * Ll * C, C, (int)L, C, Kpe, WAN_EPI_F32,
+                              nullptr, 0, GWS, GWSB, stream));
     }
     const int64_t emod_layer = 6 * (int64_t)batch * C;
     for (int l = 0; l < w->num_layers; ++l) {
@@ -127,7 +131,7 @@ extern "C" wan_status_t wan_dit_forward(const void* latent, int latent_dtype, vo
     }
     const int64_t bC = (int64_t)batch * C;                    // ehead = [shift][scale], each [batch][C] (Head.forward :545-547)
     WAN_TRY(wan_ln_modulate(ws->x, ehead + bC, ehead, 1, ws->block.h, M, C, Ll, w->blocks[0].eps, stream));
-    WAN_TRY(wan_gemm_bf16(ws->block.h, C, w->head_w, C, w->head_b, ws->head_out, Nh, (int)M, Nh, C, WAN_EPI_F32, nullptr, 0, stream));
+    WAN_TRY(wan_gemm_bf16_ws(ws->block.h, C, w->head_w, C, w->head_b, ws->head_out, Nh, (int)M, Nh, C, WAN_EPI_F32, nullptr, 0, GWS, GWSB, stream));
     for (int b = 0; b < batch; ++b)
         WAN_TRY(wan_unpatchify(ws->head_out + (int64_t)b * Ll * Nh, Nh, at(out, (int64_t)b * w->out_dim * F * H * W * out_el), out_dtype,
                                w->out_dim, gf, gh, gw, pt, ph, pw, zero_frames, stream));

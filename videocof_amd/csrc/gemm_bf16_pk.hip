@@ -50,6 +50,7 @@ struct PkArgs {
     int gm;               // M tiles per rasterisation group
     int nworkers;         // grid size (multiple of 8)
     int min_units;        // smallest stream-K range worth a worker (units of two K tiles)
+    int sched;            // main-loop schedule: 0 = one barrier per K tile (requests in two bursts), 1 = schedule D (see the kernel)
     int dynamic;          // whole tiles by ticket from the per-XCD counters (1) or in lockstep order (0: developer A/B)
     int* counters;        // workspace head: [0, nworkers) arrival counters of the split tiles, [512 + 16 x] the ticket counter of XCD x
     char* slots;          // workspace + kCounterBytes: 2 slots of 256 KiB per worker
@@ -159,7 +160,7 @@ __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast
 // 32x32x16 form of gemm_w4_kernel: on random operands, with every CU busy, the chip sustains 1.99-2.05 PFLOP/s of bare 16x16x32 MFMAs
 // against 1.59-1.78 of 32x32x16 (2.45 either way on zeros: tools/probe/mfma_power.hip, profiles/r04/mfma_power.log) -- twice the K depth
 // per accumulator update is half the accumulator traffic, and the power that saves comes back as clock.
-template <int EPI>
+template <int EPI, int SCHED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(PkArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
@@ -324,6 +325,41 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         });
     };
 
+    // Schedule D (g.sched == 1): shrink the LDS residency of a K tile so that its buffer can take requests for most of the time.
+    //   slots   0..31   the 16 fragments of k half 1 (one per 2 MFMAs): by slot 32 every fragment of position kt is in registers
+    //   slot   32       barrier B1: buffer b is free
+    //   slots  33..123  the 16 pieces (A 0..7, W 0..7) of position kt + 2 -> buffer b, one per 6 MFMAs (96 cycles: 43 B/clk per CU,
+    //                   two thirds of the vector-memory path's rate) -- every piece has >= 97 MFMA slots (~1550 cycles) to land
+    //   slot   96       barrier B2 behind vmcnt(11): position kt + 1 (requested during the previous K tile) has landed; the 11 pieces
+    //                   of position kt + 2 issued so far stay in flight
+    //   slots  96..126  the 16 fragments of k half 0 of position kt + 1 (buffer 1 - b)
+    auto ktile_d = [&](int kt, int b) __attribute__((always_inline)) {
+        const bool jump = kt + 2 == cur.ke;
+        __amdgpu_buffer_rsrc_t ra, rw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s_ = h * 64 + i * 8 + j;
+            if (s_ == 32) { __builtin_amdgcn_s_barrier(); GP_SB(); ra = rsrc_of(sa); rw = rsrc_of(sq); }
+            if (s_ == 96) { asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); __builtin_amdgcn_s_barrier(); GP_SB(); }
+            if constexpr (kTransposed) GP_MFMA(acc[i][j], af[h][i], wf[h][j]);
+            else GP_MFMA(acc[i][j], wf[h][j], af[h][i]);
+            GP_SB();
+            if (s_ < 32 && s_ % 2 == 0) fetch(1, s_ / 2, b);
+            else if (s_ == 1) advance(sa, 0, jump);
+            else if (s_ == 3) advance(sq, 1, jump);
+            else if (s_ >= 33 && (s_ - 33) % 6 == 0) {
+                const int k = (s_ - 33) / 6;
+                if (k < 8) stage_piece(ra, b, 0, k, g.lda);
+                else stage_piece(rw, b, 1, k - 8, g.ldw);
+            } else if (s_ >= 96 && s_ % 2 == 0) fetch(0, (s_ - 96) / 2, 1 - b);
+            GP_SB();
+        }
+    };
+
     // ---- stream prologue: position cur.kb -> buffer 0 (waited for), the A half of position cur.kb + 1 -> buffer 1 (in flight)
     {
         sa = stream_at(0, cur.kb); sq = stream_at(1, cur.kb);
@@ -333,9 +369,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
         sa = stream_at(0, cur.kb + 1); sq = stream_at(1, cur.kb + 1);       // a segment has at least two K tiles
-        const __amdgpu_buffer_rsrc_t ra1 = rsrc_of(sa);
+        const __amdgpu_buffer_rsrc_t ra1 = rsrc_of(sa), rw1 = rsrc_of(sq);
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage_piece(ra1, 1, 0, j, g.lda);
+        if constexpr (SCHED == 1) {            // schedule D keeps a whole K tile in flight
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage_piece(rw1, 1, 1, j, g.ldw);
+        }
     }
 
     for (;;) {
@@ -346,9 +386,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < 16; ++f) fetch(0, f, 0);
-        for (int kt = cur.kb; kt < cur.ke; kt += 2) {
-            ktile(kt, 0);
-            ktile(kt + 1, 1);
+        if constexpr (SCHED == 1) {
+            for (int kt = cur.kb; kt < cur.ke; kt += 2) {
+                ktile_d(kt, 0);
+                ktile_d(kt + 1, 1);
+            }
+        } else {
+            for (int kt = cur.kb; kt < cur.ke; kt += 2) {
+                ktile(kt, 0);
+                ktile(kt + 1, 1);
+            }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads below
 
@@ -543,11 +590,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef GP_SB
 }
 
-template <int EPI>
+template <int EPI, int SCHED>
 wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI, SCHED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 64);
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16_ws: cannot reserve %d B of LDS: %s", kLdsBytes + 64, hipGetErrorString(e));
@@ -560,7 +607,7 @@ wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
         wan_set_error("wan_gemm_bf16_ws: cannot clear the arrival counters: %s", hipGetErrorString(hipGetLastError()));
         return WAN_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemm_pk_kernel<EPI>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
+    hipLaunchKernelGGL((gemm_pk_kernel<EPI, SCHED>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16_ws");
     return WAN_OK;
 }
@@ -590,6 +637,7 @@ static void pk_plan_args(PkArgs& g, int M, int N, int K) {
     g.min_units = (K / BK / 2 + 3) / 4;
     if (const int mu = wan_tune(WAN_TUNE_GEMM_PK_MIN_UNITS); mu > 0) g.min_units = mu;
     g.dynamic = wan_tune(WAN_TUNE_GEMM_PK_ORDER) != 1;
+    g.sched = wan_tune(WAN_TUNE_GEMM_PK_SCHED);
 }
 
 // Host arithmetic only: segment `index` of worker `worker` of the persistent GEMM's plan for this shape -- the SAME functions the
@@ -619,12 +667,14 @@ wan_status_t wan_gemm_bf16_pk(const void* A, int64_t lda, const void* W, int64_t
     pk_plan_args(g, M, N, K);
     g.counters = (int*)workspace;
     g.slots = (char*)workspace + kCounterBytes;
+#define WAN_PK(E) (g.sched == 1 ? launch_pk<E, 1>(g, s) : launch_pk<E, 0>(g, s))
     switch (epilogue) {
-        case WAN_EPI_BF16: return launch_pk<WAN_EPI_BF16>(g, s);
-        case WAN_EPI_GELU_BF16: return launch_pk<WAN_EPI_GELU_BF16>(g, s);
-        case WAN_EPI_F32: return launch_pk<WAN_EPI_F32>(g, s);
-        case WAN_EPI_RESID_F32: return launch_pk<WAN_EPI_RESID_F32>(g, s);
-        case WAN_EPI_BF16_T: return launch_pk<WAN_EPI_BF16_T>(g, s);
+        case WAN_EPI_BF16: return WAN_PK(WAN_EPI_BF16);
+        case WAN_EPI_GELU_BF16: return WAN_PK(WAN_EPI_GELU_BF16);
+        case WAN_EPI_F32: return WAN_PK(WAN_EPI_F32);
+        case WAN_EPI_RESID_F32: return WAN_PK(WAN_EPI_RESID_F32);
+        case WAN_EPI_BF16_T: return WAN_PK(WAN_EPI_BF16_T);
         default: wan_set_error("wan_gemm_bf16_ws: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
     }
+#undef WAN_PK
 }

@@ -904,11 +904,21 @@ class WanTransformer3DModel(nn.Module):
             bufs.nself = int(lib.wan_attention_workspace_bytes(B, Ll, L, H, 128))
             bufs.ncross = int(lib.wan_attention_workspace_bytes(B, Ll, self.text_len, H, 128))
             holder.cws = BlockWorkspace(p(bufs.h), p(bufs.qk), p(bufs.att), p(bufs.cq), p(bufs.ff), p(bufs.vt), bufs.vt.stride(1),
-                                        None, bufs.nself, None, bufs.ncross)
+                                        None, bufs.nself, None, bufs.ncross, None, 0)
         # the attention scratches belong to the call sites (AttentionWorkspace objects that may be re-allocated when another
         # shape asks for more): take their CURRENT addresses on every call, never a cached pointer
         holder.cws.attn_ws_self = self._ws_self.get(self._device, max(bufs.nself, 16)).data_ptr()
         holder.cws.attn_ws_cross = self._ws_cross.get(self._device, max(bufs.ncross, 16)).data_ptr()
+        # the persistent GEMM's workspace: the same per-device buffer ops.gemm hands to the per-op path (so that the composite and
+        # the Python launch sequence run the SAME kernels and stay bit-identical); sized by the widest Linear of the block
+        M = B * Ll
+        gws = None
+        for (n_, k_) in ((2 * self.dim, self.dim), (self.ffn_dim, self.dim), (self.dim, self.ffn_dim), (self.dim, self.dim)):
+            t = ops.gemm_workspace(self._device, M, n_, k_)
+            if t is not None and (gws is None or t.numel() > gws.numel()):
+                gws = t
+        holder.cws.gemm_ws = gws.data_ptr() if gws is not None else None
+        holder.cws.gemm_ws_bytes = gws.numel() if gws is not None else 0
         return holder.cws
 
     def _forward_composite(self, x, emod, ehead, kvs, rp, bufs, B, Ll, L, out_dtype):
