@@ -17,6 +17,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     u32x4 a[8], b[8];
     for (int i = 0; i < 8; ++i) { a[i] = sm[(threadIdx.x * 8 + i) & 4095]; b[i] = sm[(threadIdx.x * 8 + i + 1024) & 4095]; }
     const u32x4* lp = sm + (threadIdx.x & 63);
+    float xs[8], ex[8], sum = 0.f; unsigned pk[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) { xs[i] = -0.37f * (float)((threadIdx.x * 7 + i * 13) % 29); ex[i] = 0.f; }
     if constexpr (SHAPE == 32) {
         f32x16 acc[16];
         for (int i = 0; i < 16; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
@@ -27,10 +29,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < 4; ++j) {
                     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i * 4 + j]) : "v"(a[i]), "v"(b[j]));
                     if (LDS && ((i * 4 + j) & 1) == 0) { const int f = (i * 4 + j) / 2; if (f < 4) a[4 + f] = lp[(f * 64 + it * 7) & 4032]; else b[f] = lp[(f * 64 + it * 5) & 4032]; }
+                    if (LDS == 2) {      // the softmax stream of an attention tile: per 32x32x16 MFMA one v_exp_f32, one v_add_f32, half a v_cvt_pk_bf16_f32
+                        asm volatile("v_exp_f32 %0, %1" : "=v"(ex[(i * 4 + j) & 7]) : "v"(xs[(i * 4 + j) & 7]));
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(i * 4 + j + 4) & 7]));
+                        if (((i * 4 + j) & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(i * 4 + j) >> 1 & 3]) : "v"(ex[(i * 4 + j) & 7]), "v"(ex[(i * 4 + j + 1) & 7]));
+                    }
                 }
             if (LDS) for (int f = 0; f < 4; ++f) { a[f] = a[4 + f]; }
         }
-        float s = 0; for (int i = 0; i < 16; ++i) s += acc[i][0];
+        float s = sum + (float)pk[0] + (float)pk[1] + (float)pk[2] + (float)pk[3]; for (int i = 0; i < 16; ++i) s += acc[i][0];
         out[blockIdx.x * 256 + threadIdx.x] = s;
     } else {
         f32x4 acc[64];
@@ -42,9 +49,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < 8; ++j) {
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i * 8 + j]) : "v"(a[i]), "v"(b[j]));
                     if (LDS && ((i * 8 + j) & 3) == 0) { const int f = (i * 8 + j) / 4; if (f < 8) a[f] = lp[(f * 64 + it * 7) & 4032]; else b[f - 8] = lp[(f * 64 + it * 5) & 4032]; }
+                    if (LDS == 2 && ((i * 8 + j) & 1) == 0) {      // the same stream per FLOP: one exp + one add per two 16x16x32 MFMAs, a convert per four
+                        const int q = (i * 8 + j) >> 1;
+                        asm volatile("v_exp_f32 %0, %1" : "=v"(ex[q & 7]) : "v"(xs[q & 7]));
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(q + 4) & 7]));
+                        if ((q & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(q >> 1) & 3]) : "v"(ex[q & 7]), "v"(ex[(q + 1) & 7]));
+                    }
                 }
         }
-        float s = 0; for (int i = 0; i < 64; ++i) s += acc[i][0];
+        float s = sum + (float)pk[0] + (float)pk[1] + (float)pk[2] + (float)pk[3]; for (int i = 0; i < 64; ++i) s += acc[i][0];
         out[blockIdx.x * 256 + threadIdx.x] = s;
     }
 }
@@ -79,6 +92,8 @@ int main() {
         snprintf(nm, sizeof nm, "16x16x32, %s operands, MFMA only", d); run<16, 0>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s operands, + ds_read_b128 per 2 MFMA", d); run<32, 1>(nm, src, out);
         snprintf(nm, sizeof nm, "16x16x32, %s operands, + ds_read_b128 per 4 MFMA", d); run<16, 1>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + softmax VALU stream", d); run<32, 2>(nm, src, out);
+        snprintf(nm, sizeof nm, "16x16x32, %s, + LDS reads + softmax VALU stream", d); run<16, 2>(nm, src, out);
     }
     return 0;
 }
