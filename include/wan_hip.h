@@ -327,7 +327,7 @@ wan_status_t wan_sp_unpack_heads(const void* wire, void* x_bf16, int64_t ldx, in
 wan_status_t wan_sp_unpack_vt(const void* wire, void* vt_bf16, int64_t ldvt, int P, int B, int Cl, int T, void* stream);
 
 /* a21' The collective itself, owned by the library (for a host without torch.distributed; the Python host may use either):
- *      one communicator = one RCCL comm + ONE side HIP stream + two events.
+ *      one communicator = one RCCL comm + ONE side HIP stream + a small ring of events (one per exchange in flight).
  *      replaces: set_multi_gpus_devices / init_distributed_environment (dist/fuser.py:35-54) and the head all-to-all inside
  *                xFuserLongContextAttention (dist/wan_xfuser.py:68-111).
  *      wan_sp_unique_id: rank 0 creates the 128-byte rendezvous token; the host distributes it (MPI, a file, torchrun's store).
@@ -341,6 +341,11 @@ wan_status_t wan_sp_unpack_vt(const void* wire, void* vt_bf16, int64_t ldvt, int
  *      wan_sp_wait before the kernel that reads the receive buffers: `compute_stream` then waits (on the device) for every
  *                exchange started so far.  The host is never synchronised.  send / receive buffers must be distinct and stay
  *                untouched between start and wait (persistent pairs, as videocof_amd/wan_transformer3d.py keeps them).
+ *      wan_sp_ticket / wan_sp_wait_for: the finer form -- wan_sp_ticket right after a start names that exchange, wan_sp_wait_for
+ *                makes `compute_stream` wait for it (and, the side stream being in order, for every EARLIER one) while exchanges
+ *                started later stay in flight: the k exchange can be consumed while the q exchange behind it still runs.  A
+ *                ticket is good for a wait at any later time (a recycled event marks a later point of the side stream).  One
+ *                host thread drives a communicator.
  *      wan_sp_all_gather: recv[r] <- send of rank r (the head output, wan_transformer3d.py:1085-1086); also asynchronous.
  *      RCCL is bound at run time (dlopen "librccl.so.1"): WAN_ERR_UNSUPPORTED if it cannot be loaded. */
 typedef struct wan_sp_comm wan_sp_comm;
@@ -354,6 +359,8 @@ wan_status_t wan_sp_a2a_scatter_heads(wan_sp_comm* comm, const void* send_wire, 
 wan_status_t wan_sp_a2a_gather_heads(wan_sp_comm* comm, const void* send_wire, void* recv_wire, int64_t bytes_total, void* compute_stream);
 wan_status_t wan_sp_all_gather(wan_sp_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* compute_stream);
 wan_status_t wan_sp_wait(wan_sp_comm* comm, void* compute_stream);
+int64_t wan_sp_ticket(const wan_sp_comm* comm);
+wan_status_t wan_sp_wait_for(wan_sp_comm* comm, int64_t ticket, void* compute_stream);
 wan_status_t wan_sp_destroy(wan_sp_comm* comm);
 
 /* ---------------------------------------------------------------------------

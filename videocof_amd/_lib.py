@@ -137,6 +137,8 @@ SIGNATURES = {
     "wan_sp_a2a_gather_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sp_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sp_wait": (c_int, [c_void_p, c_void_p]),
+    "wan_sp_ticket": (c_int64, [c_void_p]),
+    "wan_sp_wait_for": (c_int, [c_void_p, c_int64, c_void_p]),
     "wan_sp_destroy": (c_int, [c_void_p]),
     "wan_attention_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "wan_gemm_plan": (c_int, [c_int, c_int, c_int]),

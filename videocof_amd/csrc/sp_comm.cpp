@@ -36,15 +36,21 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "not attempted";      // the loader's own account of a failure (dlerror() is consumed by reading it: capture it once, here)
 };
 
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        size_t used = 0;
+        r.why[0] = 0;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
+            const char* e = dlerror();                 // every candidate's reason is kept, not only the last one's
+            const int n = snprintf(r.why + used, sizeof(r.why) - used, "%s%s", used ? "; " : "", e ? e : name);
+            if (n > 0) used = used + (size_t)n < sizeof(r.why) ? used + (size_t)n : sizeof(r.why) - 1;
         }
         if (!r.handle) return;
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
@@ -54,6 +60,7 @@ Rccl& rccl() {
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllToAll && r.AllGather && r.GetErrorString;
+        if (!r.ok) snprintf(r.why, sizeof(r.why), "librccl was loaded but lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllToAll / ncclAllGather / ncclGetErrorString");
     });
     return r;
 }
@@ -65,8 +72,14 @@ struct wan_sp_comm {
     bool owns_comm = false;
     int rank = 0, world = 1, device = 0;
     hipStream_t side = nullptr;
-    hipEvent_t ready = nullptr, done = nullptr;      // compute -> side, side -> compute
-    int64_t started = 0;                             // exchanges enqueued since the last wait (statistics / misuse check)
+    hipEvent_t ready = nullptr;                      // compute -> side
+    // side -> compute: one event per exchange from a small ring, so that a wait joins ITS exchange only (the k exchange can be
+    // consumed while the q exchange behind it is still in flight).  A ticket is the 1-based count of exchanges started on this
+    // communicator; the event of ticket t lives in slot t % kRing and stays valid until kRing further exchanges have started.
+    static constexpr int kRing = 8;
+    hipEvent_t done[kRing] = {};
+    int64_t ticket = 0;                              // exchanges started so far
+    int64_t waited = 0;                              // every ticket <= waited has been joined by a wait on the caller's stream
 };
 
 #define WAN_SP_HIP(call, what)                                                              \
@@ -88,7 +101,7 @@ struct wan_sp_comm {
 
 extern "C" wan_status_t wan_sp_unique_id(void* id128) {
     WAN_REQUIRE(id128 != nullptr, WAN_ERR_INVALID, "wan_sp_unique_id: null buffer");
-    WAN_REQUIRE(rccl().ok, WAN_ERR_UNSUPPORTED, "wan_sp_unique_id: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+    WAN_REQUIRE(rccl().ok, WAN_ERR_UNSUPPORTED, "wan_sp_unique_id: librccl.so.1 could not be loaded (%s)", rccl().why);
     static_assert(sizeof(ncclUniqueId) == WAN_SP_UNIQUE_ID_BYTES, "rendezvous token size");
     ncclUniqueId id;
     WAN_SP_NCCL(rccl().GetUniqueId(&id), "wan_sp_unique_id");
@@ -100,14 +113,14 @@ static wan_status_t finish_init(wan_sp_comm* c) {
     WAN_SP_HIP(hipGetDevice(&c->device), "wan_sp_init: hipGetDevice");
     WAN_SP_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking), "wan_sp_init: side stream");
     WAN_SP_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming), "wan_sp_init: event");
-    WAN_SP_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming), "wan_sp_init: event");
+    for (int i = 0; i < wan_sp_comm::kRing; ++i) WAN_SP_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming), "wan_sp_init: event");
     return WAN_OK;
 }
 
 extern "C" wan_status_t wan_sp_init(wan_sp_comm** out, const void* id128, int rank, int world_size) {
     WAN_REQUIRE(out != nullptr && id128 != nullptr, WAN_ERR_INVALID, "wan_sp_init: null argument");
     WAN_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, WAN_ERR_INVALID, "wan_sp_init: rank %d of %d", rank, world_size);
-    WAN_REQUIRE(rccl().ok, WAN_ERR_UNSUPPORTED, "wan_sp_init: librccl.so.1 could not be loaded");
+    WAN_REQUIRE(rccl().ok, WAN_ERR_UNSUPPORTED, "wan_sp_init: librccl.so.1 could not be loaded (%s)", rccl().why);
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     wan_sp_comm* c = new wan_sp_comm();
@@ -127,7 +140,7 @@ extern "C" wan_status_t wan_sp_init(wan_sp_comm** out, const void* id128, int ra
 extern "C" wan_status_t wan_sp_init_from_comm(wan_sp_comm** out, void* nccl_comm, int rank, int world_size) {
     WAN_REQUIRE(out != nullptr && nccl_comm != nullptr, WAN_ERR_INVALID, "wan_sp_init_from_comm: null argument");
     WAN_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, WAN_ERR_INVALID, "wan_sp_init_from_comm: rank %d of %d", rank, world_size);
-    WAN_REQUIRE(rccl().ok, WAN_ERR_UNSUPPORTED, "wan_sp_init_from_comm: librccl.so.1 could not be loaded");
+    WAN_REQUIRE(rccl().ok, WAN_ERR_UNSUPPORTED, "wan_sp_init_from_comm: librccl.so.1 could not be loaded (%s)", rccl().why);
     wan_sp_comm* c = new wan_sp_comm();
     c->comm = (ncclComm_t)nccl_comm; c->rank = rank; c->world = world_size; c->owns_comm = false;
     const wan_status_t st = finish_init(c);
@@ -149,7 +162,8 @@ static wan_status_t a2a_start(wan_sp_comm* c, const void* send, void* recv, int6
     WAN_SP_HIP(hipEventRecord(c->ready, cs), what);                 // everything enqueued on the compute stream so far ...
     WAN_SP_HIP(hipStreamWaitEvent(c->side, c->ready, 0), what);     // ... precedes the exchange
     WAN_SP_NCCL(rccl().AllToAll(send, recv, (size_t)(bytes_total / c->world), ncclInt8, c->comm, c->side), what);
-    ++c->started;
+    ++c->ticket;
+    WAN_SP_HIP(hipEventRecord(c->done[c->ticket % wan_sp_comm::kRing], c->side), what);
     return WAN_OK;
 }
 
@@ -169,17 +183,32 @@ extern "C" wan_status_t wan_sp_all_gather(wan_sp_comm* c, const void* send, void
     WAN_SP_HIP(hipEventRecord(c->ready, cs), "wan_sp_all_gather");
     WAN_SP_HIP(hipStreamWaitEvent(c->side, c->ready, 0), "wan_sp_all_gather");
     WAN_SP_NCCL(rccl().AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, c->comm, c->side), "wan_sp_all_gather");
-    ++c->started;
+    ++c->ticket;
+    WAN_SP_HIP(hipEventRecord(c->done[c->ticket % wan_sp_comm::kRing], c->side), "wan_sp_all_gather");
     return WAN_OK;
 }
 
+// the ticket of the exchange started last (0 before the first one): pass it to wan_sp_wait_for
+extern "C" int64_t wan_sp_ticket(const wan_sp_comm* c) { return c ? c->ticket : 0; }
+
+// the caller's stream waits (on the device) for exchange `ticket` -- and, the side stream being in order, for every earlier one;
+// exchanges started after it stay in flight.  A communicator is driven by ONE host thread (the reference is single-threaded per
+// rank); the tickets are plain counters.
+extern "C" wan_status_t wan_sp_wait_for(wan_sp_comm* c, int64_t ticket, void* compute_stream) {
+    WAN_REQUIRE(c != nullptr, WAN_ERR_INVALID, "wan_sp_wait_for: null communicator");
+    WAN_REQUIRE(ticket >= 0 && ticket <= c->ticket, WAN_ERR_INVALID, "wan_sp_wait_for: ticket %lld of %lld started", (long long)ticket, (long long)c->ticket);
+    if (ticket == 0) return WAN_OK;
+    // an event slot recycled by later exchanges marks a LATER point of the in-order side stream: waiting on it is still correct
+    const int64_t t = ticket + wan_sp_comm::kRing <= c->ticket ? c->ticket : ticket;
+    WAN_SP_HIP(hipStreamWaitEvent((hipStream_t)compute_stream, c->done[t % wan_sp_comm::kRing], 0), "wan_sp_wait_for");
+    if (t > c->waited) c->waited = t;
+    return WAN_OK;
+}
+
+// join everything started so far
 extern "C" wan_status_t wan_sp_wait(wan_sp_comm* c, void* compute_stream) {
     WAN_REQUIRE(c != nullptr, WAN_ERR_INVALID, "wan_sp_wait: null communicator");
-    if (c->started == 0) return WAN_OK;
-    WAN_SP_HIP(hipEventRecord(c->done, c->side), "wan_sp_wait");
-    WAN_SP_HIP(hipStreamWaitEvent((hipStream_t)compute_stream, c->done, 0), "wan_sp_wait");
-    c->started = 0;
-    return WAN_OK;
+    return wan_sp_wait_for(c, c->ticket, compute_stream);
 }
 
 extern "C" wan_status_t wan_sp_destroy(wan_sp_comm* c) {
@@ -187,7 +216,7 @@ extern "C" wan_status_t wan_sp_destroy(wan_sp_comm* c) {
     (void)hipStreamSynchronize(c->side);
     if (c->owns_comm && c->comm) (void)rccl().CommDestroy(c->comm);
     if (c->ready) (void)hipEventDestroy(c->ready);
-    if (c->done) (void)hipEventDestroy(c->done);
+    for (hipEvent_t e : c->done) if (e) (void)hipEventDestroy(e);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return WAN_OK;

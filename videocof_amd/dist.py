@@ -159,15 +159,20 @@ class LibraryComm:
         from . import _lib
         self._lib, self._ct = _lib, ctypes
         lib = _lib.load()
+        if (rank is None) != (world_size is None):
+            raise ValueError("LibraryComm: give rank AND world_size, or neither (both are then taken from the process group)")
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_initialized() else 1
-            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            rank = dist.get_rank(group) if dist.is_initialized() else 0          # the rank INSIDE `group`
         uid = (ctypes.c_ubyte * 128)()
         if rank == 0:
             _lib.check(lib.wan_sp_unique_id(uid), "wan_sp_unique_id")
         if world_size > 1:
             box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0, group=group)
+            # broadcast_object_list addresses its source by GLOBAL rank: group rank 0 of a sub-group (an SP group inside a
+            # data-parallel world) is generally not global rank 0
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
             uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
         self._comm = ctypes.c_void_p()
         _lib.check(lib.wan_sp_init(ctypes.byref(self._comm), uid, int(rank), int(world_size)), "wan_sp_init")
@@ -183,7 +188,10 @@ class LibraryComm:
         lib, vp = self._lib.load(), self._ct.c_void_p
         self._lib.check(lib.wan_sp_a2a_scatter_heads(self._comm, vp(send.data_ptr()), vp(recv.data_ptr()),
                                                      send.numel() * send.element_size(), self._stream()), "wan_sp_a2a_scatter_heads")
-        wait = lambda: self._lib.check(lib.wan_sp_wait(self._comm, self._stream()), "wan_sp_wait")
+        ticket = int(lib.wan_sp_ticket(self._comm))
+        # the wait joins THIS exchange (and earlier ones) only: exchanges started after it stay in flight, as with the per-work
+        # waits of the torch.distributed transport
+        wait = lambda: self._lib.check(lib.wan_sp_wait_for(self._comm, ticket, self._stream()), "wan_sp_wait_for")
         if async_op:
             return wait
         wait()

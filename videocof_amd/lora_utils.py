@@ -81,7 +81,7 @@ def merge_lora_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.
         if up.dim() == 4:
             delta = torch.mm(up.flatten(1), down.flatten(1)).reshape(w.shape)
         else:
-            delta = torch.mm(up, down)
+            delta = torch.mm(up, down)      # (rocBLAS / hipBLASLt through torch: checkpoint ingest, once per load, outside every timed path)
         if delta.shape != w.shape:
             raise ValueError(f"LoRA for {mod}: delta {tuple(delta.shape)} does not match weight {tuple(w.shape)}")
         sd[mod + ".weight"] = (w.to(dev, torch.float32) + multiplier * scale * delta).to(w.dtype).to(w.device)
@@ -124,7 +124,7 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
         up = elems["lora_up.weight"].to(w.device, torch.float32).flatten(1)
         down = elems["lora_down.weight"].to(w.device, torch.float32).flatten(1)
         scale = float(elems["alpha"]) / up.shape[1] if "alpha" in elems else 1.0
-        delta = torch.mm(up, down)
+        delta = torch.mm(up, down)      # (rocBLAS / hipBLASLt through torch: checkpoint ingest, once per load, outside every timed path)
         if delta.shape != w.shape:
             raise ValueError(f"LoRA for {mod}: delta {tuple(delta.shape)} does not match weight {tuple(w.shape)}")
         # One bf16 rounding of the weight per merge call, as in the reference: its `weight.data += ...` runs on the bf16
@@ -139,6 +139,8 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
     model.lora_layers_merged = merged                 # the reference returns the pipeline, so the count rides here
     if hasattr(model, "_ctx_cache"):
         model._ctx_cache = None          # hoisted text K/V were built from the old cross-attention weights
+    if hasattr(model, "_reset_attention_scratch"):
+        model._reset_attention_scratch() # the sticky "max-free attempt off" word described the pre-merge q / k statistics
     if getattr(model, "_fp8", ()):
         # the reference quantises first and merges afterwards (fast_infer.py:352-359, 371-385): the e4m3 copies made by
         # enable_fp8_linear must follow the merged bf16 weights, or q|k / v / ffn keep running the pre-LoRA values

@@ -53,6 +53,21 @@ class WanPipeline:
         self._interrupt = False
         self._graphed = None
         self._graphed_loop = None
+        self.release_workspaces_after_denoise = False     # see __call__: hand the DiT's activation buffers back before the VAE decode
+        # Set to a dict to get synchronised wall seconds per stage of the next __call__ ("text_encoder", "vae_encode",
+        # "denoise_loop", "vae_decode"): a measuring aid (bench.py's `e2e` object); None = no synchronisation anywhere.
+        self.stage_seconds = None
+
+    def _stage(self, name, t0=None):
+        """Stage clock for ``stage_seconds``: call without t0 to start (returns the start time), with t0 to stop."""
+        if self.stage_seconds is None:
+            return None
+        import time
+        torch.cuda.synchronize()
+        if t0 is None:
+            return time.perf_counter()
+        self.stage_seconds[name] = self.stage_seconds.get(name, 0.0) + time.perf_counter() - t0
+        return None
 
     guidance_scale = property(lambda self: self._guidance_scale)
     num_timesteps = property(lambda self: self._num_timesteps)
@@ -171,8 +186,10 @@ class WanPipeline:
         self._interrupt = False
         device = torch.device(device) if device is not None else self.transformer.device
         do_cfg = guidance_scale > 1.0                                                           # :592
+        t_stage = self._stage("text_encoder")
         prompt_embeds, negative_prompt_embeds = self.encode_prompt(
             prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device, max_sequence_length)
+        self._stage("text_encoder", t_stage)
         in_prompt_embeds = (negative_prompt_embeds + prompt_embeds) if do_cfg else prompt_embeds   # :605-608
 
         if not isinstance(self.scheduler, FlowUniPCMultistepScheduler):
@@ -184,6 +201,7 @@ class WanPipeline:
         ratio = getattr(self.vae, "temporal_compression_ratio", 4)
         condition_count = 1 if source_frames == 1 else (source_frames - 1) // ratio + 1         # :630-631
         ground_latent_count = 0
+        t_stage = self._stage("vae_encode")
         if cot:
             ground_latent_count = 1 if reasoning_frames <= 1 else (reasoning_frames - 1) // ratio + 1   # :637
             latents = self.prepare_cot_video_latents(video, ground_latent_count, weight_dtype, device,
@@ -192,6 +210,7 @@ class WanPipeline:
             # repeat / org layouts: noise block has the source's frame count (:370-379)
             latents = self.prepare_cot_video_latents(video, 0, weight_dtype, device, generator, latents,
                                                      source_latents)
+        self._stage("vae_encode", t_stage)
         B, _, Ftot, hl, wl = latents.shape
         ps = self.transformer.config.patch_size
         seq_len = math.ceil((hl * wl) / (ps[1] * ps[2]) * Ftot)                                 # :686-689
@@ -260,6 +279,7 @@ class WanPipeline:
                         latents = out.pop("latents", latents)
             return latents
 
+        t_stage = self._stage("denoise_loop")
         try:
             if capture_graph == "loop":
                 # the whole loop as ONE hipGraph (videocof_amd.GraphedLoop): first call of a signature eager, second captures
@@ -291,12 +311,16 @@ class WanPipeline:
                 self.transformer.skip_source_frames = prev_skip
             if prev_mask is not None:
                 self.transformer.mask_source_frames = prev_mask
-            if hasattr(self.transformer, "release_workspaces"):
-                # 7 GB of activation buffers at 14B / 67k tokens: hand them back before the VAE decode (and to whatever else
-                # shares the device); the sets a captured graph replays from stay
+            if self.release_workspaces_after_denoise and hasattr(self.transformer, "release_workspaces"):
+                # opt-in: 7 GB of activation buffers at 14B / 67k tokens handed back before the VAE decode (for hosts that share
+                # the device); the sets a captured graph replays from stay.  Off by default: 288 GB of HBM do not need it, every call
+                # would re-allocate and zero-fill the set, and in capture_graph='loop' mode the capture call would then allocate
+                # (and record the zero-fill of) its workspaces inside the graph.
                 self.transformer.release_workspaces(keep_pinned=True)
+        self._stage("denoise_loop", t_stage)
 
         # -- decode (:757-790)
+        t_stage = self._stage("vae_decode")
         ground_video = edit_video = video_out = None
         if output_type == "numpy":
             if self.vae is None:
@@ -321,4 +345,5 @@ class WanPipeline:
                 edit_video = torch.from_numpy(edit_video) if isinstance(edit_video, np.ndarray) else edit_video
         elif output_type != "latent":
             raise ValueError(f"output_type {output_type!r} not supported ('numpy' or 'latent')")
+        self._stage("vae_decode", t_stage)
         return WanPipelineOutput(videos=video_out, ground_videos=ground_video, edit_videos=edit_video, latents=latents)

@@ -313,8 +313,7 @@ class WanTransformer3DModel(nn.Module):
         self._device = dev
         self._ctx_cache = None
         self._graph_epoch += 1                         # new weight tensors
-        for ws in (self._ws_self, self._ws_cross, self._ws_self_sfx, self._ws_cross_sfx):
-            ws.reset()                                 # the sticky "max-free attempt off" word described the OLD weights' scores
+        self._reset_attention_scratch()                # the sticky "max-free attempt off" word described the OLD weights' scores
         if self._fp8:
             self.enable_fp8_linear(self._fp8, attn_smooth_k=self.fp8_attn_smooth_k)          # re-quantise from the new bf16 weights
         return IncompatibleKeys(missing, extra)
@@ -521,6 +520,7 @@ class WanTransformer3DModel(nn.Module):
         self._fp8 = layers
         self._bufs, self._bufs_last = {}, None
         self._graph_epoch += 1              # new e4m3 tensors: a graph captured before must not replay the old ones
+        self._reset_attention_scratch()
 
     def disable_fp8_linear(self):
         for blk in self.blocks:
@@ -528,6 +528,15 @@ class WanTransformer3DModel(nn.Module):
         self._fp8 = ()
         self._bufs, self._bufs_last = {}, None
         self._graph_epoch += 1
+        self._reset_attention_scratch()
+
+    def _reset_attention_scratch(self):
+        """The sticky "max-free attempt off" word of the attention scratches describes the scores of the weights and of the kernel
+        family that tripped it: whatever changes either (new weights, a LoRA merge, switching the fp8 attention kernels on or off)
+        starts the four call sites afresh, so that a trip of the old configuration never routes the new one through the attempt
+        plus a full fix-up for good."""
+        for ws in (self._ws_self, self._ws_cross, self._ws_self_sfx, self._ws_cross_sfx):
+            ws.reset()
 
     def clear_context_cache(self):
         """Drop the hoisted text K/V^T (0.8 GB at 14B) and the references that keep the prompt embeddings alive."""
