@@ -426,8 +426,6 @@ def main():
     model.load_state_dict(sd, device=dev)
     del sd
     if args.fp8:
-        if sp and not set(args.fp8_layers.split(",")) <= {"attn", "attn_pv"}:
-            raise SystemExit("--fp8 Linears cover the single-device forward (under Ulysses only --fp8-layers attn[,attn_pv])")
         model.enable_fp8_linear(tuple(args.fp8_layers.split(",")), attn_smooth_k=not args.fp8_no_smooth_k)
     if sp:
         vdist.init_sequence_parallel()

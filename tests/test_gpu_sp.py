@@ -340,6 +340,57 @@ def test_sp_over_the_library_owned_communicator():
     assert "in-place" in inplace_error
 
 
+def _sp_composition_worker(q_out):
+    """fp8 Linears under the Ulysses branch (library-owned communicator, one rank); graph capture of a sequence-parallel forward is
+    refused (videocof_amd/graph.py::_check_capturable says why)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    from videocof_amd import GraphedForward, WanTransformer3DModel
+    from videocof_amd import dist as vdist
+    from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+    heads, layers = 4, 3
+    cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=layers, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=layers, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+    lat = det_uniform("sp.lat", (1, 16, 7, 12, 20), 1.0).cuda()
+    ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda()]
+    t = torch.tensor([749], device="cuda:0")
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    bf16 = m(lat, t, ctx, 420, **kw)
+    m.enable_fp8_linear(("qkv", "ffn", "o", "cross"))
+    single8 = m(lat, t, ctx, 420, **kw)
+    vdist.init_sequence_parallel(backend="library", rank=0, world_size=1)
+    m.enable_multi_gpus_inference()
+    m.force_ulysses = True
+    sp8 = m(lat, t, ctx, 420, **kw)                           # fp8 projections + exchanges
+    again = m(lat, t, ctx, 420, **kw)
+    wb = m._bufs[m._bufs_last]
+    used = bool(m._usp and wb.vt is None and hasattr(wb, "hq"))
+    try:
+        GraphedForward(m)
+        refused = False
+    except NotImplementedError:
+        refused = True
+    torch.cuda.synchronize()
+    vdist.destroy_sequence_parallel()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    q_out.put((refused, used, rel(sp8, single8), rel(sp8, bf16), bool(torch.equal(again, sp8))))
+
+
+def test_fp8_linears_compose_with_ulysses():
+    """fp8 projections under sequence parallelism (q, k and V^T projected from the same e4m3 token rows, weight copies split by output
+    rows) == the single-device fp8 forward up to the projection split, bitwise repeatable, really different from bf16."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_sp_composition_worker, args=(q,))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    refused, used, rel_single, rel_bf16, again = q.get(timeout=5)
+    assert refused and used and again
+    assert rel_single < 5e-3 and 1e-4 < rel_bf16 < 3e-2, (rel_single, rel_bf16)
+
+
 def _shard_shape_worker(rank, world, port, q_out):
     """14B width (40 heads -> 5 per rank at P = 8: no XCD pinning, split-KV tail round on), L = 16 384."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"

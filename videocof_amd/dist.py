@@ -136,16 +136,39 @@ class SequenceParallelGroup:
 
     # [B, Ll, N] -> [B, P*Ll, N]
     def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
+        """The one all-gather of a forward (the head output, wan_transformer3d.py:1085-1086), into a PERSISTENT receive buffer
+        (one per shape, kept on the group): a forward allocates nothing for it.  The result is a view of that buffer (B = 1) or a
+        second persistent buffer filled by one permuting copy (B > 1); it is overwritten by the next call of the same shape."""
         P = self.world_size
         y = y.contiguous()
+        recv, out = _gather_buffers(self, y, P)
         if self._host_staged and y.is_cuda:
             yc = y.cpu()
             parts = [torch.empty_like(yc) for _ in range(P)]
             dist.all_gather(parts, yc, group=self.group)
-            return torch.cat(parts, dim=1).to(y.device)
-        parts = [torch.empty_like(y) for _ in range(P)]
-        dist.all_gather(parts, y, group=self.group)
-        return torch.cat(parts, dim=1)
+            recv.copy_(torch.stack(parts))
+        else:
+            dist.all_gather_into_tensor(recv.view(-1), y.view(-1), group=self.group)
+        return _gathered_view(recv, out)
+
+
+def _gather_buffers(owner, y: torch.Tensor, P: int):
+    """(receive buffer [P, B, T, N], output buffer [B, P, T, N] or None) of `owner` for inputs shaped like y -- allocated once."""
+    cache = owner.__dict__.setdefault("_ag_bufs", {})
+    key = (tuple(y.shape), y.dtype, str(y.device))
+    if key not in cache:
+        recv = torch.empty((P,) + tuple(y.shape), device=y.device, dtype=y.dtype)
+        out = None if y.shape[0] == 1 else torch.empty((y.shape[0], P) + tuple(y.shape[1:]), device=y.device, dtype=y.dtype)
+        cache[key] = (recv, out)
+    return cache[key]
+
+
+def _gathered_view(recv: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+    P, B, T = recv.shape[0], recv.shape[1], recv.shape[2]
+    if out is None:                                   # B == 1: [P, 1, T, N] is [1, P*T, N] as it stands
+        return recv.view(1, P * T, *recv.shape[3:])
+    out.copy_(recv.transpose(0, 1))
+    return out.view(B, P * T, *recv.shape[3:])
 
 
 class LibraryComm:
@@ -200,12 +223,12 @@ class LibraryComm:
     def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
         P = self.world_size
         y = y.contiguous()
-        recv = torch.empty((P,) + tuple(y.shape), device=y.device, dtype=y.dtype)
+        recv, out = _gather_buffers(self, y, P)       # persistent: nothing is allocated per forward
         lib, vp = self._lib.load(), self._ct.c_void_p
         self._lib.check(lib.wan_sp_all_gather(self._comm, vp(y.data_ptr()), vp(recv.data_ptr()), y.numel() * y.element_size(),
                                               self._stream()), "wan_sp_all_gather")
         self._lib.check(lib.wan_sp_wait(self._comm, self._stream()), "wan_sp_wait")
-        return torch.cat(list(recv), dim=1)
+        return _gathered_view(recv, out)
 
     def close(self):
         if getattr(self, "_comm", None):

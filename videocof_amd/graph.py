@@ -30,6 +30,15 @@ import torch
 __all__ = ["GraphedForward", "GraphedLoop"]
 
 
+def _check_capturable(model) -> None:
+    """Single device only.  Recording a sequence-parallel forward was tried in round 4 over the library-owned communicator (RCCL calls on
+    a side stream forked from and joined back into the capturing stream by events -- the fork / join pattern of stream capture): the
+    eager warm-up call is fine, `hipStreamEndCapture` then segfaults inside the runtime (ROCm 7.2, one rank, both capture-error modes;
+    profiles/r04/sp_graph_capture_rccl_segfault.log).  Until that is understood the collectives stay eager."""
+    if model.sp_world_size != 1 or getattr(model, "force_ulysses", False):
+        raise NotImplementedError("graph capture covers the single-device forward (collectives stay eager)")
+
+
 class _Entry:
     __slots__ = ("x", "t", "graph", "out", "calls", "kv", "epoch", "bufs", "attn_bufs")
 
@@ -38,8 +47,7 @@ class GraphedForward:
     """Callable with the signature of ``WanTransformer3DModel.forward`` (T2V / CoF arguments)."""
 
     def __init__(self, model, warmup_calls: int = 1):
-        if model.sp_world_size != 1:
-            raise NotImplementedError("graph capture covers the single-device forward (collectives stay eager)")
+        _check_capturable(model)
         self.model = model
         self.warmup_calls = max(1, int(warmup_calls))
         self._entries: Dict[tuple, _Entry] = {}
@@ -141,8 +149,7 @@ class GraphedLoop:
     later calls replay.  Entries pin their workspaces and follow the model's ``_graph_epoch`` exactly like ``GraphedForward``'s."""
 
     def __init__(self, model):
-        if model.sp_world_size != 1:
-            raise NotImplementedError("graph capture covers the single-device forward (collectives stay eager)")
+        _check_capturable(model)
         self.model = model
         self._entries: Dict[tuple, _LoopEntry] = {}
         self.replays = 0

@@ -490,7 +490,8 @@ class WanTransformer3DModel(nn.Module):
         per layer at the 14B shape); off: the RMSNorm+RoPE kernel writes the e4m3 operands directly.  "attn_pv" (with "attn"): the
         P.V product as well -- V^T is re-quantised per layer into MX e4m3 blocks of 32 keys (``wan_vt_quantize_mx``, 0.23 ms), P inside
         the kernel; SageAttention-2's operating point (``wan_attention_fwd_f8``, include/wan_hip.h a9'').  Under Ulysses sequence
-        parallelism the Linears stay bf16 and the two attention options run on each rank's arrived (bf16-wire) operands, batch 1 only.
+        parallelism the projections run in e4m3 as well (q, k and V^T are projected from the same e4m3 token rows, their weight copies
+        split by output rows); the wires stay bf16 and the two attention options run on each rank's arrived operands, batch 1 only.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
@@ -755,8 +756,8 @@ class WanTransformer3DModel(nn.Module):
         C, H, P, M = self.dim, self.num_heads, self.sp_world_size, B * Ll
         h, qk, att, cq, ff, vt, qk3 = bufs.h, bufs.qk, bufs.att, bufs.cq, bufs.ff, bufs.vt, bufs.qk3
         usp = self._usp
-        f8 = blk.f8 if (blk.f8 and not usp) else {}            # fp8 Linears: single-device path only (the bf16 weights serve Ulysses)
-        a8_sp = usp and bool(blk.f8) and "attn" in blk.f8       # the fp8 attention products also run on the arrived Ulysses operands
+        f8 = blk.f8 or {}                                       # fp8 Linears (every projection below has both forms, Ulysses included)
+        a8_sp = usp and "attn" in f8                            # the fp8 attention products also run on the arrived Ulysses operands
         if not usp and not f8 and self._attn_events is None and self.use_block_composite:
             # the same launch sequence as below, enqueued by ONE C call (wan_dit_block_forward): 1 FFI crossing instead of 15
             self._block_composite(blk, em, xs, bufs, ctx_kv, rp, B, Ll, L)
@@ -814,14 +815,22 @@ class WanTransformer3DModel(nn.Module):
             # ([P*Ll][B][C/P], uniform strides), the attention output IS the send buffer of the inverse exchange; the only
             # re-layout passes per layer are wan_sp_unpack_vt and wan_sp_unpack_heads (2 x M*C bf16 each way).
             sp, Cl, Lt = self._sp, C // P, P * Ll
-            ops.gemm(h, blk.w_qk[C:], blk.b_qk[C:], ops.EPI_BF16, out=qk[:, C:])
+            if "qk" in f8:          # e4m3 operands: the q | k weight copy and its per-output-channel scales split by rows like the bf16 one
+                w8, ws8 = f8["qk"]
+                proj = lambda rows, bias, out: ops.gemm_fp8(bufs.hq, bufs.rs, w8[rows], ws8[rows], bias, ops.EPI_BF16, out=out)
+                proj_vt = lambda b, out: ops.gemm_fp8(bufs.hq[b * Ll:(b + 1) * Ll], bufs.rs[b * Ll:(b + 1) * Ll], *f8["v"], blk.b_v,
+                                                      ops.EPI_BF16_T, out=out)
+            else:
+                proj = lambda rows, bias, out: ops.gemm(h, blk.w_qk[rows], bias, ops.EPI_BF16, out=out)
+                proj_vt = lambda b, out: ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=out)
+            proj(slice(C, 2 * C), blk.b_qk[C:], qk[:, C:])
             ops.rmsnorm_rope_sp(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp, bufs.kw_s, None, P, B)
             wait_k = sp.exchange(bufs.kw_r, bufs.kw_s, async_op=True)
             vsend = bufs.vw_s.view(C, B, Ll)
             for b in range(B):
-                ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=vsend[:, b])
+                proj_vt(b, vsend[:, b])
             wait_v = sp.exchange(bufs.vw_r, bufs.vw_s, async_op=True)
-            ops.gemm(h, blk.w_qk[:C], blk.b_qk[:C], ops.EPI_BF16, out=qk[:, :C])
+            proj(slice(0, C), blk.b_qk[:C], qk[:, :C])
             ops.rmsnorm_rope_sp(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, bufs.qw_s, None, P, B,
                                 x0_scale=self._qs)
             wait_q = sp.exchange(bufs.qw_r, bufs.qw_s, async_op=True)
