@@ -387,6 +387,74 @@ def test_attention_f8_error_statement(Lq, Lk, H, qstd):
         assert redone > 0
 
 
+@pytest.mark.parametrize("qstd", [1.0, 4.0, 10.0, 30.0])
+def test_fp8_attention_where_the_mode_stops(qstd):
+    """MODE statement over the score scale (log2-domain scores ~ N(0, (1.44 * qstd)^2)): with exponents that keep q and k out of the e4m3
+    clamp (what the per-layer calibration of `enable_fp8_linear` picks) the error of both fp8 attention kernels against the bf16 operands
+    is the 3-mantissa-bit rounding of q and k alone -- a score moves by ~4 % of |q||k| / sqrt(d), i.e. in proportion to the score
+    scale, until softmax becomes a hard arg-max that the rounding flips.  The static exponents (5, 2) additionally saturate once
+    |q| * 2^5 > 448 (q std >~ 4).  Bounds asserted per scale; DESIGN.md section 13 quotes them."""
+    g = torch.Generator(device=DEV).manual_seed(77)
+    Lq, Lk, H = 256, 4096, 2
+    C = H * 128
+    q = (torch.randn(Lq, C, device=DEV, generator=g) * qstd * ops.q_prescale(128)).bfloat16()
+    k = torch.randn(Lk, C, device=DEV, generator=g).bfloat16()
+    v = (torch.randn(Lk, C, device=DEV, generator=g) + torch.linspace(-1, 1, C, device=DEV)).bfloat16()
+    vt = ops.transpose_pad(v)[None]
+    v8, vs = ops.vt_quantize_mx(vt, H, Lk)
+    ref16 = _attention_ref_log2(q.view(-1, H, 128), k.view(-1, H, 128), v.view(-1, H, 128), Lk)
+    pick = lambda t: int(max(-8, min(8, math.floor(math.log2(448.0 / float(t.float().abs().max()))) - 1)))
+    res = {}
+    for name, (qe, ke) in (("static", (5, 2)), ("calibrated", (pick(q), pick(k)))):
+        q8 = (q.float() * 2.0 ** qe).clamp(-448, 448).to(ops.FP8)
+        k8 = (k.float() * 2.0 ** ke).clamp(-448, 448).to(ops.FP8)
+        sat = float(((q.float() * 2.0 ** qe).abs() > 448).float().mean())
+        o_qk8 = ops.attention_fwd_qk8(q8[None], k8[None], vt, H, qe, ke, k_len=Lk)[0]
+        o_f8 = ops.attention_fwd_f8(q8[None], k8[None], v8, vs, vt, H, qe, ke, k_len=Lk, workspace=ops.AttentionWorkspace())[0]
+        res[name] = (rel_l2(o_qk8.view(-1, H, 128), ref16), rel_l2(o_f8.view(-1, H, 128), ref16), sat, (qe, ke))
+    o16 = ops.attention_fwd(q[None], k[None], vt, H, k_len=Lk, q_prescaled=True)[0]
+    e16 = rel_l2(o16.view(-1, H, 128), ref16)
+    print(f"fp8 attention, q std {qstd}: bf16 kernel {e16:.2e}; static exponents {res['static'][3]}: QK^T fp8 {res['static'][0]:.2e}, all fp8 "
+          f"{res['static'][1]:.2e}, {100 * res['static'][2]:.1f} % of q clamped; calibrated {res['calibrated'][3]}: {res['calibrated'][0]:.2e}, "
+          f"{res['calibrated'][1]:.2e}, {100 * res['calibrated'][2]:.1f} % clamped")
+    assert res["calibrated"][2] == 0.0 and e16 < 6e-3
+    bound = {1.0: 6e-2, 4.0: 1.2e-1, 10.0: 2.0e-1, 30.0: 3.0e-1}[qstd]
+    assert res["calibrated"][0] < bound and res["calibrated"][1] < bound + 2e-2
+    assert res["calibrated"][0] <= res["static"][0] * 1.05
+
+
+def test_fp8_attention_exponents_are_calibrated_per_layer():
+    """`enable_fp8_linear(("attn", ...))` measures each layer's q / k range on the first forward (K smoothing on) and keeps the exponents:
+    a model whose norm_q / norm_k gains put the static exponents into the e4m3 clamp stays closer to its bf16 forward than with the
+    static pair; the exponents differ per layer, survive later forwards, and are re-measured after a weight change."""
+    cfg = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    sd = deterministic_dit_state_dict(**cfg)
+    for i, gain in enumerate((40.0, 3.0)):
+        sd[f"blocks.{i}.self_attn.norm_q.weight"] = sd[f"blocks.{i}.self_attn.norm_q.weight"] * gain
+    m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    m.load_state_dict(sd, device=DEV)
+    lat = det_uniform("fp8c.lat", (1, 16, 7, 12, 20), 1.0).to(DEV)
+    ctx = [det_uniform("fp8c.ctx", (37, 64), 1.0).to(DEV)]
+    t = torch.tensor([899], device=DEV)
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    bf = m(lat, t, ctx, 420, **kw)
+    m.fp8_attn_calibrate = False
+    m.enable_fp8_linear(("attn", "attn_pv"))
+    static = m(lat, t, ctx, 420, **kw)
+    assert all("attn_exp" not in b.f8 for b in m.blocks)
+    m.fp8_attn_calibrate = True
+    m.enable_fp8_linear(("attn", "attn_pv"))
+    cal = m(lat, t, ctx, 420, **kw)
+    exps = [b.f8["attn_exp"] for b in m.blocks]
+    assert exps[0][0] < exps[1][0] and torch.equal(m(lat, t, ctx, 420, **kw), cal) and [b.f8["attn_exp"] for b in m.blocks] == exps
+    e_static, e_cal = rel_l2(static, bf), rel_l2(cal, bf)
+    print(f"small DiT with norm_q gains x40 / x3: all-fp8 attention vs bf16 forward: static exponents {e_static:.2e}, calibrated {exps}: {e_cal:.2e}")
+    assert e_cal < e_static             # layer 0's q * 2^5 sits in the e4m3 clamp with the static pair
+    m.load_state_dict(deterministic_dit_state_dict(**cfg), device=DEV)          # new weights: the fp8 state is rebuilt, exponents re-measured
+    m(lat, t, ctx, 420, **kw)
+    assert [b.f8["attn_exp"] for b in m.blocks] != exps
+
+
 def test_fp8_attention_kernels_batch_strides():
     """B = 2 (the CFG batch): the e4m3 q / k, the MX V^T and its scales are indexed per sample -- a batched call equals two single calls bit
     for bit, for the fp8-QK^T kernel and for the all-fp8 one."""

@@ -84,7 +84,7 @@ class GraphedForward:
         key = (tuple(x.shape), x.dtype, key_t, int(seq_len), tuple(frame_split_indices or ()),
                tuple(tuple(g) for g in (ground_frame_indices or ())), int(m.skip_source_frames),
                int(m.mask_source_frames), len(context), torch.cuda.current_device(), tuple(m._fp8),
-               bool(m.use_block_composite), bool(m.use_forward_composite), tuple(m.fp8_attn_exponents), bool(m.fp8_attn_smooth_k))
+               bool(m.use_block_composite), bool(m.use_forward_composite), tuple(m.fp8_attn_exponents), bool(m.fp8_attn_smooth_k), bool(getattr(m, 'fp8_attn_calibrate', False)))
         epoch = m._graph_epoch
         for k in [k for k, e in self._entries.items() if e.epoch != epoch]:
             stale = self._entries.pop(k)                 # weights / fp8 copies / workspaces were replaced since the capture
@@ -176,7 +176,7 @@ class GraphedLoop:
         T, D = m.text_len, m.text_dim
         key = key + (tuple(latents.shape), latents.dtype, len(context), torch.cuda.current_device(), tuple(m._fp8),
                      bool(m.use_block_composite), bool(m.use_forward_composite), int(m.skip_source_frames), int(m.mask_source_frames),
-                     tuple(m.fp8_attn_exponents), bool(m.fp8_attn_smooth_k))
+                     tuple(m.fp8_attn_exponents), bool(m.fp8_attn_smooth_k), bool(getattr(m, 'fp8_attn_calibrate', False)))
         epoch = m._graph_epoch
         for k in [k for k, e in self._entries.items() if e.epoch != epoch]:
             stale = self._entries.pop(k)

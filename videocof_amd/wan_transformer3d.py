@@ -130,6 +130,11 @@ class WanTransformer3DModel(nn.Module):
         self._ctx_cache = None
         self._fp8 = ()                      # enable_fp8_linear: which projections run in e4m3 (lossy, opt-in)
         self.fp8_attn_exponents = (5, 2)    # "attn": q8 = e4m3(q * scale * log2e * 2^5), k8 = e4m3(k * 2^2) (include/wan_hip.h a9')
+        # "attn" with K smoothing: replace the two static exponents by per-LAYER ones measured on the first forward after
+        # enable_fp8_linear (the largest |q| and |k - mean| of that layer's operands, one bit of head-room): a checkpoint whose q / k
+        # gains put the static choice into the e4m3 clamp (+-448) no longer saturates.  What calibration cannot buy is precision:
+        # 3 mantissa bits move a log2-domain score by ~4 % of |q||k|/sqrt(d) -- DESIGN.md section 13 states where the mode stops.
+        self.fp8_attn_calibrate = True
         self.fp8_attn_smooth_k = True       # "attn": quantise k - mean_tokens(k) (sageattn's smooth_k; softmax-invariant)
         self.use_block_composite = True     # single-device blocks through wan_dit_block_forward (one C call per block)
         self.use_forward_composite = True   # ... and, when nothing hooks into the block loop, the whole token path through wan_dit_forward
@@ -768,13 +773,27 @@ class WanTransformer3DModel(nn.Module):
         else:
             ops.ln_modulate(xs, em[1], em[0], True, Ll, self.eps, out=h)
         a8 = "attn" in f8                 # QK^T on the fp8 matrix pipe: the norm+rope kernel writes e4m3 q / k instead of bf16
-        qe, ke = self.fp8_attn_exponents
+        qe, ke = f8.get("attn_exp") or self.fp8_attn_exponents
+
+        def calibrate(q_bf16, k_bf16, mean, rows_per_batch):
+            """Per-layer exponents from this call's operands (first forward after enable_fp8_linear; one host sync per layer, once)."""
+            nonlocal qe, ke
+            if not (self.fp8_attn_calibrate and "attn_exp" not in f8) or torch.cuda.is_current_stream_capturing():
+                return
+            kc = k_bf16.float()
+            if mean is not None:
+                kc = kc.view(mean.shape[0], rows_per_batch, -1) - mean[:, None, :].float()
+            aq, ak = float(q_bf16.float().abs().max()), float(kc.abs().max())
+            pick = lambda a: int(max(-8, min(8, math.floor(math.log2(448.0 / max(a, 1e-30))) - 1)))
+            qe, ke = pick(aq), pick(ak)
+            f8["attn_exp"] = (qe, ke)
 
         def norm_rope():
             if a8 and self.fp8_attn_smooth_k:
                 # K smoothing (sageattn's smooth_k): the bf16 norm + rope as usual, the per-sample token mean of k, then e4m3 q and k - mean
                 ops.rmsnorm_rope_(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, x0_scale=self._qs)
                 ops.col_mean(qk[:, C:], Ll, L, B, out=bufs.kmean, workspace=bufs.kmean_ws)
+                calibrate(qk[:, :C], qk[:, C:], bufs.kmean, Ll)
                 ops.qk_quantize_fp8(qk[:, :C], qk[:, C:], Ll, bufs.kmean, 2.0 ** qe, 2.0 ** ke, bufs.q8, bufs.k8)
             elif a8:
                 ops.rmsnorm_rope_fp8(qk[:, :C], blk.nq, qk[:, C:], blk.nk, self.d, self.eps, self._rope_dev, rp, bufs.q8, bufs.k8,
@@ -851,6 +870,8 @@ class WanTransformer3DModel(nn.Module):
                 mean = None
                 if self.fp8_attn_smooth_k:
                     mean = ops.col_mean(k_arr, Lt, L, 1, out=bufs.kmean.view(-1)[:Cl].view(1, Cl), workspace=bufs.kmean_ws)
+                    if self.sp_world_size == 1:       # (ranks would have to agree on the exponents: calibration is single-process)
+                        calibrate(q_arr, k_arr, mean, Lt)
                 ops.qk_quantize_fp8(q_arr, k_arr, Lt, mean, 2.0 ** qe, 2.0 ** ke, q8v, k8v)
                 if "attn_pv" in blk.f8:
                     ops.vt_quantize_mx(bufs.vt_full, H // P, L, v8=bufs.v8, scales=bufs.v8s)
