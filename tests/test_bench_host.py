@@ -96,8 +96,11 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     lib = _lib.load()
     L, C, F, H = 67080, 5120, 13824, 40
     for (M, N, K) in ((L, 2 * C, C), (L, C, C), (L, F, C), (L, C, F)):
-        kernel = _lib.GEMM_VARIANT_KERNELS[lib.wan_gemm_plan(M, N, K)]
-        assert kernel == "gemm_w4_kernel" and seen(kernel), (M, N, K, kernel, paths[-1])
+        # the model's Linears bring a workspace (ops.gemm / wan_dit_block_forward -> wan_gemm_bf16_ws): the persistent stream-K kernel;
+        # without one the same shapes stay on the 4-wave one-workgroup-per-tile kernel
+        kernel = _lib.GEMM_VARIANT_KERNELS[lib.wan_gemm_ws_plan(M, N, K)]
+        assert kernel == "gemm_pk_kernel" and seen(kernel), (M, N, K, kernel, paths[-1])
+        assert _lib.GEMM_VARIANT_KERNELS[lib.wan_gemm_plan(M, N, K)] == "gemm_w4_kernel" and lib.wan_gemm_workspace_bytes(M, N, K) > 0
     ws = lib.wan_attention_workspace_bytes(1, L, L, H, 128)
     v = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED, ws)
     assert v & 15 == 2 and v & _lib.ATTN_VARIANT_XCD_PINNED and v & _lib.ATTN_VARIANT_SPLIT_TAIL       # max-free attempt + fix-up
