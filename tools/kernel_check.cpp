@@ -506,6 +506,13 @@ int main(int argc, char** argv) {
             Dev<char> out(osz); out.zero();
             const int64_t wsb = wan_gemm_workspace_bytes(g.M, g.N, g.K);
             Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            if (wan_get_tuning("gemm_exp") & 64) {          // experiment builds: where a workgroup's cycles go (s_memtime stamps, thread 0 of workers 0..127)
+                WAN(wan_gemm_bf16_ws(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi, g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, ws.p, wsb, nullptr));
+                HIP(hipDeviceSynchronize());
+                std::vector<int> h(1024); HIP(hipMemcpy(h.data(), ws.p, 4096, hipMemcpyDeviceToHost));
+                double a = 0, b = 0, c = 0; for (int w = 0; w < 128; ++w) { a += h[640 + 3 * w]; b += h[641 + 3 * w]; c += h[642 + 3 * w]; }
+                printf("  cycles[%-18s] segment start %.1f %%, K loop %.1f %%, epilogue + switch %.1f %%  (total %.0f x16 ticks per workgroup)\n", g.what, 100 * a / (a + b + c), 100 * b / (a + b + c), 100 * c / (a + b + c), (a + b + c) / 128);
+            }
             for (int round = 0; round < 2; ++round)
                 for (int arm = 0; arm < 2; ++arm) {
                     double ms = time_ms([&] { WAN(wan_gemm_bf16_ws(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,

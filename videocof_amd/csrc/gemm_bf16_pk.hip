@@ -28,6 +28,10 @@
 
 #include "common.hpp"
 
+#ifndef WAN_DEV_EXPERIMENTS
+#define WAN_DEV_EXPERIMENTS 0
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -51,6 +55,7 @@ struct PkArgs {
     int nworkers;         // grid size (multiple of 8)
     int min_units;        // smallest stream-K range worth a worker (units of two K tiles)
     int sched;            // main-loop schedule: 0 = one barrier per K tile (requests in two bursts), 1 = schedule D (see the kernel)
+    int exp;              // `make EXPERIMENTS=1` builds only (gemm_exp), TIMING ONLY: bit 5 = no epilogue at all, bit 6 = s_memtime stamps (where a workgroup's cycles go)
     int dynamic;          // whole tiles by ticket from the per-XCD counters (1) or in lockstep order (0: developer A/B)
     int* counters;        // workspace head: [0, nworkers) arrival counters of the split tiles, [512 + 16 x] the ticket counter of XCD x
     char* slots;          // workspace + kCounterBytes: 2 slots of 256 KiB per worker
@@ -378,6 +383,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
     }
 
+#if WAN_DEV_EXPERIMENTS
+    long long t_start = 0, t_loop = 0, t_epi = 0, t_mark = __builtin_readcyclecounter();
+#define GP_STAMP(ACC) do { if (g.exp & 64) { const long long n_ = __builtin_readcyclecounter(); ACC += n_ - t_mark; t_mark = n_; } } while (0)
+#else
+#define GP_STAMP(ACC) do { } while (0)
+#endif
     for (;;) {
         // ---- segment start: K tile cur.kb sits in buffer 0 (published), the A half of cur.kb + 1 is in flight
 #pragma unroll
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < 16; ++f) fetch(0, f, 0);
+        GP_STAMP(t_start);
         if constexpr (SCHED == 1) {
             for (int kt = cur.kb; kt < cur.ke; kt += 2) {
                 ktile_d(kt, 0);
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads below
+        GP_STAMP(t_loop);
 
         // ---- partial segment: publish my piece, take a ticket; only the last arriver goes on to the epilogue
         bool reduce = false;
@@ -425,6 +438,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
 
+#if WAN_DEV_EXPERIMENTS
+        if ((g.exp & 32) == 0)
+#endif
         if (!cur.partial || reduce) {
             const int m0 = cur.tm * BM, n0 = cur.tn * BN;
             // last arriver of a split tile: the pieces added IN K ORDER (mine from registers), tile by tile, back into my
@@ -468,6 +484,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                 // columns n = .. + 4 kg .. + 3.  A batch = one m tile x four n tiles (one row, four float4 per lane): bias, residual stream and
                 // gate rows of a batch are loaded back to back, one batch ahead of their use.  Out-of-range rows / columns read a clamped
                 // address and are not stored.  (The wave-uniform options -- bias? gate? -- select straight-line copies.)
+                // (wave-uniform: all 128 columns of the wave exist and every 8-column group is 16-byte aligned)
+                const bool wide = n0 + wc * 128 + 128 <= g.N && (g.ldo & 7) == 0 && (((uintptr_t)g.out) & 15) == 0;
                 auto epilogue_rows = [&](auto has_bias, auto has_gate) {
                     constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_GATE = decltype(has_gate)::value;
                     const int rpb = HAS_GATE ? (int)g.rows_per_batch : 1;
@@ -496,6 +514,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                         }
                     };
                     auto store_batch = [&](int bi, const Batch& B) {
+                        unsigned pk[4][2];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 a = acc[bi >> 1][(bi & 1) * 4 + q];
@@ -504,12 +523,35 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
                             }
+                            if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
+                                // 16-byte stores (CDNA4 guide T21): the tiles (q, q + 1) of a pair trade halves between lanes 16 apart --
+                                // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second
+                                // -- after which lane groups 0 / 2 own columns 0..7 / 8..15 of tile q and groups 1 / 3 those of tile
+                                // q + 1: a store instruction then covers 16 rows x 64 contiguous bytes instead of 16 x 32, and there
+                                // are half as many of them (the epilogue of a lone workgroup per CU is bound by store ISSUE)
+                                pk[q][0] = pack_bf16x2(v[0], v[1]); pk[q][1] = pack_bf16x2(v[2], v[3]);
+                                if (q & 1) {
+                                    if (wide) {
+                                        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[q - 1][0]), "+v"(pk[q][0]));
+                                        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[q - 1][1]), "+v"(pk[q][1]));
+                                        // this lane now holds 8 columns of tile q - 1 + (kg & 1): columns 8 (kg >> 1) .. + 7 of it
+                                        const int col = n0 + wc * 128 + ((bi & 1) * 4 + q - 1 + (kg & 1)) * 16 + (kg >> 1) * 8;
+                                        const u32x4 o = {pk[q - 1][0], pk[q - 1][1], pk[q][0], pk[q][1]};
+                                        if (B.mok) *reinterpret_cast<u32x4*>((bf16_t*)g.out + (int64_t)B.mm * g.ldo + col) = o;
+                                    } else {
+#pragma unroll
+                                        for (int qq = q - 1; qq <= q; ++qq) {
+                                            if (!(B.mok && B.nok[qq])) continue;
+                                            const u32x2 o = {pk[qq][0], pk[qq][1]};
+                                            *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)B.mm * g.ldo + B.nn[qq]) = o;
+                                        }
+                                    }
+                                }
+                                continue;
+                            }
                             if (!(B.mok && B.nok[q])) continue;
                             const int64_t off = (int64_t)B.mm * g.ldo + B.nn[q];
-                            if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
-                                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                                *reinterpret_cast<u32x2*>((bf16_t*)g.out + off) = o;
-                            } else if constexpr (EPI == WAN_EPI_F32) {
+                            if constexpr (EPI == WAN_EPI_F32) {
                                 *reinterpret_cast<float4*>((float*)g.out + off) = make_float4(v[0], v[1], v[2], v[3]);
                             } else {
                                 *reinterpret_cast<float4*>((float*)g.out + off) =
@@ -568,6 +610,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
 
+        GP_STAMP(t_epi);
         // ---- advance the stream
         if (!nxt.valid) break;
         cur = nxt; pc = pn;
@@ -584,6 +627,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         pn = panel(nxt);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // zero-length requests past the last segment still write LDS: let them finish
+#if WAN_DEV_EXPERIMENTS
+    if ((g.exp & 64) && tid == 0 && blockIdx.x < 128) {          // counters words [640, 1024) are free
+        g.counters[640 + 3 * blockIdx.x] = (int)(t_start >> 4); g.counters[641 + 3 * blockIdx.x] = (int)(t_loop >> 4); g.counters[642 + 3 * blockIdx.x] = (int)(t_epi >> 4);
+    }
+#endif
+#undef GP_STAMP
 #undef GP_MFMA
 #undef GP_MFMA_A
 #undef GP_MFMA_V
@@ -638,6 +687,7 @@ static void pk_plan_args(PkArgs& g, int M, int N, int K) {
     if (const int mu = wan_tune(WAN_TUNE_GEMM_PK_MIN_UNITS); mu > 0) g.min_units = mu;
     g.dynamic = wan_tune(WAN_TUNE_GEMM_PK_ORDER) != 1;
     g.sched = wan_tune(WAN_TUNE_GEMM_PK_SCHED);
+    g.exp = wan_tune(WAN_TUNE_GEMM_EXP);
 }
 
 // Host arithmetic only: segment `index` of worker `worker` of the persistent GEMM's plan for this shape -- the SAME functions the
