@@ -688,6 +688,35 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
 
 
+def test_persistent_gemm_beyond_4gib():
+    """gemm_pk_kernel where byte offsets leave 32 bits (BASELINE configs[4] on one device: 586 800 tokens x 5 120 fp32 = 12 GB of
+    residual stream, 16 GB of ffn activations): an A operand of 4.4 GB (M = 330 000 rows of K = 6 656) and an fp32 read-modify-write
+    output of 4.7 GB (N = 3 584), sampled rows on both sides of the 2^31 / 2^32-byte marks against an fp64 product."""
+    from videocof_amd import _lib
+    M, N, K = 330000, 3584, 6656
+    assert M * K * 2 > 2 ** 32 and M * N * 4 > 2 ** 32
+    assert _lib.load().wan_gemm_ws_plan(M, N, K) == 3
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+    for r0 in range(0, M, 66000):                      # (filled in slabs: a 4.4 GB randn in fp32 would be 8.8 GB of temporaries)
+        a[r0:r0 + 66000] = torch.randn(min(66000, M - r0), K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    rows = torch.tensor([0, 255, 256, 161319, 161320, 299592, 299593, 322638, 322639, 329999], device=DEV)
+    want = a[rows].double() @ w.double().t() + bias.double()
+    o = ops.gemm(a, w, bias, ops.EPI_BF16)
+    assert rel_l2(o[rows], want) < 4e-3
+    del o
+    x = torch.zeros(M, N, device=DEV)
+    x[rows] = 1.0
+    ops.gemm(a, w, None, ops.EPI_RESID_F32, out=x)
+    assert rel_l2(x[rows], want - bias.double() + 1.0) < 1e-5
+    # the rows nobody sampled: no row written twice or skipped -- column sums against a GEMV (one row off moves them by ~2e-3)
+    cs = (x.sum(dim=0, dtype=torch.float64) - len(rows)).cpu()
+    ref = (a.float().sum(dim=0, dtype=torch.float64) @ w.double().t()).cpu()
+    assert rel_l2(cs, ref) < 2e-4
+
+
 @pytest.mark.parametrize("P,T,B,Cl", [(2, 24, 2, 128), (8, 56, 1, 640), (4, 8, 3, 8)])
 def test_sp_wire_layout_kernels(rope_dev, P, T, B, Cl):
     """wan_sp_pack_heads / wan_sp_unpack_heads / wan_sp_unpack_vt move bytes exactly like the torch statements of the
