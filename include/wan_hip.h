@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 6      /* 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
+#define WAN_ABI_VERSION 7      /* 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -317,6 +317,11 @@ wan_status_t wan_unpatchify(const float* tokens, int64_t ldt, void* out, int out
  *      wan_sp_pack_heads / wan_sp_unpack_heads: [B][T][ldx >= P*Cl] <-> token-major wire (the o projection's input).
  *      wan_sp_unpack_vt: arrived channel-major wire -> vt [B][Cl][ldvt], column s*T + t (ldvt >= P*T; pad columns untouched).
  *      Cl % 8 == 0, T % 8 == 0.
+ *      *_split (head-group pipelining): the same kernels on a wire buffer cut into TWO head groups -- channels
+ *                           [0, split) of every slab, then channels [split, Cl) -- each a complete token-major wire buffer of its
+ *                           own ([P][T][B][split], then [P][T][B][Cl - split] right behind it), so that each group travels in its own
+ *                           all-to-all: the exchange of group 1 runs under the attention of group 0, the inverse exchange of group 0
+ *                           under the attention of group 1.  split % 8 == 0, 0 <= split < Cl; split = 0 is the one-group layout.
  * ------------------------------------------------------------------------- */
 wan_status_t wan_rmsnorm_rope_sp(const void* x0_bf16, const float* w0, const void* x1_bf16, const float* w1,
                                  int64_t ld, int64_t rows, int dim, int head_dim, float eps,
@@ -325,6 +330,12 @@ wan_status_t wan_rmsnorm_rope_sp(const void* x0_bf16, const float* w0, const voi
 wan_status_t wan_sp_pack_heads(const void* x_bf16, int64_t ldx, void* wire, int P, int T, int B, int Cl, void* stream);
 wan_status_t wan_sp_unpack_heads(const void* wire, void* x_bf16, int64_t ldx, int P, int T, int B, int Cl, void* stream);
 wan_status_t wan_sp_unpack_vt(const void* wire, void* vt_bf16, int64_t ldvt, int P, int B, int Cl, int T, void* stream);
+wan_status_t wan_rmsnorm_rope_sp_split(const void* x0_bf16, const float* w0, const void* x1_bf16, const float* w1,
+                                       int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                       const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                       float x0_scale, void* wire0, void* wire1, int slabs, int batch, int split, void* stream);
+wan_status_t wan_sp_pack_heads_split(const void* x_bf16, int64_t ldx, void* wire, int P, int T, int B, int Cl, int split, void* stream);
+wan_status_t wan_sp_unpack_heads_split(const void* wire, void* x_bf16, int64_t ldx, int P, int T, int B, int Cl, int split, void* stream);
 
 /* a21' The collective itself, owned by the library (for a host without torch.distributed; the Python host may use either):
  *      one communicator = one RCCL comm + ONE side HIP stream + a small ring of events (one per exchange in flight).

@@ -90,6 +90,33 @@ def _worker(rank, world, port, L, H, q_out):
         sp.exchange(orecv, osend)                                               # slab r of [P*Ll][B][Cl] = rank r's token rows
         o_wire = sp.unpack_heads_ref(orecv.view(world, Ll, B, Cl))
         err = max(err, float((o_wire - o_ref).abs().max()))
+        # --- head-group pipelining (wan_*_split): q and o as TWO head groups, each a complete wire buffer with its
+        #     own all-to-all and its own attention call (k / V^T of a group are slices of the whole arrived operands)
+        if Hs >= 2:
+            split = (Hs // 2) * D
+            n0 = Lt * B * split
+            qs = sp.split_wire_ref(qa, split)                                  # what wan_rmsnorm_rope_sp_split writes
+            qg = torch.empty_like(qs)
+            w0 = sp.exchange(qg[:n0], qs[:n0], async_op=True)
+            w1 = sp.exchange(qg[n0:], qs[n0:], async_op=True)
+            w0(); w1()
+            mine = q[:, :, rank * Cl:(rank + 1) * Cl]
+            assert torch.equal(qg[:n0].view(Lt, B, split).permute(1, 0, 2), mine[..., :split])
+            assert torch.equal(qg[n0:].view(Lt, B, Cl - split).permute(1, 0, 2), mine[..., split:])
+            og = torch.empty(Lt * B * Cl)
+            for lo, hi, view in ((0, split, og[:n0].view(Lt, B, split)), (split, Cl, og[n0:].view(Lt, B, Cl - split))):
+                hg = (hi - lo) // D
+                qv = (qg[:n0].view(Lt, B, split) if lo == 0 else qg[n0:].view(Lt, B, Cl - split))
+                for b in range(B):
+                    view[:, b] = O.attention(qv[:, b].reshape(Lt, hg, D), kr.view(Lt, B, Cl)[:, b, lo:hi].reshape(Lt, hg, D),
+                                             vt_full[b, lo:hi, :Lp].t().reshape(Lt, hg, D), k_len=L).reshape(Lt, hi - lo)
+            ogr = torch.empty_like(og)
+            w0 = sp.exchange(ogr[:n0], og[:n0], async_op=True)                 # group 0 travels while group 1 is computed
+            sp.exchange(ogr[n0:], og[n0:])
+            w0()
+            o_grp = sp.unpack_heads_ref(sp.join_wire_ref(ogr, world, Ll, B, Cl, split))
+            err = max(err, float((o_grp - o_ref).abs().max()))
+            assert torch.equal(sp.join_wire_ref(qs, world, Ll, B, Cl, split), qa)
         with pytest.raises(ValueError):
             sp.exchange(torch.empty(7), torch.empty(7))
         # --- final token all-gather
@@ -101,7 +128,7 @@ def _worker(rank, world, port, L, H, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H", [(2, 2), (4, 4)])
+@pytest.mark.parametrize("world,H", [(2, 2), (4, 4), (2, 4)])
 def test_ulysses_exchange_and_sharded_attention(world, H):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

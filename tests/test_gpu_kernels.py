@@ -751,6 +751,20 @@ def test_sp_wire_layout_kernels(rope_dev, P, T, B, Cl):
         ops.rmsnorm_rope_sp(xin, w, None, None, 128, 1e-6, rope_dev, rp, w2, None, P, B, x0_scale=0.37)
         assert torch.equal(xin, keep)                                           # the input is not modified
         assert torch.equal(w2.view(P, T, B, Cl), ref("pack_heads_ref", inplace.view(B, T, C)))
+        if Cl >= 256:                                                           # two head groups (the *_split entry points)
+            split = (Cl // 128 // 2) * 128
+            w3 = torch.empty_like(w2)
+            ops.rmsnorm_rope_sp(xin, w, None, None, 128, 1e-6, rope_dev, rp, w3, None, P, B, x0_scale=0.37, split=split)
+            assert torch.equal(w3, SequenceParallelGroup.split_wire_ref(w2.view(P, T, B, Cl), split))
+    for split in ([8 * (Cl // 16)] if Cl >= 16 else []):
+        flat = SequenceParallelGroup.split_wire_ref(want, split)
+        w4 = torch.empty_like(wire)
+        ops.sp_pack_heads(x, w4, P, T, B, split=split)
+        assert torch.equal(w4, flat)
+        assert torch.equal(SequenceParallelGroup.join_wire_ref(flat, P, T, B, Cl, split), want)
+        back2 = torch.zeros_like(back)
+        ops.sp_unpack_heads(flat, back2, P, T, B, split=split)
+        assert torch.equal(back2, back)
 
 
 def test_attention_debug_check_catches_non_finite_vt_padding():

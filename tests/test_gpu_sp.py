@@ -42,8 +42,12 @@ def _worker(rank, world, port, q_out, heads):
         m.enable_multi_gpus_inference()
         assert m.sp_world_size == world and m.sp_world_rank == rank
         sharded = m(lat, t, ctx, 420, **kw)              # 420 tokens -> padded to a multiple of 8 * world
+        m.sp_head_groups = 1                             # one exchange / one attention launch per layer instead of head groups
+        one_group = m(lat, t, ctx, 420, **kw)
         torch.cuda.synchronize()
         rel = float((sharded - single).norm() / single.norm())
+        # heads are independent and no split tail at this size: the head-group pipeline must not change a bit
+        assert torch.equal(one_group, sharded) or heads // world < 2
         q_out.put((rank, rel, float(single.abs().mean())))
     finally:
         dist.destroy_process_group()
@@ -145,6 +149,12 @@ def _rccl_ws1_worker(port, q_out):
         wb = m._bufs[m._bufs_last]
         assert m._usp and wb.vt is None and wb.kw_s is not None     # really the wire-buffer branch
         again = m(lat, t, ctx, 420, **kw)                 # persistent wire buffers reused: a reuse hazard shows up here
+        m.sp_head_groups = 1                              # (4 local heads: the default ran 2 | 2 head groups)
+        m._comm_events = None
+        one_group = m(lat, t, ctx, 420, **kw)
+        assert torch.equal(one_group, sharded), "head-group pipelining changed the result"
+        m.sp_head_groups = 2
+        m._comm_events = comm
         lat2 = det_uniform("sp.lat2", (2, 16, 7, 12, 20), 1.0).cuda()
         other = m(lat2, t, ctx, 420, **kw)                # other data through the same buffers ...
         third = m(lat, t, ctx, 420, **kw)                 # ... and back
@@ -414,11 +424,14 @@ def _shard_shape_worker(rank, world, port, q_out):
         vdist.init_sequence_parallel()
         m.enable_multi_gpus_inference()
         ev = m._attn_events = []
+        grouped = m(lat, t, ctx, 16384, **kw)            # default: head groups 2 | 3 (128 + 192 workgroups: no tail round)
+        m.sp_head_groups = 1                             # all 5 local heads in one launch: 320 workgroups, the split-KV tail round runs
         sharded = m(lat, t, ctx, 16384, **kw)
         torch.cuda.synchronize()
         variant = int(m._last_attn_variant)
         planned = int(_lib.load().wan_attention_workspace_bytes(1, 16384, 16384, 40 // world, 128))
-        q_out.put((rank, float((sharded.float() - single.float()).norm() / single.float().norm()), variant, planned))
+        rel = lambda a: float((a.float() - single.float()).norm() / single.float().norm())
+        q_out.put((rank, max(rel(sharded), rel(grouped)), variant, planned))
     finally:
         dist.destroy_process_group()
 

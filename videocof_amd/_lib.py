@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
@@ -98,6 +98,11 @@ SIGNATURES = {
     "wan_sp_pack_heads": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_sp_unpack_heads": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_sp_unpack_vt": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_rmsnorm_rope_sp_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                          c_float, c_void_p, c_void_p, POINTER(RopeParams), c_float, c_void_p, c_void_p, c_int, c_int,
+                                          c_int, c_void_p]),
+    "wan_sp_pack_heads_split": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_sp_unpack_heads_split": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_dit_block_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockWeights), POINTER(BlockWorkspace),
                                       c_void_p, c_void_p, POINTER(RopeParams), c_int, c_int64, c_int64, c_void_p]),
     "wan_dit_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p),

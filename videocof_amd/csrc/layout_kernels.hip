@@ -147,7 +147,7 @@ extern "C" wan_status_t wan_lincomb(void* out, int dtype, const void* x0, const 
 // ---------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void sp_pack_heads_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out,
-                                                            int P, int T, int B, int Cl, bool unpack) {
+                                                            int P, int T, int B, int Cl, bool unpack, int split) {
     // one 16-byte chunk per thread; grid-stride over B*T*P*Cl/8 chunks, local layout index fastest along channels
     const int cpr = Cl >> 3;                                  // chunks per (token, slab)
     const int64_t total = (int64_t)B * T * P * cpr;
@@ -158,7 +158,11 @@ __global__ __launch_bounds__(256) void sp_pack_heads_kernel(const bf16_t* __rest
         const int t = (int)(r % T);
         const int b = (int)(r / T);
         const u32x4* loc = reinterpret_cast<const u32x4*>(x + ((int64_t)b * T + t) * ldx + (int64_t)p * Cl) + c8;
-        u32x4* wire = reinterpret_cast<u32x4*>(out + (((int64_t)p * T + t) * B + b) * Cl) + c8;
+        const int64_t cell = ((int64_t)p * T + t) * B + b;
+        const int c = c8 << 3;
+        // split > 0: channels [0, split) of every slab form head group 0, the rest group 1 -- two complete wire buffers, one behind the other
+        const int64_t at = split <= 0 ? cell * Cl + c : c < split ? cell * split + c : (int64_t)P * T * B * split + cell * (Cl - split) + (c - split);
+        u32x4* wire = reinterpret_cast<u32x4*>(out + at);
         if (unpack) *const_cast<u32x4*>(loc) = *wire;        // `x` is the destination [B][T][ldx], `out` the wire buffer
         else *wire = *loc;
     }
@@ -186,26 +190,36 @@ static wan_status_t sp_check(const char* what, int P, int T, int B, int Cl) {
     return WAN_OK;
 }
 
-extern "C" wan_status_t wan_sp_pack_heads(const void* x, int64_t ldx, void* wire, int P, int T, int B, int Cl, void* stream) {
-    WAN_REQUIRE(x && wire, WAN_ERR_INVALID, "wan_sp_pack_heads: null tensor");
-    if (wan_status_t st = sp_check("wan_sp_pack_heads", P, T, B, Cl)) return st;
-    WAN_REQUIRE(ldx >= (int64_t)P * Cl && ldx % 8 == 0, WAN_ERR_INVALID, "wan_sp_pack_heads: ldx=%lld", (long long)ldx);
+static wan_status_t sp_heads(const char* what, const void* x, int64_t ldx, void* wire, int P, int T, int B, int Cl, int split, bool unpack,
+                             void* stream) {
+    WAN_REQUIRE(x && wire, WAN_ERR_INVALID, "%s: null tensor", what);
+    if (wan_status_t st = sp_check(what, P, T, B, Cl)) return st;
+    WAN_REQUIRE(ldx >= (int64_t)P * Cl && ldx % 8 == 0, WAN_ERR_INVALID, "%s: ldx=%lld", what, (long long)ldx);
+    WAN_REQUIRE(split >= 0 && split % 8 == 0 && split < Cl, WAN_ERR_INVALID, "%s: split=%d must be a multiple of 8 below Cl=%d (0 = one group)",
+                what, split, Cl);
     const int64_t total = (int64_t)B * T * P * (Cl >> 3);
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(sp_pack_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)wire, P, T, B, Cl, false);
-    WAN_CHECK_LAUNCH("wan_sp_pack_heads");
+    hipLaunchKernelGGL(sp_pack_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)wire, P, T, B, Cl,
+                       unpack, split);
+    WAN_CHECK_LAUNCH(what);
     return WAN_OK;
 }
 
+extern "C" wan_status_t wan_sp_pack_heads(const void* x, int64_t ldx, void* wire, int P, int T, int B, int Cl, void* stream) {
+    return sp_heads("wan_sp_pack_heads", x, ldx, wire, P, T, B, Cl, 0, false, stream);
+}
+
 extern "C" wan_status_t wan_sp_unpack_heads(const void* wire, void* x, int64_t ldx, int P, int T, int B, int Cl, void* stream) {
-    WAN_REQUIRE(x && wire, WAN_ERR_INVALID, "wan_sp_unpack_heads: null tensor");
-    if (wan_status_t st = sp_check("wan_sp_unpack_heads", P, T, B, Cl)) return st;
-    WAN_REQUIRE(ldx >= (int64_t)P * Cl && ldx % 8 == 0, WAN_ERR_INVALID, "wan_sp_unpack_heads: ldx=%lld", (long long)ldx);
-    const int64_t total = (int64_t)B * T * P * (Cl >> 3);
-    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(sp_pack_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)wire, P, T, B, Cl, true);
-    WAN_CHECK_LAUNCH("wan_sp_unpack_heads");
-    return WAN_OK;
+    return sp_heads("wan_sp_unpack_heads", x, ldx, const_cast<void*>(wire), P, T, B, Cl, 0, true, stream);
+}
+
+extern "C" wan_status_t wan_sp_pack_heads_split(const void* x, int64_t ldx, void* wire, int P, int T, int B, int Cl, int split, void* stream) {
+    return sp_heads("wan_sp_pack_heads_split", x, ldx, wire, P, T, B, Cl, split, false, stream);
+}
+
+extern "C" wan_status_t wan_sp_unpack_heads_split(const void* wire, void* x, int64_t ldx, int P, int T, int B, int Cl, int split,
+                                                  void* stream) {
+    return sp_heads("wan_sp_unpack_heads_split", x, ldx, const_cast<void*>(wire), P, T, B, Cl, split, true, stream);
 }
 
 extern "C" wan_status_t wan_sp_unpack_vt(const void* wire, void* vt, int64_t ldvt, int P, int B, int Cl, int T, void* stream) {

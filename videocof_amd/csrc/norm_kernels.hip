@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ x0, const float* __restrict__ w0, bf16_t* __restrict__ x1,
     const float* __restrict__ w1, int64_t ld, int dim, int head_dim, float eps,
     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp, float x0_scale,
-    bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, int out_slabs, int out_batch, float x1_scale, int out_fp8) {
+    bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, int out_slabs, int out_batch, float x1_scale, int out_fp8, int out_split) {
     __shared__ float red[kWaves];
     __shared__ __attribute__((aligned(16))) float2 cs[128];   // (cos, sin) of this token's head_dim/2 pairs
     const int64_t row = blockIdx.x;
@@ -180,7 +180,12 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
                 const int Cl = dim / out_slabs, c = idx << 3;
                 const int slab = c / Cl, cl = c - slab * Cl;
                 const int64_t bi = row / rp.rows_per_batch, t = row - bi * rp.rows_per_batch;
-                *reinterpret_cast<u32x4*>(ob + (((int64_t)slab * rp.rows_per_batch + t) * out_batch + bi) * Cl + cl) = o;
+                const int64_t cell = ((int64_t)slab * rp.rows_per_batch + t) * out_batch + bi;       // (slab, token, sample)
+                // out_split > 0: two head groups, each a complete wire buffer of its own, one behind the other (layout_kernels.hip)
+                const int64_t at = out_split <= 0 ? cell * Cl + cl
+                                 : cl < out_split ? cell * out_split + cl
+                                                  : (int64_t)out_slabs * rp.rows_per_batch * out_batch * out_split + cell * (Cl - out_split) + (cl - out_split);
+                *reinterpret_cast<u32x4*>(ob + at) = o;
             }
         }
     }
@@ -273,7 +278,7 @@ static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, co
                                          int64_t ld, int64_t rows, int dim, int head_dim, float eps,
                                          const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
                                          float x0_scale, void* out0, void* out1, int out_slabs, int out_batch, void* stream,
-                                         float x1_scale, int out_fp8);
+                                         float x1_scale, int out_fp8, int out_split = 0);
 
 static wan_status_t rmsnorm_rope_impl(void* x0, const float* w0, void* x1, const float* w1,
                                       int64_t ld, int64_t rows, int dim, int head_dim, float eps,
@@ -287,7 +292,7 @@ static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, co
                                          int64_t ld, int64_t rows, int dim, int head_dim, float eps,
                                          const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
                                          float x0_scale, void* out0, void* out1, int out_slabs, int out_batch, void* stream,
-                                         float x1_scale, int out_fp8) {
+                                         float x1_scale, int out_fp8, int out_split) {
     WAN_REQUIRE(x0 && w0, WAN_ERR_INVALID, "wan_rmsnorm_rope: null tensor");
     if (out_fp8) {
         WAN_REQUIRE(out0 != nullptr && (out1 != nullptr) == (x1 != nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope_fp8: one output per input tensor");
@@ -299,6 +304,9 @@ static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, co
                         rows == (int64_t)out_batch * rp->rows_per_batch, WAN_ERR_INVALID,
                     "wan_rmsnorm_rope_sp: slabs=%d batch=%d rows=%lld rows_per_batch=%lld dim=%d", out_slabs, out_batch,
                     (long long)rows, (long long)rp->rows_per_batch, dim);
+        WAN_REQUIRE(out_split >= 0 && out_split % 8 == 0 && out_split < dim / out_slabs, WAN_ERR_INVALID,
+                    "wan_rmsnorm_rope_sp_split: split=%d must be a multiple of 8 inside a slab of %d channels (0 = one group)", out_split,
+                    dim / out_slabs);
     }
     WAN_REQUIRE(x0_scale == x0_scale && x0_scale != 0.f, WAN_ERR_INVALID, "wan_rmsnorm_rope: x0_scale must be a non-zero number (1 = none)");
     WAN_REQUIRE((x1 == nullptr) == (w1 == nullptr), WAN_ERR_INVALID, "wan_rmsnorm_rope: x1/w1 must both be set or both NULL");
@@ -325,7 +333,7 @@ static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, co
     hipStream_t s = (hipStream_t)stream;
     const int nv = (dim / 8 + kThreads - 1) / kThreads;
     dim3 grid((unsigned)rows, x1 ? 2 : 1), block(kThreads);
-#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch, x1_scale, out_fp8); break;
+#define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch, x1_scale, out_fp8, out_split); break;
     switch (nv) { RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) }
 #undef RR_CASE
     WAN_CHECK_LAUNCH("wan_rmsnorm_rope");
@@ -346,6 +354,15 @@ extern "C" wan_status_t wan_rmsnorm_rope_sp(const void* x0, const float* w0, con
     WAN_REQUIRE(wire0 != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_sp: null wire buffer");
     return rmsnorm_rope_impl(const_cast<void*>(x0), w0, const_cast<void*>(x1), w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp,
                              x0_scale, wire0, wire1, slabs, batch, stream);
+}
+
+extern "C" wan_status_t wan_rmsnorm_rope_sp_split(const void* x0, const float* w0, const void* x1, const float* w1,
+                                                  int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+                                                  const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
+                                                  float x0_scale, void* wire0, void* wire1, int slabs, int batch, int split, void* stream) {
+    WAN_REQUIRE(wire0 != nullptr, WAN_ERR_INVALID, "wan_rmsnorm_rope_sp_split: null wire buffer");
+    return rmsnorm_rope_impl_ex(const_cast<void*>(x0), w0, const_cast<void*>(x1), w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, rp,
+                                x0_scale, wire0, wire1, slabs, batch, stream, 1.0f, 0, split);
 }
 
 extern "C" wan_status_t wan_rmsnorm_rope_fp8(const void* x0, const float* w0, const void* x1, const float* w1,

@@ -81,6 +81,18 @@ class SequenceParallelGroup:
         P, T, B, Cl = wire.shape
         return wire.permute(2, 1, 0, 3).reshape(B, T, P * Cl)
 
+    @staticmethod
+    def split_wire_ref(wire: torch.Tensor, split: int) -> torch.Tensor:
+        """token-major wire [P, T, B, Cl] -> the two-head-group form of include/wan_hip.h's ``*_split`` kernels, flat: channels
+        [0, split) of every slab as a complete wire buffer [P, T, B, split], then channels [split, Cl) as [P, T, B, Cl - split]."""
+        return torch.cat([wire[..., :split].reshape(-1), wire[..., split:].reshape(-1)])
+
+    @staticmethod
+    def join_wire_ref(flat: torch.Tensor, P: int, T: int, B: int, Cl: int, split: int) -> torch.Tensor:
+        """The inverse of ``split_wire_ref``: [P, T, B, Cl]."""
+        n0 = P * T * B * split
+        return torch.cat([flat[:n0].view(P, T, B, split), flat[n0:P * T * B * Cl].view(P, T, B, Cl - split)], dim=-1)
+
     def pack_vt_ref(self, vt: torch.Tensor) -> torch.Tensor:
         """[B, C, T] -> channel-major wire [P, C/P, B, T] (what the V projection writes per sample with ldo = B*T)."""
         B, C, T = vt.shape

@@ -125,9 +125,10 @@ def rmsnorm_rope_(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor]
 @_on_tensor_device
 def rmsnorm_rope_sp(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tensor], w1: Optional[torch.Tensor], head_dim: int,
                     eps: float, rope: Tuple[torch.Tensor, torch.Tensor], rope_params: RopeParams, wire0: torch.Tensor,
-                    wire1: Optional[torch.Tensor], slabs: int, batch: int, x0_scale: float = 1.0) -> None:
+                    wire1: Optional[torch.Tensor], slabs: int, batch: int, x0_scale: float = 1.0, split: int = 0) -> None:
     """``rmsnorm_rope_`` that leaves x0 / x1 untouched and writes the results into Ulysses token-major wire buffers
-    ``[slabs][rows_per_batch][batch][dim / slabs]`` (include/wan_hip.h, a21)."""
+    ``[slabs][rows_per_batch][batch][dim / slabs]`` (include/wan_hip.h, a21).  ``split`` > 0: two head groups, channels [0, split) and
+    [split, dim / slabs) of every slab, each a complete wire buffer, one behind the other (``wan_rmsnorm_rope_sp_split``)."""
     _need(x0, torch.bfloat16, "rmsnorm_rope_sp.x0")
     _need(w0, torch.float32, "rmsnorm_rope_sp.w0")
     rows, dim = x0.shape
@@ -144,34 +145,46 @@ def rmsnorm_rope_sp(x0: torch.Tensor, w0: torch.Tensor, x1: Optional[torch.Tenso
             raise ValueError("rmsnorm_rope_sp: x0 / x1 must share shape and row stride, and x1 needs wire1")
     cos, sin = rope
     lib = _lib.load()
+    if split:
+        _lib.check(lib.wan_rmsnorm_rope_sp_split(_p(x0), _p(w0), _p(x1), _p(w1), ld, rows, dim, head_dim, float(eps), _p(cos), _p(sin),
+                                                 ctypes.byref(rope_params), float(x0_scale), _p(wire0), _p(wire1), int(slabs), int(batch),
+                                                 int(split), _stream()), "wan_rmsnorm_rope_sp_split")
+        return
     _lib.check(lib.wan_rmsnorm_rope_sp(_p(x0), _p(w0), _p(x1), _p(w1), ld, rows, dim, head_dim, float(eps), _p(cos), _p(sin),
                                        ctypes.byref(rope_params), float(x0_scale), _p(wire0), _p(wire1), int(slabs), int(batch),
                                        _stream()), "wan_rmsnorm_rope_sp")
 
 
 @_on_tensor_device
-def sp_pack_heads(x: torch.Tensor, wire: torch.Tensor, P: int, T: int, B: int) -> torch.Tensor:
-    """x bf16 [B*T, ldx >= C] (C = P * Cl) -> token-major wire [P][T][B][Cl]."""
+def sp_pack_heads(x: torch.Tensor, wire: torch.Tensor, P: int, T: int, B: int, split: int = 0) -> torch.Tensor:
+    """x bf16 [B*T, ldx >= C] (C = P * Cl) -> token-major wire [P][T][B][Cl] (``split`` > 0: two head-group wires, see ``rmsnorm_rope_sp``)."""
     _need(x, torch.bfloat16, "sp_pack_heads.x")
     _need(wire, torch.bfloat16, "sp_pack_heads.wire")
     C = x.shape[1]
     if x.shape[0] != B * T or C % P or not wire.is_contiguous() or wire.numel() < B * T * C:
         raise ValueError("sp_pack_heads: shapes disagree")
     lib = _lib.load()
-    _lib.check(lib.wan_sp_pack_heads(_p(x), x.stride(0), _p(wire), P, T, B, C // P, _stream()), "wan_sp_pack_heads")
+    if split:
+        _lib.check(lib.wan_sp_pack_heads_split(_p(x), x.stride(0), _p(wire), P, T, B, C // P, int(split), _stream()), "wan_sp_pack_heads_split")
+    else:
+        _lib.check(lib.wan_sp_pack_heads(_p(x), x.stride(0), _p(wire), P, T, B, C // P, _stream()), "wan_sp_pack_heads")
     return wire
 
 
 @_on_tensor_device
-def sp_unpack_heads(wire: torch.Tensor, x: torch.Tensor, P: int, T: int, B: int) -> torch.Tensor:
-    """token-major wire [P][T][B][Cl] -> x bf16 [B*T, ldx >= P*Cl] (column s * Cl + c)."""
+def sp_unpack_heads(wire: torch.Tensor, x: torch.Tensor, P: int, T: int, B: int, split: int = 0) -> torch.Tensor:
+    """token-major wire [P][T][B][Cl] -> x bf16 [B*T, ldx >= P*Cl] (column s * Cl + c); ``split`` > 0: from two head-group wires."""
     _need(x, torch.bfloat16, "sp_unpack_heads.x")
     _need(wire, torch.bfloat16, "sp_unpack_heads.wire")
     C = x.shape[1]
     if x.shape[0] != B * T or C % P or not wire.is_contiguous() or wire.numel() < B * T * C:
         raise ValueError("sp_unpack_heads: shapes disagree")
     lib = _lib.load()
-    _lib.check(lib.wan_sp_unpack_heads(_p(wire), _p(x), x.stride(0), P, T, B, C // P, _stream()), "wan_sp_unpack_heads")
+    if split:
+        _lib.check(lib.wan_sp_unpack_heads_split(_p(wire), _p(x), x.stride(0), P, T, B, C // P, int(split), _stream()),
+                   "wan_sp_unpack_heads_split")
+    else:
+        _lib.check(lib.wan_sp_unpack_heads(_p(wire), _p(x), x.stride(0), P, T, B, C // P, _stream()), "wan_sp_unpack_heads")
     return x
 
 

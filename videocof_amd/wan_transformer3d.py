@@ -124,6 +124,10 @@ class WanTransformer3DModel(nn.Module):
         # Take the Ulysses branch even when the group has ONE rank (tests: the async RCCL exchanges, their waits and the
         # persistent wire buffers become live code on a single GPU; results equal the plain path).  Off in production.
         self.force_ulysses = False
+        # Ulysses head-group pipelining: q and o travel as TWO head groups, each in its own all-to-all, and the attention runs once per
+        # group -- the q exchange of group 1 runs under the attention of group 0, the o exchange of group 0 under the attention of
+        # group 1.  1 = one exchange / one attention launch per layer.  Needs >= 2 local heads.
+        self.sp_head_groups = 2
         self._usp = False                   # this forward runs the Ulysses branch (set by forward)
         self._comm_events = None            # bench.py: list collecting (start, end) HIP events around the EXPOSED exchanges
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
@@ -850,10 +854,21 @@ class WanTransformer3DModel(nn.Module):
                 proj_vt(b, vsend[:, b])
             wait_v = sp.exchange(bufs.vw_r, bufs.vw_s, async_op=True)
             proj(slice(0, C), blk.b_qk[:C], qk[:, :C])
+            # Head groups (q and o only; k and V^T are already under the projections).  The RMSNorm of q spans ALL heads of a token
+            # (wan_transformer3d.py:264-267: WanRMSNorm(dim)), so no head group of q exists before the whole projection does -- the
+            # pipeline is between the exchanges and the attention launches, not inside the projection: with groups g0 | g1 the
+            # exposed transfers per layer are q(g0) and o(g1), ONE exchange's worth instead of two.
+            Hl = H // P
+            h0 = Hl // 2 if (self.sp_head_groups >= 2 and Hl >= 2 and not a8_sp) else 0
+            split, n0 = h0 * self.d, Lt * B * h0 * self.d        # group 0: channels [0, split) of every slab, n0 elements of wire
             ops.rmsnorm_rope_sp(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, bufs.qw_s, None, P, B,
-                                x0_scale=self._qs)
-            wait_q = sp.exchange(bufs.qw_r, bufs.qw_s, async_op=True)
-            cev = self._comm_pair()             # exposed: whatever of the three exchanges the projections did not cover
+                                x0_scale=self._qs, split=split)
+            if h0:
+                wait_q = sp.exchange(bufs.qw_r[:n0], bufs.qw_s[:n0], async_op=True)
+                wait_q1 = sp.exchange(bufs.qw_r[n0:], bufs.qw_s[n0:], async_op=True)
+            else:
+                wait_q = sp.exchange(bufs.qw_r, bufs.qw_s, async_op=True)
+            cev = self._comm_pair()             # exposed: whatever of the exchanges the projections did not cover (q: group 0 only)
             wait_k()
             wait_v()
             ops.sp_unpack_vt(bufs.vw_r, bufs.vt_full, P, Ll)
@@ -861,7 +876,17 @@ class WanTransformer3DModel(nn.Module):
             self._comm_done(cev)
             as_bld = lambda w: w.view(Lt, B, Cl).permute(1, 0, 2)          # [B, P*Ll, Cl] view: row stride B*Cl, sample stride Cl
             ev = self._event_pair()
-            if a8_sp:
+            if h0:
+                # a group's wire buffer reads as [P*Ll][B][its channels]; k / V^T of the group are column / row slices of the whole ones
+                grp = lambda w, g: (w[:n0].view(Lt, B, split) if g == 0 else w[n0:].view(Lt, B, Cl - split)).permute(1, 0, 2)
+                k_all = as_bld(bufs.kw_r)
+                ops.attention_fwd(grp(bufs.qw_r, 0), k_all[..., :split], bufs.vt_full[:, :split], h0, k_len=L, out=grp(bufs.ow_s, 0),
+                                  q_prescaled=True, workspace=self._ws_self)
+                wait_o0 = sp.exchange(bufs.ow_r[:n0], bufs.ow_s[:n0], async_op=True)      # ... under the attention of group 1
+                wait_q1()                                                                  # (arrived under the attention of group 0)
+                ops.attention_fwd(grp(bufs.qw_r, 1), k_all[..., split:], bufs.vt_full[:, split:], Hl - h0, k_len=L, out=grp(bufs.ow_s, 1),
+                                  q_prescaled=True, workspace=self._ws_self)
+            elif a8_sp:
                 # fp8 attention on the arrived operands (bf16 wires; every rank holds all tokens of its heads, so the K mean is local)
                 if B != 1:
                     raise NotImplementedError("fp8 attention under sequence parallelism covers batch 1 (no CFG batch)")
@@ -884,10 +909,14 @@ class WanTransformer3DModel(nn.Module):
                 ops.attention_fwd(as_bld(bufs.qw_r), as_bld(bufs.kw_r), bufs.vt_full, H // P, k_len=L, out=as_bld(bufs.ow_s),
                                   q_prescaled=True, workspace=self._ws_self)
             self._event_done(ev, B * seq_len)
-            cev = self._comm_pair()             # exposed: the inverse exchange sits between attention and the o projection
-            sp.exchange(bufs.ow_r, bufs.ow_s)
+            cev = self._comm_pair()             # exposed: the inverse exchange sits between attention and the o projection (group 1 only)
+            if h0:
+                sp.exchange(bufs.ow_r[n0:], bufs.ow_s[n0:])
+                wait_o0()
+            else:
+                sp.exchange(bufs.ow_r, bufs.ow_s)
             self._comm_done(cev)
-            ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B)
+            ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B, split=split)
             o_in = att
         if "o" in f8:
             ops.quantize_rows_fp8(o_in, out=bufs.attq, out_scale=bufs.atts)
