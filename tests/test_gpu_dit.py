@@ -498,6 +498,9 @@ def test_end_to_end_video_in_video_out():
     assert out.edit_videos.shape == (1, 3, 9, 32, 48)          # 3 target latents -> 9 frames
     assert out.videos.shape == (1, 3, 10, 32, 48)
     assert 0.0 <= float(out.videos.min()) and float(out.videos.max()) <= 1.0
+    # `videos` = grounding | edit frames (pipeline_wan.py:777), decoded straight into one page-locked clip: the segments are its views
+    assert out.videos.dtype == np.float32 and np.array_equal(out.videos[:, :, :1], out.ground_videos)
+    assert np.array_equal(out.videos[:, :, 1:], out.edit_videos) and np.shares_memory(out.videos, out.edit_videos)
     # oracle chain from the SAME noise (the pipeline's latents[:, :, 3:] at step 0 are the generator's draw)
     gen2 = torch.Generator(device=DEV).manual_seed(7)
     noise = torch.randn((1, 16, 4, 4, 6), generator=gen2, device=DEV, dtype=torch.float32).cpu()
