@@ -1093,6 +1093,27 @@ class WanTransformer3DModel(nn.Module):
             raise NotImplementedError("per-token timesteps (Wan2.2-5B) are never produced by WanPipeline")
         if t.numel() != B or len(context) != B:
             raise ValueError(f"batch mismatch: x has {B} samples, t {t.numel()}, context {len(context)}")
+        # Samples with DIFFERENT CoF position maps in one call (rope_apply_qk takes them per sample, :160-179; WanPipeline never produces
+        # this): the kernels take one map per launch, and a sample's result does not depend on its batch mates, so the call is served
+        # group by group -- samples that share a map together, the outputs back in the caller's order.
+        if B > 1 and frame_split_indices is not None and len(frame_split_indices) > 0:
+            gfi = ground_frame_indices if (ground_frame_indices is not None and len(ground_frame_indices) > 0) else None
+            if len(frame_split_indices) != B or (gfi is not None and len(gfi) != B):
+                raise ValueError(f"frame_split_indices / ground_frame_indices must have one entry per sample ({B})")
+            keys = [(int(frame_split_indices[b]), tuple(int(v) for v in gfi[b]) if gfi is not None else None) for b in range(B)]
+            if len(set(keys)) > 1:
+                if self.teacache is not None:
+                    raise NotImplementedError("TeaCache keeps one residual per call: samples of a call must share their CoF position map")
+                outs = [None] * B
+                for key in dict.fromkeys(keys):
+                    idx = [b for b in range(B) if keys[b] == key]
+                    sel = torch.tensor(idx, device=x.device)
+                    y = self.forward(x.index_select(0, sel), t.index_select(0, sel.to(t.device)), [context[b] for b in idx], seq_len,
+                                     cond_flag=cond_flag, frame_split_indices=[key[0]] * len(idx),
+                                     ground_frame_indices=[key[1]] * len(idx) if key[1] is not None else None)
+                    for j, b in enumerate(idx):
+                        outs[b] = y[j]
+                return torch.stack(outs)
         P, rank = self.sp_world_size, self.sp_world_rank
         usp = self._usp = self._sp is not None and (P > 1 or self.force_ulysses)
         if usp:
