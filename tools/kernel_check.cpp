@@ -337,7 +337,7 @@ static void check_layout() {
 }
 
 // ------------------------------------------------------------------ perf
-static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
+static void perf(bool big, bool attn_only = false, bool gemm_only = false, bool rows_only = false) {
     hipDeviceProp_t prop; HIP(hipGetDeviceProperties(&prop, 0));
     printf("device: %s, %d CUs, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
     const int L = big ? 67080 : 32760;
@@ -355,6 +355,7 @@ static void perf(bool big, bool attn_only = false, bool gemm_only = false) {
         ms = time_ms([&] { WAN(wan_rmsnorm_rope(qk.p, w.p, qk.p + C, w.p, 2 * C, L, C, 128, 1e-6f, dct.p, dst.p, &rp, 1.0f, nullptr)); });
         printf("  rmsnorm_rope q+k L=%d C=%d: %.3f ms  %.0f GB/s (8C B/row)\n", L, C, ms, 8.0 * C * L / ms / 1e6);
     }
+    if (rows_only) return;
     struct G { int M, N, K; int epi; const char* what; };
     std::vector<G> gs = {{8392, 5120, 5120, WAN_EPI_BF16, "14B o/q proj, SP8 shard"}, {8392, 13824, 5120, WAN_EPI_GELU_BF16, "14B ffn.0, SP8 shard"},
                          {8392, 5120, 13824, WAN_EPI_RESID_F32, "14B ffn.2, SP8 shard"}, {16776, 5120, 5120, WAN_EPI_BF16, "14B o/q proj, SP4 shard"},
@@ -419,6 +420,11 @@ int main(int argc, char** argv) {
     if (mode == "check" || mode == "all") {
         check_ln(); check_rmsnorm_rope(); check_gemm(); check_attn(); check_layout();
         printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+    }
+    if (mode == "rows") {         // the HBM-bound row kernels alone: numerics, then the 14B-width timings at L = 67 080 (three rounds)
+        check_ln(); check_rmsnorm_rope();
+        printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
+        for (int r = 0; r < 3; ++r) perf(true, false, false, true);
     }
     if (mode == "gemm") { check_gemm(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, false, true); }
     if (mode == "attn") { check_attn(); printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail); perf(big, true); }
