@@ -767,6 +767,42 @@ def test_sp_wire_layout_kernels(rope_dev, P, T, B, Cl):
         assert torch.equal(back2, back)
 
 
+def test_row_kernels_rows_per_workgroup_are_bitwise_the_one_row_kernels(rope_dev):
+    """LN-modulate and RMSNorm+RoPE with 2 (default) or 4 token rows per workgroup -- the per-column parameters fetched once per group --
+    against the one-row kernels: same arithmetic, same summation order, so every output form must agree BITWISE; row counts that
+    leave a ragged last group, samples whose boundary falls inside a group, strided rows, the wire and e4m3 output forms."""
+    g = torch.Generator().manual_seed(5)
+    for dim, rows_per_batch, B in ((5120, 37, 2), (1536, 50, 1), (256, 9, 3)):
+        rows = rows_per_batch * B
+        x = torch.randn(rows, dim, generator=g).to(DEV)
+        sc, sh = torch.randn(B, dim, generator=g).to(DEV), torch.randn(B, dim, generator=g).to(DEV)
+        qk = bf(torch.randn(rows, 2 * dim + 16, generator=g)).to(DEV)
+        w0, w1 = (torch.rand(dim, generator=g) + 0.5).to(DEV), (torch.rand(dim, generator=g) + 0.5).to(DEV)
+        rp = RopeParams(3, 3, 5, 2, 1, 2, 4, rows_per_batch, 1024)            # CoF map, token offset 4, rows past the 45-token grid
+        P = 2
+        res = {}
+        for R in (1, 2, 4):
+            ops.set_tuning("row_group", R)
+            try:
+                ln = ops.ln_modulate(x, sc, sh, True, rows_per_batch, 1e-6)
+                ln_plain = ops.ln_modulate(x, None, None, False, rows, 1e-6)
+                a = qk.clone()
+                ops.rmsnorm_rope_(a[:, :dim], w0, a[:, dim:2 * dim], w1, 128, 1e-6, rope_dev, rp, x0_scale=0.37)
+                wire = torch.zeros(rows * dim, device=DEV, dtype=torch.bfloat16)
+                ops.rmsnorm_rope_sp(qk[:, :dim], w0, None, None, 128, 1e-6, rope_dev, rp, wire, None, P, B, x0_scale=0.37,
+                                    split=(dim // P // 128 // 2) * 128)
+                q8, k8 = torch.zeros(rows, dim, device=DEV, dtype=ops.FP8), torch.zeros(rows, dim, device=DEV, dtype=ops.FP8)
+                ops.rmsnorm_rope_fp8(qk[:, :dim], w0, qk[:, dim:2 * dim], w1, 128, 1e-6, rope_dev, rp, q8, k8, x0_scale=4.0, x1_scale=2.0)
+                nr = qk[:, :dim].clone()
+                ops.rmsnorm_rope_(nr, w0, None, None, 128, 1e-6)                  # no rotation (the cross-attention q form)
+                res[R] = (ln, ln_plain, a, wire, q8.view(torch.uint8), k8.view(torch.uint8), nr)
+            finally:
+                ops.set_tuning("row_group", 2)
+        for R in (2, 4):
+            for i, (u, v) in enumerate(zip(res[1], res[R])):
+                assert torch.equal(u, v), (dim, R, i)
+
+
 def test_attention_debug_check_catches_non_finite_vt_padding():
     """The one caller contract the kernels cannot enforce -- V^T pad columns [Lk, roundup(Lk, 64)) finite -- is checked
     (synchronising) when the `debug_checks` switch is on, and costs nothing when it is off."""

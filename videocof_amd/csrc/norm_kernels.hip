@@ -86,6 +86,111 @@ __global__ __launch_bounds__(kThreads) void ln_modulate_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------ R rows per workgroup (round 4)
+// What bounds the row kernels is not the row traffic but (a) the per-column parameters -- the modulation vectors (2 x 4C bytes) or the
+// RMSNorm gains (4C bytes) came from L2 once PER ROW, against 4C / 2C bytes of HBM reads for the row itself: LN-modulate ran 4.9 TB/s
+// with its vectors and 5.95 TB/s, the rate of a plain fp32 -> bf16 cast, without them (tools/probe/rows_probe.py) -- and (b) the bytes
+// in flight per CU (a persistent form that kept the parameters in registers lost more to its lower occupancy than it saved,
+// profiles/r04/row_kernels_persistent_variant_ab.log).  Here a workgroup owns R consecutive rows: a thread reads its columns'
+// parameters ONCE for the R rows, the R row sums share one pair of barriers, and a resident workgroup keeps R rows in flight.
+// R = 2 is the default (profiles/r04/row_kernels_rows_per_workgroup_ab.log: LN-modulate 4.85 -> 5.7 TB/s, 97 % of the cast rate in
+// process; RMSNorm+RoPE 4.7 -> 5.0-5.3; R = 4 costs LN-modulate its occupancy: 192 registers).  Per-row arithmetic and summation order
+// are those of the one-row kernels: results are bitwise equal.
+template <int NW, int R>
+__device__ __forceinline__ void block_sum_n(float (&v)[R], float (*red)[NW]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = wave_sum(v[r]);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();   // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) red[r][wid] = v[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t += red[r][i];
+        v[r] = t;
+    }
+}
+
+template <int NV, int R>   // float4 per thread and row
+__global__ __launch_bounds__(kThreads) void ln_modulate_rows_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    float add_one, bf16_t* __restrict__ out, int dim, int64_t rows, int64_t rows_per_batch, float eps) {
+    __shared__ float red[R][kWaves];
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int nvec = dim >> 2;
+    float4 v[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (row0 + r) * (int64_t)dim);
+        const bool live = row0 + r < rows;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * kThreads;
+            v[r][i] = (live && idx < nvec) ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (threadIdx.x + i * kThreads < nvec) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    }
+    block_sum_n<kWaves, R>(s, red);
+    float mean[R], q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = s[r] / (float)dim;
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (threadIdx.x + i * kThreads < nvec) {
+                const float a = v[r][i].x - mean[r], bb = v[r][i].y - mean[r], c = v[r][i].z - mean[r], d = v[r][i].w - mean[r];
+                q[r] += (a * a + bb * bb) + (c * c + d * d);
+            }
+        }
+    }
+    block_sum_n<kWaves, R>(q, red);
+    const int64_t last = (row0 + R < rows ? row0 + R : rows) - 1;
+    const int64_t b0 = row0 / rows_per_batch;
+    const bool one_sample = last / rows_per_batch == b0;          // (a group that straddles two samples fetches per row)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nvec) {
+            float4 a, c;
+            auto fetch = [&](int64_t b) {
+                a = make_float4(add_one, add_one, add_one, add_one);
+                c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (scale) { const float4 t = reinterpret_cast<const float4*>(scale + b * dim)[idx]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+                else if (add_one == 0.f) { a = make_float4(1.f, 1.f, 1.f, 1.f); }
+                if (shift) c = reinterpret_cast<const float4*>(shift + b * dim)[idx];
+            };
+            fetch(b0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < rows) {
+                    if (!one_sample) fetch((row0 + r) / rows_per_batch);
+                    const float rstd = rsqrtf(q[r] / (float)dim + eps);
+                    const float y0 = (v[r][i].x - mean[r]) * rstd * a.x + c.x;
+                    const float y1 = (v[r][i].y - mean[r]) * rstd * a.y + c.y;
+                    const float y2 = (v[r][i].z - mean[r]) * rstd * a.z + c.z;
+                    const float y3 = (v[r][i].w - mean[r]) * rstd * a.w + c.w;
+                    u32x2 o = {pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
+                    reinterpret_cast<u32x2*>(out + (row0 + r) * (int64_t)dim)[idx] = o;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ RMSNorm + RoPE
 struct RopeDev {
     int F, Hp, Wp, mode, f_src, ground_end, max_pos;
@@ -191,6 +296,120 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_rope_kernel(
     }
 }
 
+
+template <int NV, int R>   // 16-byte chunks (8 bf16) per thread and row; see ln_modulate_rows_kernel
+__global__ __launch_bounds__(kThreads) void rmsnorm_rope_rows_kernel(
+    bf16_t* __restrict__ x0, const float* __restrict__ w0, bf16_t* __restrict__ x1,
+    const float* __restrict__ w1, int64_t ld, int64_t rows, int dim, int head_dim, float eps,
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, RopeDev rp, float x0_scale,
+    bf16_t* __restrict__ out0, bf16_t* __restrict__ out1, int out_slabs, int out_batch, float x1_scale, int out_fp8, int out_split) {
+    __shared__ float red[R][kWaves];
+    __shared__ __attribute__((aligned(16))) float2 cs[R][128];   // (cos, sin) of each row's head_dim/2 pairs
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    bf16_t* xb = blockIdx.y == 0 ? x0 : x1;
+    bf16_t* ob = blockIdx.y == 0 ? out0 : out1;               // nullptr: in place
+    const float* w = blockIdx.y == 0 ? w0 : w1;
+    const int nchunk = dim >> 3;
+    const int half = head_dim >> 1;
+
+    u32x4 v[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const u32x4* xr = reinterpret_cast<const u32x4*>(xb + (row0 + r) * ld);
+        const bool live = row0 + r < rows;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * kThreads;
+            if (live && idx < nchunk) v[r][i] = xr[idx]; else v[r][i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    bool rotate[R];
+    const int64_t hw = (int64_t)rp.Hp * rp.Wp;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        rotate[r] = rope_cos != nullptr && rp.token_offset + ((row0 + r) % rp.rows_per_batch) < (int64_t)rp.F * hw;   // rows past the grid pass through (:202)
+    if (rope_cos != nullptr) {
+        for (int e = threadIdx.x; e < R * half; e += kThreads) {
+            const int r = e / half, p = e - r * half;
+            const int64_t tok = rp.token_offset + ((row0 + r) % rp.rows_per_batch);
+            if (row0 + r < rows && tok < (int64_t)rp.F * hw) {
+                const int f = (int)(tok / hw);
+                const int rem = (int)(tok - (int64_t)f * hw);
+                const int hh = rem / rp.Wp, ww = rem - hh * rp.Wp;
+                int pt = f;                                     // default 0..F-1 (:191)
+                if (rp.mode == 1) pt = f < rp.f_src ? f : f - rp.f_src;                    // paired (:183-188)
+                else if (rp.mode == 2)                                                     // CoF (:160-179)
+                    pt = f < rp.f_src ? f + 1 : (f < rp.ground_end ? 0 : f - rp.ground_end + 1);
+                int pos = p < rp.ct ? pt : (p < rp.ct + rp.ch ? hh : ww);
+                pos = pos < rp.max_pos ? pos : rp.max_pos - 1;
+                cs[r][p] = make_float2(rope_cos[(int64_t)pos * half + p], rope_sin[(int64_t)pos * half + p]);
+            }
+        }
+    }
+    float ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ss[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (threadIdx.x + i * kThreads < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bf16lo_to_f32(v[r][i][j]), b = bf16hi_to_f32(v[r][i][j]);
+                    ss[r] += a * a + b * b;
+                }
+            }
+        }
+    }
+    block_sum_n<kWaves, R>(ss, red);                       // also orders the cs[][] writes
+    const float post = blockIdx.y == 0 ? x0_scale : x1_scale;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < nchunk) {
+            const float4 wa = reinterpret_cast<const float4*>(w)[idx * 2];        // once for the R rows
+            const float4 wb = reinterpret_cast<const float4*>(w)[idx * 2 + 1];
+            const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            const int p0 = ((idx << 3) % head_dim) >> 1;    // first complex pair of this chunk within its head
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = row0 + r;
+                if (row >= rows) continue;
+                const float rstd = rsqrtf(ss[r] / (float)dim + eps) * post;
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = bf16lo_to_f32(v[r][i][j]) * rstd * wv[2 * j];
+                    float b = bf16hi_to_f32(v[r][i][j]) * rstd * wv[2 * j + 1];
+                    if (rotate[r]) {
+                        const float2 c = cs[r][p0 + j];
+                        const float ra = a * c.x - b * c.y;
+                        const float rb = a * c.y + b * c.x;
+                        a = ra; b = rb;
+                    }
+                    o[j] = pack_bf16x2(a, b);
+                }
+                if (ob == nullptr) {
+                    reinterpret_cast<u32x4*>(xb + row * ld)[idx] = o;
+                } else if (out_fp8) {
+                    u32x2 q8 = {pack_fp8x4(bf16lo_to_f32(o[0]), bf16hi_to_f32(o[0]), bf16lo_to_f32(o[1]), bf16hi_to_f32(o[1])),
+                                pack_fp8x4(bf16lo_to_f32(o[2]), bf16hi_to_f32(o[2]), bf16lo_to_f32(o[3]), bf16hi_to_f32(o[3]))};
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(ob) + row * (int64_t)dim + (idx << 3)) = q8;
+                } else {
+                    const int Cl = dim / out_slabs, c = idx << 3;
+                    const int slab = c / Cl, cl = c - slab * Cl;
+                    const int64_t bi = row / rp.rows_per_batch, t = row - bi * rp.rows_per_batch;
+                    const int64_t cell = ((int64_t)slab * rp.rows_per_batch + t) * out_batch + bi;       // (slab, token, sample)
+                    const int64_t at = out_split <= 0 ? cell * Cl + cl
+                                     : cl < out_split ? cell * out_split + cl
+                                                      : (int64_t)out_slabs * rp.rows_per_batch * out_batch * out_split + cell * (Cl - out_split) + (cl - out_split);
+                    *reinterpret_cast<u32x4*>(ob + at) = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" wan_status_t wan_ln_modulate(const float* x, const float* scale, const float* shift, int add_one,
@@ -207,6 +426,16 @@ extern "C" wan_status_t wan_ln_modulate(const float* x, const float* scale, cons
     dim3 grid((unsigned)rows), block(kThreads);
     bf16_t* out = (bf16_t*)out_bf16;
     const float ao = add_one ? 1.f : 0.f;
+    const int R = wan_tune(WAN_TUNE_ROW_GROUP);                   // rows per workgroup: 2 (default), 4, or 1 = the one-row kernel
+    if ((R == 2 || R == 4) && nv <= 6) {
+        dim3 ggrid((unsigned)((rows + R - 1) / R));
+#define LG_CASE(N) case N: if (R == 4) hipLaunchKernelGGL((ln_modulate_rows_kernel<N, 4>), ggrid, block, 0, s, x, scale, shift, ao, out, dim, rows, rows_per_batch, eps); \
+                           else hipLaunchKernelGGL((ln_modulate_rows_kernel<N, 2>), ggrid, block, 0, s, x, scale, shift, ao, out, dim, rows, rows_per_batch, eps); break;
+        switch (nv) { LG_CASE(1) LG_CASE(2) LG_CASE(3) LG_CASE(4) LG_CASE(5) LG_CASE(6) }
+#undef LG_CASE
+        WAN_CHECK_LAUNCH("wan_ln_modulate");
+        return WAN_OK;
+    }
 #define LN_CASE(N) case N: hipLaunchKernelGGL(ln_modulate_kernel<N>, grid, block, 0, s, x, scale, shift, ao, out, dim, rows_per_batch, eps); break;
     switch (nv) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
 #undef LN_CASE
@@ -333,6 +562,16 @@ static wan_status_t rmsnorm_rope_impl_ex(void* x0, const float* w0, void* x1, co
     hipStream_t s = (hipStream_t)stream;
     const int nv = (dim / 8 + kThreads - 1) / kThreads;
     dim3 grid((unsigned)rows, x1 ? 2 : 1), block(kThreads);
+    const int R = wan_tune(WAN_TUNE_ROW_GROUP);                   // rows per workgroup: 2 (default), 4, or 1 = the one-row kernel
+    if ((R == 2 || R == 4) && head_dim <= 256) {
+        dim3 ggrid((unsigned)((rows + R - 1) / R), x1 ? 2 : 1);
+#define RG_CASE(N) case N: if (R == 4) hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<N, 4>), ggrid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch, x1_scale, out_fp8, out_split); \
+                           else hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<N, 2>), ggrid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, rows, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch, x1_scale, out_fp8, out_split); break;
+        switch (nv) { RG_CASE(1) RG_CASE(2) RG_CASE(3) RG_CASE(4) }
+#undef RG_CASE
+        WAN_CHECK_LAUNCH("wan_rmsnorm_rope");
+        return WAN_OK;
+    }
 #define RR_CASE(N) case N: hipLaunchKernelGGL(rmsnorm_rope_kernel<N>, grid, block, 0, s, (bf16_t*)x0, w0, (bf16_t*)x1, w1, ld, dim, head_dim, eps, rope_cos, rope_sin, d, x0_scale, (bf16_t*)out0, (bf16_t*)out1, out_slabs, out_batch, x1_scale, out_fp8, out_split); break;
     switch (nv) { RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) }
 #undef RR_CASE
