@@ -788,16 +788,17 @@ int main(int argc, char** argv) {
     }
     if (mode == "attnx") {        // in-process A/B of the self-attention launch at the bench shape: tuning key=value sets from argv
         // usage: kernel_check attnx [H] "k1=v1,k2=v2" "k1=v1" ...   (each quoted group is one arm; "" = defaults)
-        const int L = 67080; int H = 40; int first = 2;
+        const int L = 67080; int H = 40; int first = 2; int Lk = L;
         if (argc > 2 && atoi(argv[2]) > 0) { H = atoi(argv[2]); first = 3; }
-        const int C = H * 128; const int64_t ldvt = (L + 63) / 64 * 64;
+        if (argc > first && !strncmp(argv[first], "Lk=", 3)) { Lk = atoi(argv[first] + 3); ++first; }     // cross-attention: Lk=512
+        const int C = H * 128; const int64_t ldvt = (Lk + 63) / 64 * 64;
         auto hq = to_bf(randn((size_t)4096 * 128));
-        Dev<bf16> q((size_t)L * C), k((size_t)L * C), vt((size_t)C * ldvt), o((size_t)L * C);
+        Dev<bf16> q((size_t)L * C), k((size_t)Lk * C), vt((size_t)C * ldvt), o((size_t)L * C);
         auto fill = [&](Dev<bf16>& d) { for (size_t off = 0; off < d.n; off += hq.size()) HIP(hipMemcpy(d.p + off, hq.data(), std::min(hq.size(), d.n - off) * 2, hipMemcpyHostToDevice)); };
         fill(k); fill(vt);
         { std::vector<float> hf = bf_to_f(hq); for (auto& x : hf) x *= WAN_ATTN_QSCALE(0.0883883f); hq = to_bf(hf); }
         fill(q);
-        const int64_t wsb = wan_attention_workspace_bytes(1, L, L, H, 128);
+        const int64_t wsb = wan_attention_workspace_bytes(1, L, Lk, H, 128);
         Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
         const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp", "attn_w4", "attn_ref"};
         const int nkeys = 6;
@@ -812,8 +813,8 @@ int main(int argc, char** argv) {
                 const size_t eq = tok.find('=');
                 if (eq != std::string::npos) WAN(wan_set_tuning(tok.substr(0, eq).c_str(), atoi(tok.c_str() + eq + 1)));
             }
-            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, L, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr)); }, 4, 1);
-            printf("  attnx[%-28s] L=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", arm.c_str(), L, H, ms, 4.0 * L * L * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
+            double ms = time_ms([&] { WAN(wan_attention_fwd(q.p, C, 0, k.p, C, 0, vt.p, ldvt, 0, o.p, C, 0, 1, L, Lk, H, 128, 0.0883883f, WAN_ATTN_Q_PRESCALED, wsb ? ws.p : nullptr, wsb, nullptr)); }, Lk == L ? 4 : 20, 2);
+            printf("  attnx[%-28s] L=%d Lk=%d H=%d: %.3f ms  %.0f TFLOP/s  (variant 0x%x)\n", arm.c_str(), L, Lk, H, ms, 4.0 * L * Lk * C / ms / 1e9, wan_get_tuning("last_attn_variant"));
             fflush(stdout);
         }
     }
