@@ -7,7 +7,7 @@ repo=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$repo/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify"
+cmd="python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-e2e"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $cmd > "$out/trace.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- $cmd > "$out/pmc_$c.log" 2>&1

@@ -7,7 +7,7 @@ repo=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$repo/gpurun_out/profsq_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify ${BENCH_ARGS:-}"
+cmd="python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-e2e ${BENCH_ARGS:-}"
 i=0; args=""
 for grp in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD"; do
