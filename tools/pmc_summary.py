@@ -18,7 +18,7 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     m = re.search(r"(attn_fwd_w4_kernel<[^>]*>|gemm_pk_kernel<[^>]*>|gemm_w4_kernel<[^>]*>|attn_fwd_v2_kernel<[^>]*>|attn_fwd_kernel<[^>]*>|gemm256_kernel<[^>]*>|gemm_bf16_kernel<[^>]*>|"
-                  r"ln_modulate_kernel|rmsnorm_rope_kernel|rmsnorm_rope|conv_cl_kernel<[^>]*>|conv3_patch_kernel|conv3_head_kernel<[^>]*>|attn_combine_kernel)", name)
+                  r"ln_modulate_rows_kernel<[^>]*>|ln_modulate_kernel|rmsnorm_rope_rows_kernel|rmsnorm_rope_kernel|rmsnorm_rope|conv_cl_kernel<[^>]*>|conv3_patch_kernel|conv3_head_kernel<[^>]*>|attn_combine_kernel)", name)
     return m.group(1) if m else name[:60]
 
 
