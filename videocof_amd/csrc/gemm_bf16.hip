@@ -298,7 +298,9 @@ extern "C" wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void*
                                          void* out, int64_t ldo, int M, int N, int K, int epilogue,
                                          const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes,
                                          void* stream) {
-    if (workspace == nullptr || M <= 0 || N <= 0 || K <= 0 || wan_gemm_ws_plan(M, N, K) != WAN_GEMM_VARIANT_256_PK)
+    // (a gate whose samples are shorter than a wave's 128 rows: the persistent kernel's epilogue allows one sample seam per wave)
+    if (workspace == nullptr || M <= 0 || N <= 0 || K <= 0 || wan_gemm_ws_plan(M, N, K) != WAN_GEMM_VARIANT_256_PK ||
+        (gate != nullptr && rows_per_batch < 128))
         return wan_gemm_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, stream);
     WAN_REQUIRE(A && W && out, WAN_ERR_INVALID, "wan_gemm_bf16_ws: null tensor");
     WAN_REQUIRE(N % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_bf16_ws: N=%d must be a multiple of 4", N);

@@ -168,7 +168,12 @@ __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast
 template <int EPI, int SCHED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(PkArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
+    // D = mfma(A fragment, W fragment): lane (l15, kg) holds output COLUMN .. + l15 and the four consecutive ROWS .. + 4 kg .. + 3 of a
+    // tile -- the form of the transposed store, and (round 4) of the fp32 epilogues: there a register of the tile is 4 rows x 16
+    // CONSECUTIVE columns across the 16 lanes of a row group, i.e. 64 contiguous bytes per row group and dword access, where the
+    // swapped product puts consecutive ROWS on consecutive lanes and every lane's 16 bytes become a request of their own.
+    constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T || EPI == WAN_EPI_F32 || EPI == WAN_EPI_RESID_F32);
+    constexpr bool kRowMajorOut = (EPI != WAN_EPI_BF16_T);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
@@ -479,18 +484,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                 reduce_chunk(std::integral_constant<int, 2>{}); reduce_chunk(std::integral_constant<int, 3>{});
             }
             const int l4 = kg * 4;
+            int seam_b_lo = 0, seam_next = 0x7fffffff;
             if constexpr (!kTransposed) {
-                // Swapped product (W fragment as A operand): lane (l15, kg) holds output row m = .. + l15 and, per tile, the 4 consecutive
-                // columns n = .. + 4 kg .. + 3.  A batch = one m tile x four n tiles (one row, four float4 per lane): bias, residual stream and
-                // gate rows of a batch are loaded back to back, one batch ahead of their use.  Out-of-range rows / columns read a clamped
-                // address and are not stored.  (The wave-uniform options -- bias? gate? -- select straight-line copies.)
+                // bf16 outputs.  Swapped product (W fragment as A operand): lane (l15, kg) holds output row m = .. + l15 and, per tile, the 4
+                // consecutive columns n = .. + 4 kg .. + 3 (two bf16 pairs).  A batch = one m tile x four n tiles; the bias of a batch is
+                // loaded one batch ahead of its use.  Out-of-range rows / columns read a clamped address and are not stored.
                 // (wave-uniform: all 128 columns of the wave exist and every 8-column group is 16-byte aligned)
                 const bool wide = n0 + wc * 128 + 128 <= g.N && (g.ldo & 7) == 0 && (((uintptr_t)g.out) & 15) == 0;
-                auto epilogue_rows = [&](auto has_bias, auto has_gate) {
-                    constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_GATE = decltype(has_gate)::value;
-                    const int rpb = HAS_GATE ? (int)g.rows_per_batch : 1;
+                auto epilogue_rows = [&](auto has_bias) {
+                    constexpr bool HAS_BIAS = decltype(has_bias)::value;
                     struct Batch {
-                        float4 bq[4], xr[4], gq[4];
+                        float4 bq[4];
                         int nn[4], mm;
                         bool nok[4], mok;
                     };
@@ -498,7 +502,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                         const int m = m0 + wr * 128 + (bi >> 1) * 16 + l15;
                         B.mok = m < g.M;
                         B.mm = B.mok ? m : g.M - 1;
-                        const int64_t brow = HAS_GATE ? (int64_t)(B.mm / rpb) * g.N : 0;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int n = n0 + wc * 128 + ((bi & 1) * 4 + t) * 16 + l4;
@@ -506,11 +509,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                             B.nn[t] = B.nok[t] ? n : 0;
                             if constexpr (HAS_BIAS) B.bq[t] = *reinterpret_cast<const float4*>(g.bias + B.nn[t]);
                             else B.bq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if constexpr (EPI == WAN_EPI_RESID_F32) {
-                                B.xr[t] = *reinterpret_cast<const float4*>((const float*)g.out + (int64_t)B.mm * g.ldo + B.nn[t]);
-                                if constexpr (HAS_GATE) B.gq[t] = *reinterpret_cast<const float4*>(g.gate + brow + B.nn[t]);
-                                else B.gq[t] = make_float4(1.f, 1.f, 1.f, 1.f);
-                            }
                         }
                     };
                     auto store_batch = [&](int bi, const Batch& B) {
@@ -523,44 +521,32 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f32(v[r]);
                             }
-                            if constexpr (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16) {
-                                // 16-byte stores (CDNA4 guide T21): the tiles (q, q + 1) of a pair trade halves between lanes 16 apart --
-                                // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second
-                                // -- after which lane groups 0 / 2 own columns 0..7 / 8..15 of tile q and groups 1 / 3 those of tile
-                                // q + 1: a store instruction then covers 16 rows x 64 contiguous bytes instead of 16 x 32, and there
-                                // are half as many of them (the epilogue of a lone workgroup per CU is bound by store ISSUE)
-                                pk[q][0] = pack_bf16x2(v[0], v[1]); pk[q][1] = pack_bf16x2(v[2], v[3]);
-                                if (q & 1) {
-                                    if (wide) {
-                                        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[q - 1][0]), "+v"(pk[q][0]));
-                                        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[q - 1][1]), "+v"(pk[q][1]));
-                                        // this lane now holds 8 columns of tile q - 1 + (kg & 1): columns 8 (kg >> 1) .. + 7 of it
-                                        const int col = n0 + wc * 128 + ((bi & 1) * 4 + q - 1 + (kg & 1)) * 16 + (kg >> 1) * 8;
-                                        const u32x4 o = {pk[q - 1][0], pk[q - 1][1], pk[q][0], pk[q][1]};
-                                        if (B.mok) *reinterpret_cast<u32x4*>((bf16_t*)g.out + (int64_t)B.mm * g.ldo + col) = o;
-                                    } else {
+                            // 16-byte stores (CDNA4 guide T21): the tiles (q, q + 1) of a pair trade halves between lanes 16 apart --
+                            // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second
+                            // -- after which lane groups 0 / 2 own columns 0..7 / 8..15 of tile q and groups 1 / 3 those of tile
+                            // q + 1: a store instruction then covers 16 rows x 64 contiguous bytes instead of 16 x 32, and there
+                            // are half as many of them
+                            pk[q][0] = pack_bf16x2(v[0], v[1]); pk[q][1] = pack_bf16x2(v[2], v[3]);
+                            if (q & 1) {
+                                if (wide) {
+                                    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[q - 1][0]), "+v"(pk[q][0]));
+                                    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[q - 1][1]), "+v"(pk[q][1]));
+                                    // this lane now holds 8 columns of tile q - 1 + (kg & 1): columns 8 (kg >> 1) .. + 7 of it
+                                    const int col = n0 + wc * 128 + ((bi & 1) * 4 + q - 1 + (kg & 1)) * 16 + (kg >> 1) * 8;
+                                    const u32x4 o = {pk[q - 1][0], pk[q - 1][1], pk[q][0], pk[q][1]};
+                                    if (B.mok) *reinterpret_cast<u32x4*>((bf16_t*)g.out + (int64_t)B.mm * g.ldo + col) = o;
+                                } else {
 #pragma unroll
-                                        for (int qq = q - 1; qq <= q; ++qq) {
-                                            if (!(B.mok && B.nok[qq])) continue;
-                                            const u32x2 o = {pk[qq][0], pk[qq][1]};
-                                            *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)B.mm * g.ldo + B.nn[qq]) = o;
-                                        }
+                                    for (int qq = q - 1; qq <= q; ++qq) {
+                                        if (!(B.mok && B.nok[qq])) continue;
+                                        const u32x2 o = {pk[qq][0], pk[qq][1]};
+                                        *reinterpret_cast<u32x2*>((bf16_t*)g.out + (int64_t)B.mm * g.ldo + B.nn[qq]) = o;
                                     }
                                 }
-                                continue;
-                            }
-                            if (!(B.mok && B.nok[q])) continue;
-                            const int64_t off = (int64_t)B.mm * g.ldo + B.nn[q];
-                            if constexpr (EPI == WAN_EPI_F32) {
-                                *reinterpret_cast<float4*>((float*)g.out + off) = make_float4(v[0], v[1], v[2], v[3]);
-                            } else {
-                                *reinterpret_cast<float4*>((float*)g.out + off) =
-                                    make_float4(B.xr[q].x + v[0] * B.gq[q].x, B.xr[q].y + v[1] * B.gq[q].y, B.xr[q].z + v[2] * B.gq[q].z,
-                                                B.xr[q].w + v[3] * B.gq[q].w);
                             }
                         }
                     };
-                    // two batches in flight: the loads of batch b + 1 are issued before batch b is combined and stored
+                    // two batches in flight: the loads of batch b + 1 are issued before batch b is converted and stored
                     Batch B[2];
                     load_batch(0, B[0]);
 #pragma unroll
@@ -570,17 +556,84 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                         store_batch(bi, B[bi & 1]);
                     }
                 };
-                if constexpr (EPI == WAN_EPI_RESID_F32) {
-                    if (g.bias) {
-                        if (g.gate) epilogue_rows(std::true_type{}, std::true_type{});
-                        else epilogue_rows(std::true_type{}, std::false_type{});
-                    } else {
-                        if (g.gate) epilogue_rows(std::false_type{}, std::true_type{});
-                        else epilogue_rows(std::false_type{}, std::false_type{});
+                if (g.bias) epilogue_rows(std::true_type{});
+                else epilogue_rows(std::false_type{});
+            } else if constexpr (kRowMajorOut) {
+                // fp32 epilogues (plain and read-modify-write) from the UNswapped product: lane (l15, kg) holds column n = .. + l15 and
+                // rows m = .. + 4 kg + r of every tile, so register r of tile (i, j) is, across the wave, 4 rows x 64 contiguous bytes.
+                // Measured on the swapped form (profiles/r04/gemm_pk_resid_epilogue_loads_vs_stores.log): a lone workgroup moved its
+                // epilogue's bytes at ~16 B per clock of its CU whatever the prefetch depth -- one 16-byte request per LANE per clock,
+                // because consecutive lanes held consecutive rows.  Here 16 lanes share a request.
+                // A batch = one m tile (8 n tiles x 4 rows = 32 dwords per lane); the residual rows of batch i + 1 are requested before
+                // batch i is combined and stored.  bias / gate are per column = per lane: 8 + 8 registers for the whole tile.
+                auto epilogue_f32 = [&](auto has_bias, auto has_gate, auto seam) {
+                    constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_GATE = decltype(has_gate)::value, SEAM = decltype(seam)::value;
+                    constexpr bool RESID = EPI == WAN_EPI_RESID_F32;
+                    const int mw = m0 + wr * 128 + l4, nb = n0 + wc * 128 + l15;
+                    float bq[8], gq[8];
+                    int nn[8];
+                    bool nok[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = nb + j * 16;
+                        nok[j] = n < g.N;
+                        nn[j] = nok[j] ? n : 0;
+                        bq[j] = HAS_BIAS ? g.bias[nn[j]] : 0.f;
+                        gq[j] = (HAS_GATE && !SEAM) ? g.gate[(int64_t)seam_b_lo * g.N + nn[j]] : 1.f;
                     }
-                } else {         // the gate belongs to the residual epilogue only (wan_gemm_bf16_ws refuses it elsewhere)
-                    if (g.bias) epilogue_rows(std::true_type{}, std::false_type{});
-                    else epilogue_rows(std::false_type{}, std::false_type{});
+                    struct Rows { float x[8][4]; };
+                    auto row_of = [&](int i, int r) { return min(mw + i * 16 + r, g.M - 1); };      // clamped: a valid address, not stored
+                    auto load_rows = [&](int i, Rows& R) {
+                        if constexpr (RESID) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float* xp = (const float*)g.out + (int64_t)row_of(i, r) * g.ldo;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) R.x[j][r] = xp[nn[j]];
+                            }
+                        }
+                    };
+                    auto store_rows = [&](int i, const Rows& R) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mw + i * 16 + r;
+                            if (m >= g.M) continue;
+                            float* op = (float*)g.out + (int64_t)m * g.ldo;
+                            const float* gp = SEAM ? g.gate + (int64_t)(seam_b_lo + (m >= seam_next ? 1 : 0)) * g.N : nullptr;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                if (!nok[j]) continue;
+                                const float v = acc[i][j][r] + bq[j];
+                                if constexpr (RESID) op[nn[j]] = R.x[j][r] + v * (SEAM ? gp[nn[j]] : gq[j]);
+                                else op[nn[j]] = v;
+                            }
+                        }
+                    };
+                    Rows R[2];
+                    load_rows(0, R[0]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (i + 1 < 8) load_rows(i + 1, R[(i + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_rows(i, R[i & 1]);
+                    }
+                };
+                using T = std::true_type; using F = std::false_type;
+                if constexpr (EPI == WAN_EPI_RESID_F32) {
+                    if (g.gate) {
+                        // the gate row of a token row is that of its sample, row / rows_per_batch: one (scalar) division per wave and tile;
+                        // rows_per_batch >= 128 (the host sends anything else to the per-tile kernels), so the 128 rows of a wave meet at
+                        // most one boundary: the wave that holds it runs the SEAM copy (gate fetched per row)
+                        seam_b_lo = __builtin_amdgcn_readfirstlane(min(m0 + wr * 128, g.M - 1) / (int)g.rows_per_batch);
+                        seam_next = (seam_b_lo + 1) * (int)g.rows_per_batch;
+                        const bool one_sample = min(m0 + wr * 128 + 127, g.M - 1) < seam_next;       // wave-uniform
+                        if (one_sample) { if (g.bias) epilogue_f32(T{}, T{}, F{}); else epilogue_f32(F{}, T{}, F{}); }
+                        else { if (g.bias) epilogue_f32(T{}, T{}, T{}); else epilogue_f32(F{}, T{}, T{}); }
+                    } else {
+                        if (g.bias) epilogue_f32(T{}, F{}, F{}); else epilogue_f32(F{}, F{}, F{});
+                    }
+                } else {
+                    if (g.bias) epilogue_f32(T{}, F{}, F{}); else epilogue_f32(F{}, F{}, F{});
                 }
             } else {
                 // Transposed store: D = mfma(A fragment, W fragment): lane (l15, kg) holds output column n = .. + l15 and the 4 consecutive
