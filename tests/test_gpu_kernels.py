@@ -688,6 +688,26 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
 
 
+def test_persistent_gemm_gate_with_short_samples_takes_the_per_tile_kernels():
+    """The persistent kernel's read-modify-write epilogue allows ONE sample seam per 128-row wave; a gate whose samples are shorter
+    (rows_per_batch < 128) is served by the per-tile kernels behind the same entry point -- same result as the fp64 statement."""
+    M, N, K, rpb = 2304, 1536, 896, 100
+    g = torch.Generator().manual_seed(21)
+    a, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    bias, gate, resid = torch.randn(N, generator=g), torch.randn((M + rpb - 1) // rpb, N, generator=g), torch.randn(M, N, generator=g)
+    ops.set_tuning("gemm_pk", 2)
+    try:
+        outs = []
+        for r in (rpb, 1152):                              # 1152: the persistent kernel (one seam, in the middle of a wave's rows)
+            o = resid.to(DEV).clone()
+            ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), ops.EPI_RESID_F32, out=o, gate=gate.to(DEV), rows_per_batch=r)
+            gsel = gate.double()[torch.arange(M) // r]
+            assert rel_l2(o, resid.double() + (a.double() @ w.double().t() + bias.double()) * gsel) < 1e-5, r
+            outs.append(o)
+    finally:
+        ops.set_tuning("gemm_pk", 1)
+
+
 def test_persistent_gemm_beyond_4gib():
     """gemm_pk_kernel where byte offsets leave 32 bits (BASELINE configs[4] on one device: 586 800 tokens x 5 120 fp32 = 12 GB of
     residual stream, 16 GB of ffn activations): an A operand of 4.4 GB (M = 330 000 rows of K = 6 656) and an fp32 read-modify-write
