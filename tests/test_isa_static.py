@@ -103,3 +103,54 @@ def test_attention_f8_main_loop_is_clean(attn_asm):
                 "v_accvgpr_mov_b32", "v_readlane_b32", "v_writelane_b32"):
         assert h.get(bad, 0) == 0, (bad, h.get(bad))
     assert sum(c for k, c in h.items() if k.startswith("v_")) <= 420
+
+
+# ------------------------------------------------------------------ the persistent stream-K GEMM (videocof_amd/csrc/gemm_bf16_pk.hip)
+@pytest.fixture(scope="module")
+def pk_asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa_pk")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", "-DWAN_DEV_EXPERIMENTS=0",
+           "-I" + os.path.join(ROOT, "include"), "--save-temps", "-c", os.path.join(ROOT, "videocof_amd", "csrc", "gemm_bf16_pk.hip"),
+           "-o", str(d / "pk.o")]
+    subprocess.run(cmd, check=True, cwd=d, capture_output=True)
+    s = next(p for p in os.listdir(d) if p.endswith("gfx950.s"))
+    return open(d / s).read().split("\n")
+
+
+@pytest.mark.parametrize("epi,what", [(0, "bf16"), (1, "gelu"), (2, "f32"), (3, "resid"), (4, "transposed")])
+def test_persistent_gemm_kernels_are_clean(pk_asm, epi, what):
+    """What must not creep back into gemm_pk_kernel<EPI, 1> (the product schedule): scratch (the kernel owns all 512 registers of a
+    lane; hipcc spills at the slightest excuse, and a spilled address is reloaded behind a vmcnt(0)), a main loop that is not exactly
+    256 MFMAs / 64 fragment reads / 32 LDS-DMA requests per two K tiles, and -- for the fp32 epilogues -- the one-16-byte-request-
+    per-lane form: they move their rows with dword accesses that the 16 lanes of a row group share."""
+    mangled = f"gemm_pk_kernelILi{epi}ELi1E"
+    body = _kernel(pk_asm, mangled)
+    meta = "\n".join(pk_asm)
+    priv = re.search(re.escape(mangled) + r"\w*\.private_seg_size, (\d+)", meta)
+    assert priv and int(priv.group(1)) == 0, (what, "scratch", priv and priv.group(1))
+    assert not any("scratch_" in l for l in body), what
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for j, l in enumerate(body):                         # the K loop = the SHORTEST backward branch range that holds MFMAs
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)\s*$", l)
+        if not m or labels.get(m.group(1), j) >= j:
+            continue
+        seg = body[labels[m.group(1)]:j + 1]
+        n = sum("v_mfma_f32_16x16x32_bf16" in x for x in seg)
+        if n and (best is None or len(seg) < len(best[1])):
+            best = (n, seg)
+    assert best is not None, what
+    n, seg = best
+    assert n == 256, (what, n)
+    count = lambda op: sum(1 for l in seg if re.match(r"\s+" + op + r"\b", l))
+    assert count("ds_read_b128") == 64 and count("buffer_load_dwordx4") == 32, (what, count("ds_read_b128"), count("buffer_load_dwordx4"))
+    assert count("s_barrier") == 4
+    for bad in ("v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_accvgpr_mov_b32", "v_readlane_b32", "v_writelane_b32"):
+        assert count(bad) == 0, (what, bad)
+    whole = lambda op: sum(1 for l in body if re.match(r"\s+" + op + r"\b", l))
+    if what in ("f32", "resid"):
+        assert whole("global_store_dwordx4") == 0 and whole("global_store_dword") >= 256, (what, whole("global_store_dword"))
+        if what == "resid":
+            assert whole("global_load_dword") >= 256
+    if what in ("bf16", "gelu"):
+        assert whole("v_permlane16_swap_b32") >= 64 and whole("global_store_dwordx4") >= 32
