@@ -589,7 +589,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                             for (int r = 0; r < 4; ++r) {
                                 const float* xp = (const float*)g.out + (int64_t)row_of(i, r) * g.ldo;
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) R.x[j][r] = xp[nn[j]];
+                                for (int j = 0; j < 8; ++j) {
+#if WAN_DEV_EXPERIMENTS
+                                    if (g.exp & 128) { R.x[j][r] = 0.f; continue; }          // timing only: no residual loads
+#endif
+                                    R.x[j][r] = xp[nn[j]];
+                                }
                             }
                         }
                     };
@@ -604,6 +609,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                             for (int j = 0; j < 8; ++j) {
                                 if (!nok[j]) continue;
                                 const float v = acc[i][j][r] + bq[j];
+#if WAN_DEV_EXPERIMENTS
+                                if (g.exp & 256) { asm volatile("" :: "v"(R.x[j][r] + v * gq[j])); continue; }      // timing only: no stores
+#endif
                                 if constexpr (RESID) op[nn[j]] = R.x[j][r] + v * (SEAM ? gp[nn[j]] : gq[j]);
                                 else op[nn[j]] = v;
                             }
