@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 7      /* 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
+#define WAN_ABI_VERSION 8      /* 8: wan_qk_quantize_fp8 takes either operand alone, tuning key gemm_pk_form replaces gemm_pk_sched, the persistent GEMM from K >= 1024; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -275,7 +275,9 @@ wan_status_t wan_rmsnorm_rope_fp8(const void* x0_bf16, const float* w0, const vo
  *   wan_col_mean_bf16:   mean[b][c] = mean over rows [0, valid_rows) of sample b of x (bf16 [batch * rows_per_batch][ld]); two-stage,
  *                        fixed summation order (bit-reproducible); workspace of wan_col_mean_workspace_bytes(batch, dim) bytes.
  *   wan_qk_quantize_fp8: q8 = e4m3(q * q_scale), k8 = e4m3((k - k_mean[b]) * k_scale), dense [rows][dim] bytes; q, k are the
- *                        bf16 results of wan_rmsnorm_rope (q already carries softmax_scale * log2(e)); k_mean = NULL: no smoothing. */
+ *                        bf16 results of wan_rmsnorm_rope (q already carries softmax_scale * log2(e)); k_mean = NULL: no smoothing.
+ *                        Either operand may be left out (q_bf16 = q8 = NULL or k_bf16 = k8 = NULL; ABI 8): under Ulysses k is
+ *                        quantised once when it has arrived, every head group of q when its own exchange has completed. */
 int64_t wan_col_mean_workspace_bytes(int batch, int dim);
 wan_status_t wan_col_mean_bf16(const void* x_bf16, int64_t ld, int64_t rows_per_batch, int valid_rows, int batch, int dim,
                                void* workspace, float* mean, void* stream);

@@ -64,7 +64,12 @@ def test_workspace_entry_falls_back_and_validates():
     assert lib.wan_gemm_ws_plan(515, 64, 1024) == lib.wan_gemm_plan(515, 64, 1024)
     assert lib.wan_gemm_workspace_bytes(515, 64, 1024) == 0
     assert lib.wan_gemm_ws_plan(67080, 5120, 5120) == 3 and _lib.GEMM_VARIANT_KERNELS[3] == "gemm_pk_kernel"
-    assert lib.wan_gemm_ws_plan(67080, 5120, 1536) == lib.wan_gemm_plan(67080, 5120, 1536) == 1          # shallow K stays on the 8-wave kernel
+    # round 5: the K = 1536 Linears of the 1.3B model at a video's token count run the persistent kernel too (K % 128 == 0, K >= 1024);
+    # without a workspace they stay on the 8-wave per-tile kernel, and shallow K (the VAE attention block's 384) stays there either way
+    assert lib.wan_gemm_ws_plan(67080, 5120, 1536) == 3 and lib.wan_gemm_plan(67080, 5120, 1536) == 1
+    assert lib.wan_gemm_ws_plan(67080, 1536, 8960) == 3 and lib.wan_gemm_ws_plan(67080, 3072, 1536) == 3
+    assert lib.wan_gemm_ws_plan(6240, 6240, 384) == lib.wan_gemm_plan(6240, 6240, 384) == 1
+    assert lib.wan_gemm_ws_plan(2304, 3072, 1536) == lib.wan_gemm_plan(2304, 3072, 1536) == 0              # < 1 tile per 2 CUs: the 128^2 kernel
     need = int(lib.wan_gemm_workspace_bytes(67080, 5120, 5120))
     st = lib.wan_gemm_bf16_ws(16, 5120, 16, 5120, None, 16, 5120, 67080, 5120, 5120, 0, None, 0, 16, need - 1, None)
     assert st == _lib.WAN_ERR_INVALID and b"workspace" in lib.wan_last_error()

@@ -645,13 +645,16 @@ def test_gemm_256_tile_kernels_all_epilogues(M, N, K, w4):
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
 
 
-@pytest.mark.parametrize("sched", [1, 0])
-@pytest.mark.parametrize("M,N,K", [(1100, 520, 512), (2304, 1536, 896), (4100, 2100, 256), (9000, 5120, 640)])
-def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
+@pytest.mark.parametrize("form", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(1100, 520, 512), (2304, 1536, 896), (4100, 2100, 256), (9000, 5120, 640), (3000, 1164, 384)])
+def test_persistent_stream_k_gemm_all_epilogues(M, N, K, form):
     """wan_gemm_bf16_ws (gemm_pk_kernel: one resident workgroup per CU, 16x16x32 MFMAs, continuous K-tile stream, tiles by
     per-XCD ticket, stream-K remainder combined in K order) at shapes that are mostly or partly SPLIT tiles (15 .. 720 tiles on 256
     workers), ragged M / N: every epilogue against an fp64 product of the same bf16 operands; bitwise run-to-run (the combine
-    order does not depend on who arrives last); garbage in the workspace does not matter."""
+    order does not depend on who arrives last); garbage in the workspace does not matter.  form 1 (product): the epilogues run from
+    row-permuted operand tiles (a lane's accumulators contiguous in the output: 16-byte stores of whole row segments); form 0: the
+    round-4 epilogues.  (3000, 1164, 384): N is not a multiple of 8 -- the last 4-column group of a row takes the 8-byte path -- and
+    the transposed output's row stride (3008) keeps 16-byte alignment while M does not fill the last 8-token group."""
     g = torch.Generator().manual_seed(M + N + K)
     a, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
     bias = torch.randn(N, generator=g) * 0.5
@@ -661,7 +664,7 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
     ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
     rpb = (M + 1) // 2
     ops.set_tuning("gemm_pk", 2)                       # 2 = whenever K % 128 == 0 (the default takes shapes the 4-wave kernel would)
-    ops.set_tuning("gemm_pk_sched", sched)
+    ops.set_tuning("gemm_pk_form", 31 if form else 0)
     try:
         from videocof_amd import _lib
         assert _lib.load().wan_gemm_ws_plan(M, N, K) == 3
@@ -676,7 +679,7 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
                          o_res, ops.gemm(ad, wd, None, ops.EPI_BF16_T)))
     finally:
         ops.set_tuning("gemm_pk", 1)
-        ops.set_tuning("gemm_pk_sched", 1)
+        ops.set_tuning("gemm_pk_form", 31)
     o_bf, o_ge, o_f32, o_res, o_t = runs[0]
     assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
     assert rel_l2(o_bf, acc) < 4e-3 and rel_l2(o_f32, acc) < 1e-5
@@ -686,6 +689,81 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, sched):
     assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
     assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc - bias.double()) < 4e-3
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_persistent_gemm_row_permuted_epilogues_equal_the_round4_epilogues_bitwise(aligned):
+    """gemm_pk_form = 1 changes WHERE a panel row sits in LDS (so that a lane's accumulators are contiguous in the output) and
+    nothing about the arithmetic: every output element is the same MFMA chain in the same k order.  All five epilogues, ragged
+    M / N, a sample seam inside a wave's rows, and -- `aligned` False -- output row strides that are multiples of 4 but not of 8
+    (bf16 rows then start on 8-byte boundaries only: the 16-byte stores fall back to 8-byte ones): bitwise equal to form 0."""
+    M, N, K = 2900, 1672, 640
+    g = torch.Generator().manual_seed(77)
+    a, w = bf(torch.randn(M, K, generator=g)).to(DEV), bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias, gate = torch.randn(N, generator=g).to(DEV), torch.randn(3, N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    pad = 0 if aligned else 4
+    ldt = ops.round_up(M, 64) + pad
+    res = {}
+    ops.set_tuning("gemm_pk", 2)
+    try:
+        for form in (1, 0):
+            ops.set_tuning("gemm_pk_form", 31 if form else 0)
+            o_bf = torch.zeros(M, N + pad, device=DEV, dtype=torch.bfloat16)[:, :N]
+            o_ge = torch.zeros(M, N + pad, device=DEV, dtype=torch.bfloat16)[:, :N]
+            o_f = torch.zeros(M, N + pad, device=DEV, dtype=torch.float32)[:, :N]
+            o_r = torch.zeros(M, N + pad, device=DEV, dtype=torch.float32)[:, :N]
+            o_r.copy_(resid)
+            o_t = torch.zeros(N, ldt, device=DEV, dtype=torch.bfloat16)
+            ops.gemm(a, w, bias, ops.EPI_BF16, out=o_bf)
+            ops.gemm(a, w, bias, ops.EPI_GELU_BF16, out=o_ge)
+            ops.gemm(a, w, None, ops.EPI_F32, out=o_f)
+            ops.gemm(a, w, bias, ops.EPI_RESID_F32, out=o_r, gate=gate, rows_per_batch=1000)       # seams at rows 1000 and 2000
+            ops.gemm(a, w, bias, ops.EPI_BF16_T, out=o_t)
+            res[form] = [t.clone() for t in (o_bf, o_ge, o_f, o_r, o_t)]
+    finally:
+        ops.set_tuning("gemm_pk", 1)
+        ops.set_tuning("gemm_pk_form", 31)
+    for name, x, y in zip(("bf16", "gelu", "f32", "resid", "transposed"), res[1], res[0]):
+        assert torch.equal(x, y), name
+    acc = a.double() @ w.double().t()
+    gsel = gate.double()[torch.arange(M, device=DEV) // 1000]
+    assert rel_l2(res[1][3], resid.double() + (acc + bias.double()) * gsel) < 1e-5
+    assert rel_l2(res[1][4][:, :M].t(), acc + bias.double()) < 4e-3 and float(res[1][4][:, M:].abs().max()) == 0.0
+
+
+def test_persistent_gemm_workspace_is_per_stream():
+    """ops.gemm's workspace (arrival / ticket counters and split-tile partial sums of the persistent kernel) is keyed by
+    (device, stream): two streams issuing large Linears of one device CONCURRENTLY never share counters.  Both streams run the
+    same mostly-split product many times, interleaved from the host without any synchronisation between them; every result
+    must be the bitwise result of the product run alone."""
+    M, N, K = 9000, 5120, 640
+    g = torch.Generator().manual_seed(5)
+    a, w = bf(torch.randn(M, K, generator=g)).to(DEV), bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    b2 = bf(torch.randn(M, K, generator=g)).to(DEV)
+    ops.set_tuning("gemm_pk", 2)
+    try:
+        ref_a, ref_b = ops.gemm(a, w, None, ops.EPI_BF16), ops.gemm(b2, w, None, ops.EPI_BF16)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            ws1 = ops.gemm_workspace(a.device, M, N, K)
+        with torch.cuda.stream(s2):
+            ws2 = ops.gemm_workspace(a.device, M, N, K)
+        assert ws1.data_ptr() != ws2.data_ptr() and ws1.data_ptr() != ops.gemm_workspace(a.device, M, N, K).data_ptr()
+        outs1 = [torch.empty_like(ref_a) for _ in range(6)]
+        outs2 = [torch.empty_like(ref_b) for _ in range(6)]
+        for o1, o2 in zip(outs1, outs2):
+            with torch.cuda.stream(s1):
+                ops.gemm(a, w, None, ops.EPI_BF16, out=o1)
+            with torch.cuda.stream(s2):
+                ops.gemm(b2, w, None, ops.EPI_BF16, out=o2)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            assert ops.gemm_workspace(a.device, M, N, K).data_ptr() == ws1.data_ptr()       # stable per stream
+    finally:
+        ops.set_tuning("gemm_pk", 1)
+    assert all(torch.equal(o, ref_a) for o in outs1) and all(torch.equal(o, ref_b) for o in outs2)
 
 
 def test_persistent_gemm_gate_with_short_samples_takes_the_per_tile_kernels():

@@ -208,44 +208,56 @@ def _fp8_attn_sp_worker(port, q_out):
         cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=layers, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
         m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=layers, text_dim=64)
         m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
-        lat = det_uniform("sp.lat", (1, 16, 7, 12, 20), 1.0).cuda()
-        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda()]
-        t = torch.tensor([749], device="cuda:0")
-        kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+        # the CFG batch of BASELINE configs[3] (two samples, two prompts): the token-major wire [P*Ll][B][Cl] is quantised as one matrix
+        lat = det_uniform("sp.lat", (2, 16, 7, 12, 20), 1.0).cuda()
+        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda(), det_uniform("sp.c1", (5, 64), 1.0).cuda()]
+        t = torch.tensor([749, 749], device="cuda:0")
+        kw = dict(frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
         bf16 = m(lat, t, ctx, 420, **kw)
         vdist.init_sequence_parallel()
         m.enable_multi_gpus_inference()
         res = []
         for layers_ in (("attn",), ("attn", "attn_pv")):
-            m.enable_fp8_linear(layers_)
+            m.enable_fp8_linear(layers_)                         # (fresh per-layer exponents: calibrated on the next forward)
             m.force_ulysses = False
             single = m(lat, t, ctx, 420, **kw)
+            exp_single = [tuple(b.f8["attn_exp"]) for b in m.blocks]
+            m.enable_fp8_linear(layers_)                         # forget them: the Ulysses branch calibrates for itself
             m.force_ulysses = True
+            assert m.sp_head_groups == 2                         # 4 local heads as 2 | 2: q groups quantised on arrival
             sharded = m(lat, t, ctx, 420, **kw)
+            exp_sp = [tuple(b.f8["attn_exp"]) for b in m.blocks]
             variant = ops.get_tuning("last_attn_variant")        # the last attention call of a forward is the bf16 cross-attention
             again = m(lat, t, ctx, 420, **kw)
+            m.sp_head_groups = 1
+            one_group = m(lat, t, ctx, 420, **kw)
+            m.sp_head_groups = 2
             wb = m._bufs[m._bufs_last]
             used = m._usp and wb.vt is None and hasattr(wb, "q8") and (("attn_pv" not in layers_) or hasattr(wb, "v8"))
             torch.cuda.synchronize()
             res.append((float((sharded - single).norm() / single.norm()), float((sharded - bf16).norm() / bf16.norm()),
-                        bool(torch.equal(again, sharded)), bool(used), bool(torch.equal(sharded, bf16)), variant))
+                        bool(torch.equal(again, sharded)), bool(used), bool(torch.equal(sharded, bf16)), variant,
+                        exp_single == exp_sp, float((one_group - sharded).norm() / sharded.norm())))
         q_out.put(res)
     finally:
         dist.destroy_process_group()
 
 
 def test_fp8_attention_options_under_ulysses():
-    """`enable_fp8_linear(("attn",))` / `(("attn", "attn_pv"))` with sequence parallelism on: same result as the single-device fp8 forward
-    up to the different q | k projection split, repeatable bitwise, and really different from the bf16 forward (the fp8 kernels ran)."""
+    """`enable_fp8_linear(("attn",))` / `(("attn", "attn_pv"))` with sequence parallelism on, a CFG batch of two samples, per-layer
+    CALIBRATED exponents and head-group pipelining (2 | 2): same result as the single-device fp8 forward up to the different q | k
+    projection split, the same calibrated exponents, repeatable bitwise, and really different from the bf16 forward."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_fp8_attn_sp_worker, args=(_free_port(), q))
     p.start()
     p.join(600)
     assert p.exitcode == 0
-    for rel_single, rel_bf16, again, used, same_as_bf16, _ in q.get(timeout=5):
+    for rel_single, rel_bf16, again, used, same_as_bf16, _, same_exponents, rel_groups in q.get(timeout=5):
         assert used and again and not same_as_bf16
+        assert same_exponents            # the Ulysses branch calibrates the per-layer exponents a single device measures
         assert rel_single < 5e-3 and 0 < rel_bf16 < 3e-2, (rel_single, rel_bf16)
+        assert rel_groups < 2e-3         # head groups: the same operands quantised per group (heads are independent)
 
 
 def _fp8_attn_gloo_worker(rank, world, port, q_out):
@@ -257,28 +269,37 @@ def _fp8_attn_gloo_worker(rank, world, port, q_out):
         from videocof_amd import WanTransformer3DModel
         from videocof_amd import dist as vdist
         from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
-        heads = 4
+        heads = 8
         cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
         m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=2, text_dim=64)
-        m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
-        lat = det_uniform("sp.lat", (1, 16, 7, 12, 20), 1.0).cuda()
-        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda()]
-        t = torch.tensor([749], device="cuda:0")
-        kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+        sd = deterministic_dit_state_dict(**cfgd)
+        # head-dependent q gains: the largest |q| sits in ONE rank's heads, so the ranks only agree on the exponents through the reduction
+        for i in range(2):
+            sd[f"blocks.{i}.self_attn.norm_q.weight"][5 * 128:6 * 128] *= 6.0
+        m.load_state_dict(sd, device="cuda:0")
+        lat = det_uniform("sp.lat", (2, 16, 7, 12, 20), 1.0).cuda()
+        ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda(), det_uniform("sp.c1", (5, 64), 1.0).cuda()]
+        t = torch.tensor([749, 749], device="cuda:0")
+        kw = dict(frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
         m.enable_fp8_linear(("attn", "attn_pv"))
         single = m(lat, t, ctx, 420, **kw)
+        exp_single = [tuple(b.f8["attn_exp"]) for b in m.blocks]
+        m.enable_fp8_linear(("attn", "attn_pv"))
         vdist.init_sequence_parallel()
         m.enable_multi_gpus_inference()
         sharded = m(lat, t, ctx, 420, **kw)
+        exp_sp = [tuple(b.f8["attn_exp"]) for b in m.blocks]
         torch.cuda.synchronize()
-        q_out.put((rank, float((sharded - single).norm() / single.norm())))
+        q_out.put((rank, float((sharded - single).norm() / single.norm()), exp_single == exp_sp, exp_sp != [(5, 2)] * 2))
     finally:
         dist.destroy_process_group()
 
 
 def test_fp8_attention_sharded_over_two_ranks_equals_single_device():
-    """All-fp8 attention with the heads REALLY split (2 ranks, gloo, shared GPU): each rank quantises its arrived heads (K mean over all
-    tokens, MX V^T) -- same numbers as the single-device fp8 forward up to the projection split."""
+    """All-fp8 attention with the heads REALLY split (2 ranks, gloo, shared GPU; 8 heads = 4 local as 2 | 2 head groups; a CFG batch of
+    two): each rank quantises its arrived heads (K mean over all tokens, MX V^T per group) with per-layer exponents CALIBRATED on the
+    first forward and agreed through an all-reduce(max) -- one rank's heads carry a x6 q gain, so without the reduction the ranks
+    would differ -- same exponents and same numbers as the single-device fp8 forward up to the projection split."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -292,6 +313,7 @@ def test_fp8_attention_sharded_over_two_ranks_equals_single_device():
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert all(r[1] < 5e-3 for r in res), res
     assert len({round(r[1], 9) for r in res}) == 1
+    assert all(r[2] and r[3] for r in res), res          # calibrated (not the static pair), and equal to the single device's
 
 
 def _library_comm_worker(q_out):

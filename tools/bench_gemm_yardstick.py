@@ -32,6 +32,15 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("SP8 ffn.2 + resid", 8392, 5120, 13824, "resid"),
     ("1.3B small ffn.2", 2304, 1536, 8960, "resid"),
     ("1.3B small ffn.0", 2304, 8960, 1536, "gelu"),
+    ("1.3B small q|k", 2304, 3072, 1536, "bf16"),
+    ("1.3B small o + resid", 2304, 1536, 1536, "resid"),
+    # BASELINE configs[1]: the 1.3B-width Linears at the VideoCoF token count (K = 1536 except ffn.2)
+    ("1.3B cof q|k", 67080, 3072, 1536, "bf16"),
+    ("1.3B cof v (T)", 67080, 1536, 1536, "bf16_t"),
+    ("1.3B cof o + gate + resid", 67080, 1536, 1536, "resid"),
+    ("1.3B cof cross q", 67080, 1536, 1536, "bf16"),
+    ("1.3B cof ffn.0 + gelu", 67080, 8960, 1536, "gelu"),
+    ("1.3B cof ffn.2 + gate + resid", 67080, 1536, 8960, "resid"),
 ]
 EPI = {"bf16": ops.EPI_BF16, "gelu": ops.EPI_GELU_BF16, "resid": ops.EPI_RESID_F32, "bf16_t": ops.EPI_BF16_T}
 
@@ -53,6 +62,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default="", help="substring filter on the shape names (comma list); skips the K-scaling rows too")
     ap.add_argument("--tuning", default="", help="comma list k=v applied through wan_set_tuning before the run")
     args = ap.parse_args()
     for kv in filter(None, args.tuning.split(",")):
@@ -61,7 +71,10 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     rows = []
+    only = [t for t in args.only.split(",") if t]
     for name, M, N, K, epi in SHAPES:
+        if only and not any(t in name for t in only):
+            continue
         a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         w = (torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02)
         bias = torch.randn(N, device=dev, dtype=torch.float32)
@@ -98,7 +111,7 @@ def main():
         del a, w, x, out_t, vt
         torch.cuda.empty_cache()
     # fixed cost per output tile: same M, N at K and 2K (plain bf16 epilogue)
-    for M, N, K in [(67080, 5120, 5120), (67080, 5120, 2560), (8392, 5120, 5120)]:
+    for M, N, K in ([] if only else [(67080, 5120, 5120), (67080, 5120, 2560), (8392, 5120, 5120)]):
         ts = []
         for kk in (K, 2 * K):
             a = torch.randn(M, kk, device=dev, dtype=torch.bfloat16)

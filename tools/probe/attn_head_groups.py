@@ -25,7 +25,7 @@ def timed(fn, n=4):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for Hl in (5, 10, 20):
+for Hl in (5, 10, 12, 20, 40):       # 12: the 1.3B model on one device; 40: the 14B model on one device (same process, same box)
     Cl = Hl * 128
     q = torch.randn(L, 1, Cl, device=dev, generator=g).bfloat16()
     k = torch.randn(L, 1, Cl, device=dev, generator=g).bfloat16()

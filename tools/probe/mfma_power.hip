@@ -29,7 +29,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < 4; ++j) {
                     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i * 4 + j]) : "v"(a[i]), "v"(b[j]));
                     if (LDS && ((i * 4 + j) & 1) == 0) { const int f = (i * 4 + j) / 2; if (f < 4) a[4 + f] = lp[(f * 64 + it * 7) & 4032]; else b[f] = lp[(f * 64 + it * 5) & 4032]; }
-                    if (LDS == 2) {      // the softmax stream of an attention tile: per 32x32x16 MFMA one v_exp_f32, one v_add_f32, half a v_cvt_pk_bf16_f32
+                    if (LDS >= 2) {      // the softmax stream of an attention tile: per 32x32x16 MFMA one v_exp_f32, one v_add_f32, half a v_cvt_pk_bf16_f32
+                        // LDS == 3: HALF the exponentials (the optimistic bound of an exponential that produces two values per instruction,
+                        // e.g. a packed-f16 form, with nothing else added); LDS == 4: none at all (adds and converts only)
+                        if (LDS == 2 || (LDS == 3 && ((i * 4 + j) & 1) == 0))
                         asm volatile("v_exp_f32 %0, %1" : "=v"(ex[(i * 4 + j) & 7]) : "v"(xs[(i * 4 + j) & 7]));
                         asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(i * 4 + j + 4) & 7]));
                         if (((i * 4 + j) & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(i * 4 + j) >> 1 & 3]) : "v"(ex[(i * 4 + j) & 7]), "v"(ex[(i * 4 + j + 1) & 7]));
@@ -94,6 +97,8 @@ int main() {
         snprintf(nm, sizeof nm, "16x16x32, %s operands, + ds_read_b128 per 4 MFMA", d); run<16, 1>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + softmax VALU stream", d); run<32, 2>(nm, src, out);
         snprintf(nm, sizeof nm, "16x16x32, %s, + LDS reads + softmax VALU stream", d); run<16, 2>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with HALF the v_exp", d); run<32, 3>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with NO v_exp", d); run<32, 4>(nm, src, out);
     }
     return 0;
 }

@@ -68,7 +68,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"gemm_pk_workers", "WAN_GEMM_PK_WORKERS", 0},      // its grid (0 = one workgroup per CU); developer A/B
     {"gemm_pk_min_units", "WAN_GEMM_PK_MIN_UNITS", 0},  // smallest stream-K range in units of two K tiles (0 = a quarter of the tile's K range)
     {"gemm_pk_order", "WAN_GEMM_PK_ORDER", 0},          // 1 = whole tiles in lockstep order instead of by per-XCD ticket (developer A/B)
-    {"gemm_pk_sched", "WAN_GEMM_PK_SCHED", 1},          // main-loop schedule of the persistent GEMM: 0 = one barrier per K tile, 1 = schedule D (requests spread over 3/4 of the K tile)
+    {"gemm_pk_form", "WAN_GEMM_PK_FORM", 29},           // epilogues of the persistent GEMM, one bit per WAN_EPI_* value: 1 = from row-permuted operand tiles (a lane's accumulators contiguous in the output), 0 = the round-4 form (developer A/B)
     {"row_group", "WAN_ROW_GROUP", 2},                  // LN-modulate / RMSNorm+RoPE: token rows per workgroup (2 or 4: per-column parameters fetched once per group; 1 = the one-row kernels)
 };
 struct Tuning {

@@ -626,14 +626,16 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     const int64_t k_row_bytes = QK8 ? a.ldk8 : a.ldk * 2;
     const int64_t k_tile_bytes = (int64_t)kKV * k_row_bytes;
     const char* const k_origin = QK8 ? (const char*)K8 : (const char*)K;
+    // (a.tile_mask: 0x7fffffff in product; the developer experiment attn_exp & 1 sets 15, so that the staging re-reads tiles 0..15
+    // and every K / V^T tile is L2-resident -- TIMING / COUNTERS ONLY, the results are garbage: what the fabric traffic costs in clock)
     auto k_rsrc = [&](int t) {          // tile min(t, nkv-1): a request past the end re-stages the last tile into a dead slot
-        const int tc = min(t, nkv - 1);
+        const int tc = min(t, nkv - 1) & a.tile_mask;
         const int64_t left = (int64_t)(Lk - tc * kKV) * k_row_bytes;             // bytes from the tile origin to the end of row Lk-1
         return __builtin_amdgcn_make_buffer_rsrc((void*)(k_origin + tc * k_tile_bytes), 0,
                                                  (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto v_rsrc = [&](int t) {          // tile min(t, nkv-1) (t <= nkv - 1 on every call); V^T pad columns exist up to roundup(Lk, 64)
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)min(t, nkv - 1) * kKV * 2), 0, 0x7fffffff, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)(min(t, nkv - 1) & a.tile_mask) * kKV * 2), 0, 0x7fffffff, 0x00020000);
     };
     auto stage_k_piece = [&](__amdgpu_buffer_rsrc_t r, int kslot, int j) {
         if constexpr (QK8) {

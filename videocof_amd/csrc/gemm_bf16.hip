@@ -278,13 +278,18 @@ extern "C" int wan_gemm_plan(int M, int N, int K) {
     return wan_gemm256_uses_w4(K) ? WAN_GEMM_VARIANT_256_W4 : WAN_GEMM_VARIANT_256_W8;
 }
 
-// The persistent stream-K form (gemm_bf16_pk.hip) takes a product when the caller brought a workspace and the 4-wave 256^2
-// kernel would have run it (gemm_pk = 1, default); gemm_pk = 2: whenever its shape rules allow (K % 128 == 0, at least one 256^2
-// tile each way); 0: never.
+// The persistent stream-K form (gemm_bf16_pk.hip) takes a product when the caller brought a workspace and a 256^2 kernel would
+// have run it (gemm_pk = 1, default): every "big" shape with K % 128 == 0 and K >= 1024.  Round 4 stopped at K >= 4096 (where the
+// 4-wave per-tile kernel ran); round 5 measured the K = 1536 Linears of the 1.3B model at M = 67 080 (profiles/r05/
+// gemm_yardstick_1p3b_gate.log): persistent 0.567 / 0.335 / 0.386 / 0.282 / 1.551 ms against 0.638 / 0.342 / 0.443 / 0.325 / 1.654 for the
+// 8-wave per-tile kernel (q|k, V^T, o + resid, cross q, ffn.0) -- at 24 K tiles per output tile the per-tile pipeline fill is
+// >= 8 % of a tile, which a continuous K-tile stream does not pay.  Shallower K (the VAE attention block's K = 384) stays where it
+// was: there the epilogue dominates and a second workgroup per CU hides it.
+// gemm_pk = 2: whenever its shape rules allow (K % 128 == 0, at least one 256^2 tile each way); 0: never.
 extern "C" int wan_gemm_ws_plan(int M, int N, int K) {
     const int pk = wan_tune(WAN_TUNE_GEMM_PK);
     const int base = wan_gemm_plan(M, N, K);
-    if (pk == 1 && base == WAN_GEMM_VARIANT_256_W4) return WAN_GEMM_VARIANT_256_PK;
+    if (pk == 1 && base != WAN_GEMM_VARIANT_128 && K % 128 == 0 && K >= 1024) return WAN_GEMM_VARIANT_256_PK;
     if (pk == 2 && K % 128 == 0 && M >= 256 && N >= 256) return WAN_GEMM_VARIANT_256_PK;
     return base;
 }

@@ -42,6 +42,7 @@ constexpr int kLdsBytes = 2 * kBufBytes;       // 128 KiB
 constexpr int kLdsFlag = kLdsBytes;            // three ints behind the ring: the arrival ticket and the tile tickets, broadcast to the workgroup
 constexpr int kCounterBytes = 4096;            // arrival counters (one int per stream-K tile) at the head of the workspace
 constexpr int64_t kSlotBytes = (int64_t)BM * BN * 4;
+constexpr int kMaxWorkers = 512;               // arrival counters [0, 512), ticket counters at 512 + 16 x: one 4 KiB header
 
 struct PkArgs {
     const bf16_t* A; int64_t lda;
@@ -54,7 +55,7 @@ struct PkArgs {
     int gm;               // M tiles per rasterisation group
     int nworkers;         // grid size (multiple of 8)
     int min_units;        // smallest stream-K range worth a worker (units of two K tiles)
-    int sched;            // main-loop schedule: 0 = one barrier per K tile (requests in two bursts), 1 = schedule D (see the kernel)
+    int form;             // 1 (product): epilogues on row-permuted operand tiles (see the kernel); 0: the round-4 epilogues (developer A/B)
     int exp;              // `make EXPERIMENTS=1` builds only (gemm_exp), TIMING ONLY: bit 5 = no epilogue at all, bit 6 = s_memtime stamps (where a workgroup's cycles go)
     int dynamic;          // whole tiles by ticket from the per-XCD counters (1) or in lockstep order (0: developer A/B)
     int* counters;        // workspace head: [0, nworkers) arrival counters of the split tiles, [512 + 16 x] the ticket counter of XCD x
@@ -165,15 +166,36 @@ __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast
 // 32x32x16 form of gemm_w4_kernel: on random operands, with every CU busy, the chip sustains 1.99-2.05 PFLOP/s of bare 16x16x32 MFMAs
 // against 1.59-1.78 of 32x32x16 (2.45 either way on zeros: tools/probe/mfma_power.hip, profiles/r04/mfma_power.log) -- twice the K depth
 // per accumulator update is half the accumulator traffic, and the power that saves comes back as clock.
-template <int EPI, int SCHED>
+// FORM 1 (round 5, the product form): every epilogue runs from the UNswapped product D = mfma(A fragment, W fragment) -- lane
+// (l15, kg) holds the output column of W-fragment row l15 and the output rows of A-fragment rows 4 kg .. 4 kg + 3 of every 16 x 16
+// tile -- and WHICH row of the operand panel sits in which LDS row is chosen so that a lane's accumulators are CONTIGUOUS in the
+// output: the LDS-DMA lands a panel row wherever its per-lane source offset says, so the permutation costs nothing (the fragment
+// reads, the swizzle and the MFMA sequence are untouched; only the eight scalar piece offsets of an operand change).
+//   * bf16 / GELU outputs (W rows permuted, kWPerm = 8): LDS row 16 j + l of a wave's 128-row W block holds panel row 8 l + j, so
+//     acc[i][0..7][r] of lane l15 are the 8 ADJACENT columns 8 l15 .. + 7 of output row 16 i + 4 kg + r: one 16-byte store per
+//     (i, r), 16 lanes = the wave's whole 256-byte row segment, four rows per instruction (32 stores per lane and tile).
+//     Round 4's form (swapped product: a lane = one row, lanes = consecutive ROWS) issued one 16-byte request per LANE -- the
+//     16 B per clock and CU that tools/probe/cu_store_rate.hip measures for that pattern against 34 for the row-group forms.
+//   * fp32 outputs, plain and read-modify-write (kWPerm = 4): LDS row 16 j + l holds panel row 64 (j >> 2) + 4 l + (j & 3), so
+//     acc[i][4 h .. 4 h + 3][r] are the 4 adjacent columns 64 h + 4 l15 .. + 3: two float4 accesses per (i, r), each 16 lanes x 16 B =
+//     256 contiguous bytes of a row (round 4: eight dword accesses of 64 contiguous bytes -- a quarter of the instructions, the
+//     form the quad-transpose experiment of round 4 paid 3 072 DPP moves for).
+//   * transposed (V^T) output (A rows permuted): LDS row 16 i + a of a wave's 128-row A block holds panel row
+//     32 (i >> 1) + 8 (a >> 2) + 4 (i & 1) + (a & 3), so (acc[2 t][j][0..3], acc[2 t + 1][j][0..3]) are 8 consecutive tokens of one
+//     channel: one 16-byte store, the four kg lanes of a column = 64 contiguous bytes (round 4: 8-byte stores, 32 contiguous bytes).
+// Every output element is the same MFMA chain as before (same k order), so results do not change.
+template <int EPI, int FORM>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(PkArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // D = mfma(A fragment, W fragment): lane (l15, kg) holds output COLUMN .. + l15 and the four consecutive ROWS .. + 4 kg .. + 3 of a
     // tile -- the form of the transposed store, and (round 4) of the fp32 epilogues: there a register of the tile is 4 rows x 16
     // CONSECUTIVE columns across the 16 lanes of a row group, i.e. 64 contiguous bytes per row group and dword access, where the
     // swapped product puts consecutive ROWS on consecutive lanes and every lane's 16 bytes become a request of their own.
-    constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T || EPI == WAN_EPI_F32 || EPI == WAN_EPI_RESID_F32);
+    constexpr bool kOutF32 = (EPI == WAN_EPI_F32 || EPI == WAN_EPI_RESID_F32);
+    constexpr bool kTransposed = FORM == 1 || EPI == WAN_EPI_BF16_T || kOutF32;
     constexpr bool kRowMajorOut = (EPI != WAN_EPI_BF16_T);
+    constexpr int kWPerm = FORM != 1 ? 0 : (EPI == WAN_EPI_BF16_T ? 0 : (kOutF32 ? 4 : 8));
+    constexpr bool kAPerm = FORM == 1 && EPI == WAN_EPI_BF16_T;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
@@ -181,14 +203,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const Slab slab = make_slab(g, (int)blockIdx.x);
 
     // ---- LDS-DMA lane offsets (see gemm_w4_kernel): piece j of wave w covers rows 64 w + 8 j + lane / 8 of an operand tile
+    // (LDS row of a piece = wid * 64 + 8 j + lane / 8; its swizzle depends on j & 1 only.  Unpermuted, the panel row is the LDS row:
+    // the lane part carries 8 (j & 1), the scalar part 16 (j >> 1).  Permuted, the lane part is the same for both parities and the
+    // scalar part carries everything that depends on j: a_srow / w_srow below.)
     int a_voff[2], w_voff[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int row = wid * 64 + p * 8 + (lane >> 3);
+        const int row = wid * 64 + p * 8 + (lane >> 3);           // LDS row
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        a_voff[p] = (int)(((int64_t)row * g.lda + c * 8) * 2);
-        w_voff[p] = (int)(((int64_t)row * g.ldw + c * 8) * 2);
+        const int arow = kAPerm ? 128 * (wid >> 1) + 64 * (wid & 1) + 8 * (lane >> 5) + ((lane >> 3) & 3) : row;
+        const int wrow = kWPerm == 8 ? 128 * (wid >> 1) + 4 * (wid & 1) + 8 * (lane >> 3)
+                       : kWPerm == 4 ? 128 * (wid >> 1) + 64 * (wid & 1) + 4 * (lane >> 3) : row;
+        a_voff[p] = (int)(((int64_t)arow * g.lda + c * 8) * 2);
+        w_voff[p] = (int)(((int64_t)wrow * g.ldw + c * 8) * 2);
     }
+    // panel rows piece j adds to the lane part (compile-time per piece)
+    auto a_srow = [](int j) { return kAPerm ? 32 * (j >> 2) + 16 * (j & 1) + 4 * ((j >> 1) & 1) : 16 * (j >> 1); };
+    auto w_srow = [](int j) { return kWPerm == 8 ? 64 * (j & 1) + (j >> 1) : kWPerm == 4 ? 32 * (j & 1) + (j >> 1) : 16 * (j >> 1); };
     // ---- fragment reads: 16 rows x 32 k per fragment; lane = (row l15, k group kg); logical chunk 4 h + kg of a 128-B row (h = k half)
     const int swz = (lane >> 1) & 7;
     int koff[2][2];                          // [LDS buffer][k half]
@@ -264,7 +295,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         const char* nb = (op ? pn.w : pn.a) + (int64_t)nxt.kb * (BK * 2);
         const int nl = nxt.valid ? (op ? pn.wb : pn.ab) - nxt.kb * (BK * 2) : 0;
         st.base = jump ? nb : st.base + BK * 2;
-        st.left = jump ? nl : st.left - BK * 2;
+        st.left = jump ? nl : max(st.left - BK * 2, 0);       // past the end of the last segment: really zero-length requests
     };
     auto rsrc_of = [&](const Stream& st) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)st.base, 0, st.left, 0x00020000);
@@ -272,7 +303,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
-            operand ? w_voff[j & 1] : a_voff[j & 1], (int)((j >> 1) * 16 * ld * 2), 0, 0);
+            operand ? w_voff[j & 1] : a_voff[j & 1], (int)((operand ? w_srow(j) : a_srow(j)) * ld * 2), 0, 0);
     };
 
     f32x4 acc[8][8];                         // [m tile][n tile]
@@ -291,51 +322,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         else if (f <= 8) wf[h][f - 1] = lds16(smem + w_base + (f - 1) * 16 * 128 + koff[buf][h]);
         else af[h][f - 8] = lds16(smem + a_base + (f - 8) * 16 * 128 + koff[buf][h]);
     };
-    // One k half H (32 of the K tile's 64) of the K tile in LDS buffer b = 64 MFMAs.  FETCH_ selects what the gaps carry:
-    //   0: k half 0 -- the 16 fragments of k half 1 (buffer b), one per 4 MFMAs, and the 8 W pieces of stream position kt + 1 -> buffer 1 - b
-    //   1: k half 1 -- slots 0..31 move the request streams on; `mid` (the tile's barrier) runs before slot 32; slots 32..63 carry the
-    //      16 fragments of k half 0 of the NEXT position (buffer 1 - b) and the 8 A pieces of position kt + 2 -> buffer b
-    auto khalf = [&](auto H_, int b, bool jump, auto&& mid) __attribute__((always_inline)) {
-        constexpr int H = decltype(H_)::value;
-        __amdgpu_buffer_rsrc_t r;
-        if constexpr (H == 0) r = rsrc_of(sq);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int slot = i * 8 + j;
-                if constexpr (H == 1) {
-                    if (slot == 32) { mid(); r = rsrc_of(sa); }
-                }
-                if constexpr (kTransposed) GP_MFMA(acc[i][j], af[H][i], wf[H][j]);
-                else GP_MFMA(acc[i][j], wf[H][j], af[H][i]);
-                GP_SB();
-                if constexpr (H == 0) {
-                    if (slot % 4 == 0) fetch(1, slot / 4, b);
-                    else if (slot % 8 == 2) stage_piece(r, 1 - b, 1, slot / 8, g.ldw);
-                } else {
-                    if (slot == 1) advance(sa, 0, jump);         // -> position kt + 2: requested in the second half of this k half
-                    else if (slot == 3) advance(sq, 1, jump);    // -> position kt + 2: requested in k half 0 of the next K tile
-                    else if (slot >= 32 && slot % 2 == 0) fetch(0, (slot - 32) / 2, 1 - b);
-                    else if (slot >= 32 && slot % 4 == 1) stage_piece(r, b, 0, (slot - 32) / 4, g.lda);
-                }
-                GP_SB();
-            }
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    // K tile kt (stream position) in buffer b: W of position kt+1 -> buffer 1-b during k half 0, A of position kt+2 -> buffer b in the
-    // last quarter (right behind the barrier that frees it); both are waited for at the barrier of position kt+1.
-    auto ktile = [&](int kt, int b) __attribute__((always_inline)) {
-        const bool jump = kt + 2 == cur.ke;      // position kt + 2 is the first K tile of the next segment
-        khalf(I0{}, b, jump, [] {});
-        khalf(I1{}, b, jump, [&] {
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my pieces of position kt+1 have landed ...
-            __builtin_amdgcn_s_barrier();            // ... everybody's have, and every wave has read the last fragment of position kt
-            GP_SB();
-        });
-    };
-
-    // Schedule D (g.sched == 1): shrink the LDS residency of a K tile so that its buffer can take requests for most of the time.
+    // The main-loop schedule ("schedule D" of round 4; the one-barrier-per-K-tile schedule it replaced is gone): shrink the LDS residency of a K tile so that its buffer can take requests for most of the time.
     //   slots   0..31   the 16 fragments of k half 1 (one per 2 MFMAs): by slot 32 every fragment of position kt is in registers
     //   slot   32       barrier B1: buffer b is free
     //   slots  33..123  the 16 pieces (A 0..7, W 0..7) of position kt + 2 -> buffer b, one per 6 MFMAs (96 cycles: 43 B/clk per CU,
@@ -382,10 +369,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         const __amdgpu_buffer_rsrc_t ra1 = rsrc_of(sa), rw1 = rsrc_of(sq);
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage_piece(ra1, 1, 0, j, g.lda);
-        if constexpr (SCHED == 1) {            // schedule D keeps a whole K tile in flight
 #pragma unroll
-            for (int j = 0; j < 8; ++j) stage_piece(rw1, 1, 1, j, g.ldw);
-        }
+        for (int j = 0; j < 8; ++j) stage_piece(rw1, 1, 1, j, g.ldw);            // the schedule keeps a whole K tile in flight
     }
 
 #if WAN_DEV_EXPERIMENTS
@@ -403,16 +388,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int f = 0; f < 16; ++f) fetch(0, f, 0);
         GP_STAMP(t_start);
-        if constexpr (SCHED == 1) {
-            for (int kt = cur.kb; kt < cur.ke; kt += 2) {
-                ktile_d(kt, 0);
-                ktile_d(kt + 1, 1);
-            }
-        } else {
-            for (int kt = cur.kb; kt < cur.ke; kt += 2) {
-                ktile(kt, 0);
-                ktile(kt + 1, 1);
-            }
+        for (int kt = cur.kb; kt < cur.ke; kt += 2) {
+            ktile_d(kt, 0);
+            ktile_d(kt + 1, 1);
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads below
         GP_STAMP(t_loop);
@@ -485,7 +463,148 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
             const int l4 = kg * 4;
             int seam_b_lo = 0, seam_next = 0x7fffffff;
-            if constexpr (!kTransposed) {
+            if constexpr (FORM == 1 && (EPI == WAN_EPI_BF16 || EPI == WAN_EPI_GELU_BF16)) {
+                // bf16 outputs from the W-row-permuted tile (kWPerm = 8): acc[i][j][r] of lane (l15, kg) is output row mw + 16 i + r,
+                // column nb + j -- 8 adjacent columns per (i, r): one 16-byte store, a wave instruction = 4 rows x 256 contiguous bytes
+                const int mw = m0 + wr * 128 + l4, nb = n0 + wc * 128 + 8 * l15;
+                const bool c0 = nb < g.N, c1 = nb + 4 < g.N;             // N % 4 == 0: a 4-column group is wholly in or out
+                const bool aligned = (g.ldo & 7) == 0 && (((uintptr_t)g.out) & 15) == 0;       // wave-uniform
+                float bq[8];
+                {
+                    const float4 b0 = (g.bias && c0) ? *reinterpret_cast<const float4*>(g.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 b1 = (g.bias && c1) ? *reinterpret_cast<const float4*>(g.bias + nb + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            v[j] = acc[i][j][r] + bq[j];
+                            if constexpr (EPI == WAN_EPI_GELU_BF16) v[j] = gelu_tanh_f32(v[j]);
+                        }
+                        const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        const int m = mw + 16 * i + r;
+                        if (m >= g.M) continue;
+                        bf16_t* op = (bf16_t*)g.out + (int64_t)m * g.ldo + nb;
+                        if (aligned && c1) {
+                            *reinterpret_cast<u32x4*>(op) = o;
+                        } else {
+                            if (c0) *reinterpret_cast<u32x2*>(op) = u32x2{o[0], o[1]};
+                            if (c1) *reinterpret_cast<u32x2*>(op + 4) = u32x2{o[2], o[3]};
+                        }
+                    }
+            } else if constexpr (FORM == 1 && kOutF32) {
+                // fp32 outputs (plain and read-modify-write) from the W-row-permuted tile (kWPerm = 4): acc[i][4 h + q][r] of lane
+                // (l15, kg) is output row mw + 16 i + r, column nb + 64 h + q -- two float4 accesses per (i, r), each 256 contiguous
+                // bytes of a row across the 16 lanes of a row group.  A batch = one m tile (8 float4 per lane); the residual rows of
+                // batch i + 1 are requested before batch i is combined and stored.  bias / gate: two float4 each per lane and tile.
+                auto epilogue_f32 = [&](auto has_bias, auto has_gate, auto seam) {
+                    constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_GATE = decltype(has_gate)::value, SEAM = decltype(seam)::value;
+                    constexpr bool RESID = EPI == WAN_EPI_RESID_F32;
+                    const int mw = m0 + wr * 128 + l4, nb = n0 + wc * 128 + 4 * l15;
+                    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bool nok[2]; int nn[2]; float4 bq[2], gq[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        nok[h] = nb + 64 * h < g.N;
+                        nn[h] = nok[h] ? nb + 64 * h : 0;                // clamped: a valid address, not stored
+                        bq[h] = HAS_BIAS ? *reinterpret_cast<const float4*>(g.bias + nn[h]) : zero;
+                        gq[h] = (HAS_GATE && !SEAM) ? *reinterpret_cast<const float4*>(g.gate + (int64_t)seam_b_lo * g.N + nn[h]) : one;
+                    }
+                    struct Rows { float4 x[4][2]; };
+                    auto row_of = [&](int i, int r) { return min(mw + i * 16 + r, g.M - 1); };
+                    auto load_rows = [&](int i, Rows& R) {
+                        if constexpr (RESID) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float* xp = (const float*)g.out + (int64_t)row_of(i, r) * g.ldo;
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) R.x[r][h] = *reinterpret_cast<const float4*>(xp + nn[h]);
+                            }
+                        }
+                    };
+                    auto store_rows = [&](int i, const Rows& R) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mw + i * 16 + r;
+                            if (m >= g.M) continue;
+                            float* op = (float*)g.out + (int64_t)m * g.ldo;
+                            const float* gp = SEAM ? g.gate + (int64_t)(seam_b_lo + (m >= seam_next ? 1 : 0)) * g.N : nullptr;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                if (!nok[h]) continue;
+                                float4 v = make_float4(acc[i][4 * h][r] + bq[h].x, acc[i][4 * h + 1][r] + bq[h].y,
+                                                       acc[i][4 * h + 2][r] + bq[h].z, acc[i][4 * h + 3][r] + bq[h].w);
+                                if constexpr (RESID) {
+                                    const float4 gv = SEAM ? *reinterpret_cast<const float4*>(gp + nn[h]) : gq[h];
+                                    const float4 x = R.x[r][h];
+                                    v = make_float4(x.x + v.x * gv.x, x.y + v.y * gv.y, x.z + v.z * gv.z, x.w + v.w * gv.w);
+                                }
+                                *reinterpret_cast<float4*>(op + nn[h]) = v;
+                            }
+                        }
+                    };
+                    Rows R[2];
+                    load_rows(0, R[0]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (i + 1 < 8) load_rows(i + 1, R[(i + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_rows(i, R[i & 1]);
+                    }
+                };
+                using T = std::true_type; using F = std::false_type;
+                if constexpr (EPI == WAN_EPI_RESID_F32) {
+                    if (g.gate) {
+                        // (as in the round-4 form below: one scalar division per wave and tile; at most one sample seam inside a wave's
+                        // 128 rows, and the wave that holds it runs the SEAM copy, which fetches the gate per row)
+                        seam_b_lo = __builtin_amdgcn_readfirstlane(min(m0 + wr * 128, g.M - 1) / (int)g.rows_per_batch);
+                        seam_next = (seam_b_lo + 1) * (int)g.rows_per_batch;
+                        const bool one_sample = min(m0 + wr * 128 + 127, g.M - 1) < seam_next;       // wave-uniform
+                        if (one_sample) { if (g.bias) epilogue_f32(T{}, T{}, F{}); else epilogue_f32(F{}, T{}, F{}); }
+                        else { if (g.bias) epilogue_f32(T{}, T{}, T{}); else epilogue_f32(F{}, T{}, T{}); }
+                    } else {
+                        if (g.bias) epilogue_f32(T{}, F{}, F{}); else epilogue_f32(F{}, F{}, F{});
+                    }
+                } else {
+                    if (g.bias) epilogue_f32(T{}, F{}, F{}); else epilogue_f32(F{}, F{}, F{});
+                }
+            } else if constexpr (FORM == 1) {
+                // transposed (V^T) store from the A-row-permuted tile: (acc[2 t][j][0..3], acc[2 t + 1][j][0..3]) of lane (l15, kg) are
+                // the 8 consecutive tokens mt .. mt + 7 (mt = m0 + wr * 128 + 32 t + 8 kg) of channel n = .. + 16 j + l15: one 16-byte
+                // store; the four kg lanes of a channel cover 64 contiguous bytes
+                const bool aligned = (g.ldo & 7) == 0 && (((uintptr_t)g.out) & 15) == 0;       // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + wc * 128 + j * 16 + l15;
+                    const bool nok = n < g.N;
+                    const float bv = (g.bias && nok) ? g.bias[n] : 0.f;
+                    if (!nok) continue;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = m0 + wr * 128 + 32 * t + 8 * kg;
+                        if (m >= g.M) continue;
+                        const f32x4 a0 = acc[2 * t][j], a1 = acc[2 * t + 1][j];
+                        const float vv[8] = {a0[0] + bv, a0[1] + bv, a0[2] + bv, a0[3] + bv, a1[0] + bv, a1[1] + bv, a1[2] + bv, a1[3] + bv};
+                        bf16_t* p = (bf16_t*)g.out + (int64_t)n * g.ldo + m;
+                        if (m + 7 < g.M && aligned) {
+                            *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]), pack_bf16x2(vv[4], vv[5]), pack_bf16x2(vv[6], vv[7])};
+                        } else {
+#pragma unroll
+                            for (int hf = 0; hf < 2; ++hf) {
+                                if (m + 4 * hf + 3 < g.M) {
+                                    *reinterpret_cast<u32x2*>(p + 4 * hf) = u32x2{pack_bf16x2(vv[4 * hf], vv[4 * hf + 1]), pack_bf16x2(vv[4 * hf + 2], vv[4 * hf + 3])};
+                                } else {
+                                    for (int r = 0; r < 4 && m + 4 * hf + r < g.M; ++r) p[4 * hf + r] = (bf16_t)vv[4 * hf + r];
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (!kTransposed) {
                 // bf16 outputs.  Swapped product (W fragment as A operand): lane (l15, kg) holds output row m = .. + l15 and, per tile, the 4
                 // consecutive columns n = .. + 4 kg .. + 3 (two bf16 pairs).  A batch = one m tile x four n tiles; the bias of a batch is
                 // loaded one batch ahead of its use.  Out-of-range rows / columns read a clamped address and are not stored.
@@ -700,11 +819,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef GP_SB
 }
 
-template <int EPI, int SCHED>
+template <int EPI, int FORM>
 wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI, SCHED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI, FORM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 64);
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16_ws: cannot reserve %d B of LDS: %s", kLdsBytes + 64, hipGetErrorString(e));
@@ -717,7 +836,7 @@ wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
         wan_set_error("wan_gemm_bf16_ws: cannot clear the arrival counters: %s", hipGetErrorString(hipGetLastError()));
         return WAN_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemm_pk_kernel<EPI, SCHED>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
+    hipLaunchKernelGGL((gemm_pk_kernel<EPI, FORM>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16_ws");
     return WAN_OK;
 }
@@ -730,7 +849,8 @@ int wan_gemm_pk_workers(int M, int N) {
     int w = wan_cu_count() & ~7;
     if (const int t = wan_tune(WAN_TUNE_GEMM_PK_WORKERS); t > 0) w = t & ~7;
     (void)tiles;
-    return w < 8 ? 8 : w;
+    // the 4 KiB counter header holds the arrival counters in words [0, workers) and the per-XCD ticket counters from word 512 on
+    return w < 8 ? 8 : (w > kMaxWorkers ? kMaxWorkers : w);
 }
 
 int64_t wan_gemm_pk_workspace_bytes(int M, int N) {
@@ -747,7 +867,7 @@ static void pk_plan_args(PkArgs& g, int M, int N, int K) {
     g.min_units = (K / BK / 2 + 3) / 4;
     if (const int mu = wan_tune(WAN_TUNE_GEMM_PK_MIN_UNITS); mu > 0) g.min_units = mu;
     g.dynamic = wan_tune(WAN_TUNE_GEMM_PK_ORDER) != 1;
-    g.sched = wan_tune(WAN_TUNE_GEMM_PK_SCHED);
+    g.form = wan_tune(WAN_TUNE_GEMM_PK_FORM);      // bit e: epilogue e (WAN_EPI_*) runs from the row-permuted tile
     g.exp = wan_tune(WAN_TUNE_GEMM_EXP);
 }
 
@@ -776,9 +896,10 @@ wan_status_t wan_gemm_bf16_pk(const void* A, int64_t lda, const void* W, int64_t
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     pk_plan_args(g, M, N, K);
+    WAN_REQUIRE(g.nworkers <= kMaxWorkers && g.nworkers % 8 == 0, WAN_ERR_INVALID, "wan_gemm_bf16_ws: %d workers (at most %d, a multiple of 8)", g.nworkers, kMaxWorkers);
     g.counters = (int*)workspace;
     g.slots = (char*)workspace + kCounterBytes;
-#define WAN_PK(E) (g.sched == 1 ? launch_pk<E, 1>(g, s) : launch_pk<E, 0>(g, s))
+#define WAN_PK(E) (((g.form >> (E)) & 1) ? launch_pk<E, 1>(g, s) : launch_pk<E, 0>(g, s))
     switch (epilogue) {
         case WAN_EPI_BF16: return WAN_PK(WAN_EPI_BF16);
         case WAN_EPI_GELU_BF16: return WAN_PK(WAN_EPI_GELU_BF16);

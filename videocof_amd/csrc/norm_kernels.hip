@@ -649,7 +649,9 @@ __global__ __launch_bounds__(256) void col_mean_finish_kernel(const float* __res
     mean[(int64_t)b * dim + c] = s * inv_rows;
 }
 
-// one workgroup per row; q8 = e4m3(q * q_scale), k8 = e4m3((k - mean[b]) * k_scale); dense [rows][dim] byte outputs
+// one workgroup per row; q8 = e4m3(q * q_scale), k8 = e4m3((k - mean[b]) * k_scale); dense [rows][dim] byte outputs.
+// Either operand may be absent (q == nullptr or k == nullptr, workgroup-uniform): the Ulysses head-group pipeline quantises k once
+// when it has arrived and every q group when ITS exchange completes.
 __global__ __launch_bounds__(kThreads) void qk_quantize_fp8_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld,
                                                                    int dim, int64_t rows_per_batch, const float* __restrict__ mean,
                                                                    float q_scale, float k_scale, unsigned char* __restrict__ q8,
@@ -657,22 +659,29 @@ __global__ __launch_bounds__(kThreads) void qk_quantize_fp8_kernel(const bf16_t*
     const int64_t row = blockIdx.x;
     const float* mu = mean ? mean + (row / rows_per_batch) * dim : nullptr;
     for (int c = threadIdx.x * 8; c < dim; c += kThreads * 8) {
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + row * ld + c), kv = *reinterpret_cast<const u32x4*>(k + row * ld + c);
-        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (mu) {
-            const float4 m0 = *reinterpret_cast<const float4*>(mu + c), m1 = *reinterpret_cast<const float4*>(mu + c + 4);
-            m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
-        }
-        float qf[8], kf[8];
+        if (q != nullptr) {
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(q + row * ld + c);
+            float qf[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qf[2 * j] = bf16lo_to_f32(qv[j]) * q_scale; qf[2 * j + 1] = bf16hi_to_f32(qv[j]) * q_scale;
-            kf[2 * j] = (bf16lo_to_f32(kv[j]) - m[2 * j]) * k_scale; kf[2 * j + 1] = (bf16hi_to_f32(kv[j]) - m[2 * j + 1]) * k_scale;
+            for (int j = 0; j < 4; ++j) { qf[2 * j] = bf16lo_to_f32(qv[j]) * q_scale; qf[2 * j + 1] = bf16hi_to_f32(qv[j]) * q_scale; }
+            const u32x2 qo = {pack_fp8x4(qf[0], qf[1], qf[2], qf[3]), pack_fp8x4(qf[4], qf[5], qf[6], qf[7])};
+            *reinterpret_cast<u32x2*>(q8 + row * (int64_t)dim + c) = qo;
         }
-        const u32x2 qo = {pack_fp8x4(qf[0], qf[1], qf[2], qf[3]), pack_fp8x4(qf[4], qf[5], qf[6], qf[7])};
-        const u32x2 ko = {pack_fp8x4(kf[0], kf[1], kf[2], kf[3]), pack_fp8x4(kf[4], kf[5], kf[6], kf[7])};
-        *reinterpret_cast<u32x2*>(q8 + row * (int64_t)dim + c) = qo;
-        *reinterpret_cast<u32x2*>(k8 + row * (int64_t)dim + c) = ko;
+        if (k != nullptr) {
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(k + row * ld + c);
+            float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (mu) {
+                const float4 m0 = *reinterpret_cast<const float4*>(mu + c), m1 = *reinterpret_cast<const float4*>(mu + c + 4);
+                m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+            }
+            float kf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = (bf16lo_to_f32(kv[j]) - m[2 * j]) * k_scale; kf[2 * j + 1] = (bf16hi_to_f32(kv[j]) - m[2 * j + 1]) * k_scale;
+            }
+            const u32x2 ko = {pack_fp8x4(kf[0], kf[1], kf[2], kf[3]), pack_fp8x4(kf[4], kf[5], kf[6], kf[7])};
+            *reinterpret_cast<u32x2*>(k8 + row * (int64_t)dim + c) = ko;
+        }
     }
 }
 }  // namespace
@@ -699,7 +708,9 @@ extern "C" wan_status_t wan_col_mean_bf16(const void* x_bf16, int64_t ld, int64_
 extern "C" wan_status_t wan_qk_quantize_fp8(const void* q_bf16, const void* k_bf16, int64_t ld, int64_t rows, int dim,
                                             int64_t rows_per_batch, const float* k_mean, float q_scale, float k_scale,
                                             void* q8, void* k8, void* stream) {
-    WAN_REQUIRE(q_bf16 && k_bf16 && q8 && k8, WAN_ERR_INVALID, "wan_qk_quantize_fp8: null tensor");
+    WAN_REQUIRE((q_bf16 != nullptr) == (q8 != nullptr) && (k_bf16 != nullptr) == (k8 != nullptr) && (q_bf16 || k_bf16), WAN_ERR_INVALID,
+                "wan_qk_quantize_fp8: each operand comes with its output (q and q8, k and k8), and at least one of the two is given");
+    WAN_REQUIRE(k_bf16 != nullptr || k_mean == nullptr, WAN_ERR_INVALID, "wan_qk_quantize_fp8: k_mean without k");
     WAN_REQUIRE(dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= dim && rows >= 0 && rows_per_batch > 0, WAN_ERR_INVALID,
                 "wan_qk_quantize_fp8: dim=%d ld=%lld rows=%lld rows_per_batch=%lld", dim, (long long)ld, (long long)rows, (long long)rows_per_batch);
     WAN_REQUIRE(q_scale == q_scale && k_scale == k_scale && q_scale != 0.f && k_scale != 0.f, WAN_ERR_INVALID, "wan_qk_quantize_fp8: scales must be non-zero numbers");

@@ -39,6 +39,10 @@ _SP: Optional["SequenceParallelGroup"] = None
 
 
 class SequenceParallelGroup:
+    """The Ulysses group on a torch.distributed process group.  NOTE on ``all_gather_tokens`` (both transports): the result is a
+    view of a PERSISTENT per-shape buffer owned by the group -- the next call with the same shape overwrites it.  Consume (or
+    clone) it before gathering again; the model's forward copies it out through the unpatchify kernel."""
+
     def __init__(self, group=None):
         self.group = group
         self.rank = dist.get_rank(group)
@@ -69,6 +73,17 @@ class SequenceParallelGroup:
         if not async_op:
             return None
         return (lambda: work.wait()) if work is not None else (lambda: None)
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        """Element-wise maximum of a small fp32 tensor over the group, in place (what the ranks agree their fp8 attention
+        exponents on: once per layer, on the first forward after ``enable_fp8_linear``)."""
+        if self._host_staged and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
 
     # torch statements of the wire layouts (CPU tests and documentation; the GPU path uses wan_sp_* / wan_rmsnorm_rope_sp)
     def pack_heads_ref(self, x: torch.Tensor) -> torch.Tensor:
@@ -231,6 +246,14 @@ class LibraryComm:
             return wait
         wait()
         return None
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        """Element-wise maximum over the ranks, in place: the library communicator has no reduction of its own, so the ranks'
+        vectors are gathered (wan_sp_all_gather) and reduced locally -- a handful of floats, once per layer and model load."""
+        if self.world_size > 1:
+            flat = t.contiguous().view(1, 1, -1)
+            t.copy_(self.all_gather_tokens(flat).view(self.world_size, -1).amax(dim=0).view(t.shape))
+        return t
 
     def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
         P = self.world_size

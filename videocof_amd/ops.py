@@ -264,21 +264,28 @@ _GEMM_WS = {}
 
 
 def gemm_workspace(dev: torch.device, M: int, N: int, K: int) -> Optional[torch.Tensor]:
-    """The caller-owned workspace of ``wan_gemm_bf16_ws`` (the persistent stream-K GEMM's partial tiles and arrival
-    counters): ONE buffer per device, grown to the largest request and then kept for the life of the process, so that its
-    address is stable under hipGraph capture.  The package issues all its GEMMs of a device on one stream (the Ulysses side
-    stream carries collectives only); a host that runs GEMMs of one device on several streams CONCURRENTLY must give each
-    stream its own workspace through the C entry point.  None when the shape does not use a workspace
+    """The caller-owned workspace of ``wan_gemm_bf16_ws`` (the persistent stream-K GEMM's partial tiles, arrival and
+    ticket counters): ONE buffer per (device, STREAM), grown to the largest request and then kept for the life of the
+    process.  The kernel keeps its counters and split-tile partial sums in it, so two launches that share a workspace must
+    be stream-ordered: keyed by the current stream, GEMMs issued on different streams of one device (two pipelines, a
+    caller's side stream) can never meet in one buffer.  Launches recorded under stream capture share one per-device
+    "capture" workspace (the capturing stream is a pool stream that differs from capture to capture; a graph bakes the
+    address in and the entry stays alive with this table); like the model's activation buffers it is owned by the graphs
+    of that device, whose replays must not overlap each other.  The buffer is NOT cleared here -- the launch clears the
+    4 KiB of counters it uses with a memset node of its own.  None when the shape does not use a workspace
     (``wan_gemm_workspace_bytes`` == 0)."""
     need = int(_lib.load().wan_gemm_workspace_bytes(M, N, K))
     if need <= 0:
         return None
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (index, "capture" if capturing else int(torch.cuda.current_stream(index).cuda_stream))
     ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the GEMM workspace would have to be (re)allocated during graph capture; run the shape eagerly once first")
-        ws = torch.zeros(need, device=dev, dtype=torch.uint8)
+        if ws is not None and capturing:
+            # growing it would free memory an already captured graph of this device still writes to
+            raise RuntimeError("the GEMM workspace of captured graphs would have to grow during a capture; capture the largest shape first")
+        ws = torch.empty(need, device=torch.device("cuda", index), dtype=torch.uint8)
         _GEMM_WS[key] = ws
     return ws
 
@@ -574,16 +581,25 @@ def col_mean(x: torch.Tensor, rows_per_batch: int, valid_rows: int, batch: int, 
 
 
 @_on_tensor_device
-def qk_quantize_fp8(q: torch.Tensor, k: torch.Tensor, rows_per_batch: int, k_mean: Optional[torch.Tensor], q_scale: float,
-                    k_scale: float, q8: torch.Tensor, k8: torch.Tensor) -> None:
-    """q8 = e4m3(q * q_scale), k8 = e4m3((k - k_mean[sample]) * k_scale) from two bf16 [rows, dim] views sharing a row stride
-    (``k_mean`` fp32 [batch, dim] or None); dense ``FP8`` [rows, dim] outputs."""
-    _need(q, torch.bfloat16, "qk_quantize_fp8.q")
-    _need(k, torch.bfloat16, "qk_quantize_fp8.k")
-    if q.shape != k.shape or q.stride(0) != k.stride(0):
-        raise ValueError("qk_quantize_fp8: q and k must share shape and row stride")
-    rows, dim = q.shape
+def qk_quantize_fp8(q: Optional[torch.Tensor], k: Optional[torch.Tensor], rows_per_batch: int, k_mean: Optional[torch.Tensor],
+                    q_scale: float, k_scale: float, q8: Optional[torch.Tensor], k8: Optional[torch.Tensor]) -> None:
+    """q8 = e4m3(q * q_scale), k8 = e4m3((k - k_mean[sample]) * k_scale) from bf16 [rows, dim] views (when both are given they
+    share shape and row stride; ``k_mean`` fp32 [batch, dim] or None); dense ``FP8`` [rows, dim] outputs.  Either operand may be
+    None together with its output (the Ulysses head-group pipeline quantises k once and every q group on arrival)."""
+    if (q is None) != (q8 is None) or (k is None) != (k8 is None) or (q is None and k is None):
+        raise ValueError("qk_quantize_fp8: q comes with q8, k with k8, and at least one pair is needed")
+    if k is None and k_mean is not None:
+        raise ValueError("qk_quantize_fp8: k_mean without k")
+    ref = q if q is not None else k
+    for nm, t in (("q", q), ("k", k)):
+        if t is not None:
+            _need(t, torch.bfloat16, "qk_quantize_fp8." + nm)
+            if t.dim() != 2 or t.shape != ref.shape or t.stride(0) != ref.stride(0):
+                raise ValueError("qk_quantize_fp8: q and k must be 2-D and share shape and row stride")
+    rows, dim = ref.shape
     for nm, t in (("q8", q8), ("k8", k8)):
+        if t is None:
+            continue
         _need(t, FP8, "qk_quantize_fp8." + nm)
         if not t.is_contiguous() or t.numel() < rows * dim:
             raise ValueError(f"qk_quantize_fp8.{nm} must be contiguous with >= rows * dim bytes")
@@ -592,7 +608,7 @@ def qk_quantize_fp8(q: torch.Tensor, k: torch.Tensor, rows_per_batch: int, k_mea
         if not k_mean.is_contiguous() or k_mean.shape[-1] != dim:
             raise ValueError("qk_quantize_fp8.k_mean must be contiguous [batch, dim]")
     lib = _lib.load()
-    _lib.check(lib.wan_qk_quantize_fp8(_p(q), _p(k), q.stride(0), rows, dim, int(rows_per_batch), _p(k_mean), float(q_scale),
+    _lib.check(lib.wan_qk_quantize_fp8(_p(q), _p(k), ref.stride(0), rows, dim, int(rows_per_batch), _p(k_mean), float(q_scale),
                                        float(k_scale), _p(q8), _p(k8), _stream()), "wan_qk_quantize_fp8")
 
 

@@ -500,7 +500,12 @@ class WanTransformer3DModel(nn.Module):
         P.V product as well -- V^T is re-quantised per layer into MX e4m3 blocks of 32 keys (``wan_vt_quantize_mx``, 0.23 ms), P inside
         the kernel; SageAttention-2's operating point (``wan_attention_fwd_f8``, include/wan_hip.h a9'').  Under Ulysses sequence
         parallelism the projections run in e4m3 as well (q, k and V^T are projected from the same e4m3 token rows, their weight copies
-        split by output rows); the wires stay bf16 and the two attention options run on each rank's arrived operands, batch 1 only.
+        split by output rows); the wires stay bf16 and the two attention options run on each rank's arrived operands -- CFG batches
+        and head-group pipelining as in the bf16 path (k is quantised once when it has arrived, every q group when its own exchange
+        completes).  The e4m3 exponents of "attn" are CALIBRATED per layer on the first forward after this call
+        (``fp8_attn_calibrate``: the largest |q| and |k - mean| of that layer's operands, one bit of head-room); under sequence
+        parallelism every rank measures its own heads and the ranks agree through one all-reduce(max) per layer (once), so a
+        sharded model uses the exponents a single device would have measured.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
         layers = tuple(layers)
@@ -859,7 +864,7 @@ class WanTransformer3DModel(nn.Module):
             # pipeline is between the exchanges and the attention launches, not inside the projection: with groups g0 | g1 the
             # exposed transfers per layer are q(g0) and o(g1), ONE exchange's worth instead of two.
             Hl = H // P
-            h0 = Hl // 2 if (self.sp_head_groups >= 2 and Hl >= 2 and not a8_sp) else 0
+            h0 = Hl // 2 if (self.sp_head_groups >= 2 and Hl >= 2) else 0
             split, n0 = h0 * self.d, Lt * B * h0 * self.d        # group 0: channels [0, split) of every slab, n0 elements of wire
             ops.rmsnorm_rope_sp(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, bufs.qw_s, None, P, B,
                                 x0_scale=self._qs, split=split)
@@ -872,49 +877,72 @@ class WanTransformer3DModel(nn.Module):
             wait_k()
             wait_v()
             ops.sp_unpack_vt(bufs.vw_r, bufs.vt_full, P, Ll)
-            wait_q()
-            self._comm_done(cev)
-            as_bld = lambda w: w.view(Lt, B, Cl).permute(1, 0, 2)          # [B, P*Ll, Cl] view: row stride B*Cl, sample stride Cl
-            ev = self._event_pair()
-            if h0:
-                # a group's wire buffer reads as [P*Ll][B][its channels]; k / V^T of the group are column / row slices of the whole ones
-                grp = lambda w, g: (w[:n0].view(Lt, B, split) if g == 0 else w[n0:].view(Lt, B, Cl - split)).permute(1, 0, 2)
-                k_all = as_bld(bufs.kw_r)
-                ops.attention_fwd(grp(bufs.qw_r, 0), k_all[..., :split], bufs.vt_full[:, :split], h0, k_len=L, out=grp(bufs.ow_s, 0),
-                                  q_prescaled=True, workspace=self._ws_self)
-                wait_o0 = sp.exchange(bufs.ow_r[:n0], bufs.ow_s[:n0], async_op=True)      # ... under the attention of group 1
-                wait_q1()                                                                  # (arrived under the attention of group 0)
-                ops.attention_fwd(grp(bufs.qw_r, 1), k_all[..., split:], bufs.vt_full[:, split:], Hl - h0, k_len=L, out=grp(bufs.ow_s, 1),
-                                  q_prescaled=True, workspace=self._ws_self)
-            elif a8_sp:
-                # fp8 attention on the arrived operands (bf16 wires; every rank holds all tokens of its heads, so the K mean is local)
-                if B != 1:
-                    raise NotImplementedError("fp8 attention under sequence parallelism covers batch 1 (no CFG batch)")
-                q_arr, k_arr = bufs.qw_r.view(Lt, Cl), bufs.kw_r.view(Lt, Cl)
-                q8v, k8v = bufs.q8.view(-1)[:Lt * Cl].view(Lt, Cl), bufs.k8.view(-1)[:Lt * Cl].view(Lt, Cl)
+            # The head groups of this rank: (first channel, channels, heads, wire elements before it).  A group's wire buffer reads as
+            # [P*Ll][B][its channels]; k / V^T of a group are column / row slices of the whole arrived ones.
+            groups = [(0, split, h0, 0), (split, Cl - split, Hl - h0, n0)] if h0 else [(0, Cl, Hl, 0)]
+            q_waits = [wait_q, wait_q1] if h0 else [wait_q]
+            wire_g = lambda w, c0, cg, off: w[off:off + Lt * B * cg].view(Lt, B, cg).permute(1, 0, 2)     # [B, P*Ll, cg]: row stride B*cg, sample stride cg
+            k_all = bufs.kw_r.view(Lt, B, Cl).permute(1, 0, 2)
+            if a8_sp:
+                # fp8 attention on the arrived operands (bf16 wires; every rank holds ALL tokens of its heads, so the K mean is local).
+                # The token-major wire [P*Ll][B][Cl] is one [P*Ll, B*Cl] matrix: a column is one (sample, channel) pair, so one column
+                # mean / one quantisation pass covers every sample of the CFG batch.  k is quantised once, when it has arrived; every
+                # head group of q when ITS exchange completes (so group 1 still travels under the attention of group 0).
+                from ._lib import load
+                k2d = bufs.kw_r.view(Lt, B * Cl)
                 mean = None
                 if self.fp8_attn_smooth_k:
-                    mean = ops.col_mean(k_arr, Lt, L, 1, out=bufs.kmean.view(-1)[:Cl].view(1, Cl), workspace=bufs.kmean_ws)
-                    if self.sp_world_size == 1:       # (ranks would have to agree on the exponents: calibration is single-process)
-                        calibrate(q_arr, k_arr, mean, Lt)
-                ops.qk_quantize_fp8(q_arr, k_arr, Lt, mean, 2.0 ** qe, 2.0 ** ke, q8v, k8v)
-                if "attn_pv" in blk.f8:
-                    ops.vt_quantize_mx(bufs.vt_full, H // P, L, v8=bufs.v8, scales=bufs.v8s)
-                    ops.attention_fwd_f8(q8v.view(1, Lt, Cl), k8v.view(1, Lt, Cl), bufs.v8, bufs.v8s, bufs.vt_full, H // P, qe, ke, k_len=L,
-                                         out=as_bld(bufs.ow_s), workspace=self._ws_self)
+                    mean = ops.col_mean(k2d, Lt, L, 1, out=bufs.kmean.view(-1)[:B * Cl].view(1, B * Cl), workspace=bufs.kmean_ws)
+                if self.fp8_attn_calibrate and "attn_exp" not in f8 and not torch.cuda.is_current_stream_capturing():
+                    # per-layer exponents, agreed by the ranks: each rank holds other heads, so the operands' maxima are reduced
+                    # (max) over the group -- the pair every rank then uses is the one a single device would have measured
+                    for w_ in q_waits:
+                        w_()
+                    kc = k2d[:L].float() if mean is None else k2d[:L].float() - mean.float()
+                    q_amax = torch.stack([bufs.qw_r[off:off + L * B * cg].float().abs().max() for (_, cg, _, off) in groups]).max()
+                    amax = torch.stack([q_amax, kc.abs().max()])       # (over the L valid token rows of every sample)
+                    if self.sp_world_size > 1:
+                        amax = sp.all_reduce_max(amax)
+                    aq, ak = (float(v) for v in amax.tolist())
+                    pick = lambda a_: int(max(-8, min(8, math.floor(math.log2(448.0 / max(a_, 1e-30))) - 1)))
+                    qe, ke = pick(aq), pick(ak)
+                    f8["attn_exp"] = (qe, ke)
+                k8w = bufs.k8.view(-1)[:Lt * B * Cl]
+                ops.qk_quantize_fp8(None, k2d, Lt, mean, 1.0, 2.0 ** ke, None, k8w)
+                k8_all = k8w.view(Lt, B, Cl).permute(1, 0, 2)
+                pv8 = "attn_pv" in f8
+                hs = int(load().wan_vt_mx_scale_bytes(1, 1, L)) if pv8 else 0          # scale bytes per (sample, head)
+            wait_o = []
+            ev = self._event_pair()
+            for gi, (c0, cg, hg, off) in enumerate(groups):
+                q_waits[gi]()                   # group 0: exposed; group 1 arrived under the attention of group 0
+                if gi == 0:
+                    self._comm_done(cev)
+                o_g = wire_g(bufs.ow_s, c0, cg, off)
+                if a8_sp:
+                    q8g = bufs.q8.view(-1)[off:off + Lt * B * cg]
+                    ops.qk_quantize_fp8(bufs.qw_r[off:off + Lt * B * cg].view(Lt, B * cg), None, Lt, None, 2.0 ** qe, 1.0, q8g, None)
+                    q8v = q8g.view(Lt, B, cg).permute(1, 0, 2)
+                    vt_g = bufs.vt_full[:, c0:c0 + cg]
+                    if pv8:
+                        # a group's V^T is quantised on its own (rows [c0, c0 + cg) of every sample; its scales are a [B][hg] block)
+                        v8g, s8g = bufs.v8[:, c0:c0 + cg], bufs.v8s[B * (c0 // self.d) * hs:B * (c0 // self.d + hg) * hs]
+                        ops.vt_quantize_mx(vt_g, hg, L, v8=v8g, scales=s8g)
+                        ops.attention_fwd_f8(q8v, k8_all[..., c0:c0 + cg], v8g, s8g, vt_g, hg, qe, ke, k_len=L, out=o_g,
+                                             workspace=self._ws_self)
+                    else:
+                        ops.attention_fwd_qk8(q8v, k8_all[..., c0:c0 + cg], vt_g, hg, qe, ke, k_len=L, out=o_g, workspace=self._ws_self)
                 else:
-                    ops.attention_fwd_qk8(q8v.view(1, Lt, Cl), k8v.view(1, Lt, Cl), bufs.vt_full, H // P, qe, ke, k_len=L,
-                                          out=as_bld(bufs.ow_s), workspace=self._ws_self)
-            else:
-                ops.attention_fwd(as_bld(bufs.qw_r), as_bld(bufs.kw_r), bufs.vt_full, H // P, k_len=L, out=as_bld(bufs.ow_s),
-                                  q_prescaled=True, workspace=self._ws_self)
+                    ops.attention_fwd(wire_g(bufs.qw_r, c0, cg, off), k_all[..., c0:c0 + cg], bufs.vt_full[:, c0:c0 + cg], hg, k_len=L,
+                                      out=o_g, q_prescaled=True, workspace=self._ws_self)
+                if gi + 1 < len(groups):        # ... the output of group 0 leaves under the attention of group 1
+                    wait_o.append(sp.exchange(bufs.ow_r[off:off + Lt * B * cg], bufs.ow_s[off:off + Lt * B * cg], async_op=True))
             self._event_done(ev, B * seq_len)
             cev = self._comm_pair()             # exposed: the inverse exchange sits between attention and the o projection (group 1 only)
-            if h0:
-                sp.exchange(bufs.ow_r[n0:], bufs.ow_s[n0:])
-                wait_o0()
-            else:
-                sp.exchange(bufs.ow_r, bufs.ow_s)
+            c0, cg, hg, off = groups[-1]
+            sp.exchange(bufs.ow_r[off:off + Lt * B * cg], bufs.ow_s[off:off + Lt * B * cg])
+            for w_ in wait_o:
+                w_()
             self._comm_done(cev)
             ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B, split=split)
             o_in = att
