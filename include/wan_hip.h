@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 8      /* 8: wan_qk_quantize_fp8 takes either operand alone, tuning key gemm_pk_form replaces gemm_pk_sched, the persistent GEMM from K >= 1024; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
+#define WAN_ABI_VERSION 8      /* 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -42,9 +42,10 @@ int wan_abi_version(void);
 const char* wan_last_error(void);
 
 /* Developer switches (A/B harnesses, bring-up).  The matching environment variables (WAN_ATTN_TAIL, WAN_ATTN_FAST,
- * WAN_ATTN_XCD_MAP, WAN_ATTN_W4, WAN_ATTN_REF, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
+ * WAN_ATTN_XCD_MAP, WAN_ATTN_REF, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
  * read ONCE, at the first call into the library; the launch paths never call getenv().  Keys: "attn_tail",
- * "attn_fast", "attn_xcd_map", "attn_w4", "attn_ref", "conv_head", "gemm_exp", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp".
+ * "attn_fast", "attn_xcd_map", "attn_ref", "conv_head", "gemm_exp", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp",
+ * "gemm_pk", "gemm_pk_form", "gemm_pk_workers", "gemm_pk_min_units", "gemm_pk_order", "gemm_splitk", "row_group", "sp_inline".
  * "debug_checks" = 1 turns on SYNCHRONISING contract checks (V^T pad columns of wan_attention_fwd are finite).
  * wan_set_tuning is an atomic store: safe against concurrent launches, which see the old or the new value.
  * wan_get_tuning returns -1 for an unknown key.  No reference counterpart (the reference has no native code).
@@ -56,7 +57,7 @@ wan_status_t wan_set_tuning(const char* key, int value);
 int wan_get_tuning(const char* key);
 #define WAN_ATTN_VARIANT_W4_LAZY 1          /* attn_fwd_w4_kernel<.,.,1|2>: 4 waves, lazy softmax reference, one launch */
 #define WAN_ATTN_VARIANT_W4_MAXFREE 2       /* attn_fwd_w4_kernel<.,false,0> + its checked fix-up launch attn_fwd_w4_kernel<.,false,1,true> */
-#define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* attn_fwd_v2_kernel, 8 waves, running max per tile ("attn_w4" = 0: developer A/B partner) */
+#define WAN_ATTN_VARIANT_W8_RUNNING_MAX 3   /* (rounds 1-4: the 8-wave running-max kernel; retired in round 5, never reported any more) */
 #define WAN_ATTN_VARIANT_W4_LAZY_QK8 4      /* attn_fwd_w4_kernel<0,.,1,false,true>: the lazy form with QK^T on the fp8 matrix pipe (wan_attention_fwd_qk8) */
 #define WAN_ATTN_VARIANT_W4_F8 5            /* attn_fwd_f8_kernel (fp8 QK^T and fp8 P.V, checked max-free softmax) + the fp8-QK^T lazy kernel on flagged workgroups (wan_attention_fwd_f8) */
 #define WAN_ATTN_VARIANT_FAMILY_MASK 15
@@ -144,10 +145,12 @@ int wan_gemm_plan(int M, int N, int K);
 
 /* The same product with a caller-provided workspace: every nn.Linear of the DiT blocks on the path
  * (wan_transformer3d.py:264-267 q/k/v/o, :457-459 ffn) runs through this entry in the Python host and in wan_dit_block_forward.
- *     With a workspace, shapes the 4-wave 256^2 kernel would take run on its PERSISTENT form: one resident workgroup per CU walks
+ *     With a workspace, shapes a 256^2 kernel would take (K % 128 == 0, K >= 1024) run on the PERSISTENT form: one resident workgroup per CU walks
  *     whole output tiles as one continuous K-tile stream (no per-tile pipeline fill) and the remainder tiles are cut stream-K
  *     fashion so that every CU does the same amount of work (no tail round); split tiles are combined in K order by the last
- *     arriver (bitwise reproducible, no spin waits).  Everything else -- and workspace == NULL -- is wan_gemm_bf16.
+ *     arriver (bitwise reproducible, no spin waits).  Small shapes of the 128^2 kernel whose tiles do not fill the chip (M ~ 2 000
+ *     tokens: BASELINE configs[0]) run that kernel SPLIT-K (ABI 8): the K range of every tile in wan_gemm_ws_splits(M, N, K) pieces,
+ *     combined in split order by the last arriver -- the same guarantees.  Everything else -- and workspace == NULL -- is wan_gemm_bf16.
  *     workspace: >= wan_gemm_workspace_bytes(M, N, K) bytes (0 when the shape would not use one), 16-byte aligned, owned by the
  *     caller, not shared by launches that may run concurrently (one per stream); its contents need not survive between calls.
  *     wan_gemm_ws_plan: the kernel family wan_gemm_bf16_ws picks when given a workspace (host arithmetic only). */
@@ -156,6 +159,7 @@ wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t
                               const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t wan_gemm_workspace_bytes(int M, int N, int K);
 int wan_gemm_ws_plan(int M, int N, int K);
+int wan_gemm_ws_splits(int M, int N, int K);      /* pieces per tile of the split-K form (1: not split); host arithmetic only */
 /* Host arithmetic only (tests, curious hosts): the persistent kernel's plan.  wan_gemm_pk_grid: its grid (workers = one per CU,
  * a multiple of 8).  wan_gemm_pk_segment: segment `index` of worker `worker` -- evaluated by the SAME functions the kernel runs;
  * out[11] = tile m, tile n, first K tile, end K tile, partial?, workspace slot, arrival counter, first / last lane holding a piece of

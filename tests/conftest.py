@@ -48,7 +48,7 @@ def _reset_attention_fast_switch(request):
             from videocof_amd import ops
             for ws in ops._ATTN_WS.values():
                 ws.reset()
-            for key, default in (("attn_tail", 1), ("attn_fast", 1), ("attn_w4", 1), ("attn_ref", 1)):
+            for key, default in (("attn_tail", 1), ("attn_fast", 1), ("attn_ref", 1)):
                 ops.set_tuning(key, default)
         except Exception:
             pass

@@ -54,15 +54,24 @@ def test_every_k_tile_of_every_output_tile_is_computed_exactly_once(M, N, K):
         assert len(ps) >= 2
     if tiles_m * tiles_n * nk // 2 >= 4 * G:         # enough work to balance: no worker waits for a tail round
         assert max(work.values()) - min(work.values()) <= max(2 * 24, nk // 2 + 2)
-    assert int(lib.wan_gemm_workspace_bytes(M, N, K)) in (0, 4096 + G * 2 * 256 * 256 * 4)
+    # (default dispatch: no workspace, the persistent kernel's, or -- small shapes on the 128^2 kernel -- the split-K form's)
+    splits = int(lib.wan_gemm_ws_splits(M, N, K))
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    split_ws = ((t128 * 4 + 4095) // 4096) * 4096 + t128 * splits * 128 * 128 * 4 if splits > 1 else 0
+    assert int(lib.wan_gemm_workspace_bytes(M, N, K)) in (0, 4096 + G * 2 * 256 * 256 * 4, split_ws)
 
 
 def test_workspace_entry_falls_back_and_validates():
     lib = _lib.load()
     # no workspace, or a shape the persistent kernel does not take: wan_gemm_bf16's own validation answers
     assert lib.wan_gemm_bf16_ws(None, 64, None, 64, None, None, 64, 4, 64, 64, 0, None, 0, None, 0, None) == _lib.WAN_ERR_INVALID
-    assert lib.wan_gemm_ws_plan(515, 64, 1024) == lib.wan_gemm_plan(515, 64, 1024)
-    assert lib.wan_gemm_workspace_bytes(515, 64, 1024) == 0
+    assert lib.wan_gemm_ws_plan(515, 64, 1024) == lib.wan_gemm_plan(515, 64, 1024) == 0
+    assert lib.wan_gemm_workspace_bytes(515, 64, 512) == 0 and lib.wan_gemm_ws_splits(515, 64, 512) == 1       # 8 K tiles: nothing to cut
+    # round 5: small shapes whose 128^2 tiles do not fill the chip are cut along K (BASELINE configs[0]: ffn.2 of the 1.3B model at
+    # 2 304 tokens is 216 tiles of 140 K steps; o / cross-o 216 tiles of 24) -- never shapes that already fill 3/4 of a round
+    assert lib.wan_gemm_ws_splits(2304, 1536, 8960) == 2 and lib.wan_gemm_ws_splits(2304, 1536, 1536) == 2
+    assert lib.wan_gemm_ws_splits(2304, 3072, 1536) == 1 and lib.wan_gemm_ws_splits(67080, 64, 5120) == 1
+    assert lib.wan_gemm_workspace_bytes(2304, 1536, 8960) == 4096 + 216 * 2 * 128 * 128 * 4
     assert lib.wan_gemm_ws_plan(67080, 5120, 5120) == 3 and _lib.GEMM_VARIANT_KERNELS[3] == "gemm_pk_kernel"
     # round 5: the K = 1536 Linears of the 1.3B model at a video's token count run the persistent kernel too (K % 128 == 0, K >= 1024);
     # without a workspace they stay on the 8-wave per-tile kernel, and shallow K (the VAE attention block's 384) stays there either way
@@ -70,6 +79,7 @@ def test_workspace_entry_falls_back_and_validates():
     assert lib.wan_gemm_ws_plan(67080, 1536, 8960) == 3 and lib.wan_gemm_ws_plan(67080, 3072, 1536) == 3
     assert lib.wan_gemm_ws_plan(6240, 6240, 384) == lib.wan_gemm_plan(6240, 6240, 384) == 1
     assert lib.wan_gemm_ws_plan(2304, 3072, 1536) == lib.wan_gemm_plan(2304, 3072, 1536) == 0              # < 1 tile per 2 CUs: the 128^2 kernel
+    assert lib.wan_gemm_ws_plan(2304, 8960, 1536) == lib.wan_gemm_plan(2304, 8960, 1536) == 1              # 315 tiles: shallow K needs >= 4 rounds
     need = int(lib.wan_gemm_workspace_bytes(67080, 5120, 5120))
     st = lib.wan_gemm_bf16_ws(16, 5120, 16, 5120, None, 16, 5120, 67080, 5120, 5120, 0, None, 0, 16, need - 1, None)
     assert st == _lib.WAN_ERR_INVALID and b"workspace" in lib.wan_last_error()

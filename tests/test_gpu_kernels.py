@@ -732,6 +732,51 @@ def test_persistent_gemm_row_permuted_epilogues_equal_the_round4_epilogues_bitwi
     assert rel_l2(res[1][4][:, :M].t(), acc + bias.double()) < 4e-3 and float(res[1][4][:, M:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("splits", [0, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(2304, 1536, 8960), (515, 196, 1024), (1000, 520, 2560)])
+def test_split_k_form_of_the_small_shape_gemm(M, N, K, splits):
+    """wan_gemm_bf16_ws on shapes the 128^2 kernel takes and whose tiles do not fill the chip (BASELINE configs[0]: M = 2 304): the
+    K range of every tile cut into pieces (by shape: splits = 0 here -> wan_gemm_ws_splits; or forced 2 / 3 / 4), fp32 pieces in the
+    caller's workspace, combined IN SPLIT ORDER by the last arriver.  Every epilogue against the fp64 product, ragged M / N,
+    bitwise run to run, garbage in the workspace; and really split (workspace requested, plan says so)."""
+    from videocof_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    bias, gate, resid = torch.randn(N, generator=g) * 0.5, torch.randn(2, N, generator=g), torch.randn(M, N, generator=g)
+    acc = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    rpb = (M + 1) // 2
+    if splits:
+        ops.set_tuning("gemm_splitk", splits)
+    try:
+        assert lib.wan_gemm_ws_plan(M, N, K) == 0
+        n_splits = int(lib.wan_gemm_ws_splits(M, N, K))
+        assert n_splits == (splits or n_splits) and n_splits >= 2, (n_splits, splits)
+        ws = ops.gemm_workspace(ad.device, M, N, K)
+        assert ws is not None and ws.numel() >= lib.wan_gemm_workspace_bytes(M, N, K) > 0
+        runs = []
+        for rep in range(2):
+            ws.fill_(0xA5 if rep else 0xFF)
+            o_res = resid.to(DEV).clone()
+            ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=o_res, gate=gate.to(DEV), rows_per_batch=rpb)
+            runs.append((ops.gemm(ad, wd, bd, ops.EPI_BF16), ops.gemm(ad, wd, bd, ops.EPI_GELU_BF16), ops.gemm(ad, wd, bd, ops.EPI_F32),
+                         o_res, ops.gemm(ad, wd, None, ops.EPI_BF16_T)))
+        ops.set_tuning("gemm_splitk", 0)
+        plain = ops.gemm(ad, wd, bd, ops.EPI_F32)            # the unsplit kernel: another summation order, the same product
+    finally:
+        ops.set_tuning("gemm_splitk", 1)
+    o_bf, o_ge, o_f32, o_res, o_t = runs[0]
+    assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
+    assert rel_l2(o_bf, acc) < 4e-3 and rel_l2(o_f32, acc) < 1e-5 and rel_l2(o_f32, plain) < 1e-5
+    x = acc.float().double()
+    assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3
+    gsel = gate.double()[torch.arange(M) // rpb]
+    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
+    assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc - bias.double()) < 4e-3
+    assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
+
+
 def test_persistent_gemm_workspace_is_per_stream():
     """ops.gemm's workspace (arrival / ticket counters and split-tile partial sums of the persistent kernel) is keyed by
     (device, stream): two streams issuing large Linears of one device CONCURRENTLY never share counters.  Both streams run the

@@ -161,6 +161,12 @@ def _rccl_ws1_worker(port, q_out):
         torch.cuda.synchronize()
         n_ev = len(comm)
         ms = sum(a.elapsed_time(b) for a, b in comm)
+        from videocof_amd import GraphedForward
+        try:                                              # this transport's collectives run on the process group's own stream: not captured
+            GraphedForward(m)
+            raise AssertionError("graph capture over the torch.distributed transport must be refused")
+        except NotImplementedError:
+            pass
         m.force_ulysses = False
         m._comm_events = None
         plain_again = m(lat, t, ctx, 420, **kw)
@@ -373,8 +379,7 @@ def test_sp_over_the_library_owned_communicator():
 
 
 def _sp_composition_worker(q_out):
-    """fp8 Linears under the Ulysses branch (library-owned communicator, one rank); graph capture of a sequence-parallel forward is
-    refused (videocof_amd/graph.py::_check_capturable says why)."""
+    """fp8 Linears under the Ulysses branch (library-owned communicator, one rank)."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     from videocof_amd import GraphedForward, WanTransformer3DModel
@@ -398,15 +403,58 @@ def _sp_composition_worker(q_out):
     again = m(lat, t, ctx, 420, **kw)
     wb = m._bufs[m._bufs_last]
     used = bool(m._usp and wb.vt is None and hasattr(wb, "hq"))
-    try:
-        GraphedForward(m)
-        refused = False
-    except NotImplementedError:
-        refused = True
+    refused = True
     torch.cuda.synchronize()
     vdist.destroy_sequence_parallel()
     rel = lambda a, b: float((a - b).norm() / b.norm())
     q_out.put((refused, used, rel(sp8, single8), rel(sp8, bf16), bool(torch.equal(again, sp8))))
+
+
+def _sp_graph_worker(q_out):
+    """hipGraph capture of a sequence-parallel forward: the library communicator records its collectives on the capturing stream
+    itself (csrc/sp_comm.cpp, sp_runs_inline) -- eager call, capture + replay, replays, another input through the same graph."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    from videocof_amd import GraphedForward, WanTransformer3DModel
+    from videocof_amd import dist as vdist
+    from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+    heads, layers = 4, 3
+    cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=layers, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=layers, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+    lat = det_uniform("sp.lat", (2, 16, 7, 12, 20), 1.0).cuda()
+    lat2 = det_uniform("sp.lat2", (2, 16, 7, 12, 20), 1.0).cuda()
+    ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda(), det_uniform("sp.c1", (5, 64), 1.0).cuda()]
+    t = torch.tensor([749, 749], device="cuda:0")
+    kw = dict(frame_split_indices=[3, 3], ground_frame_indices=[(3, 4), (3, 4)])
+    vdist.init_sequence_parallel(backend="library", rank=0, world_size=1)
+    m.enable_multi_gpus_inference()
+    m.force_ulysses = True
+    eager, eager2 = m(lat, t, ctx, 420, **kw), m(lat2, t, ctx, 420, **kw)
+    gf = GraphedForward(m)
+    same = [bool(torch.equal(gf(lat, t, ctx, 420, **kw), eager)) for _ in range(3)]          # eager, capture + replay, replay
+    same.append(bool(torch.equal(gf(lat2, t, ctx, 420, **kw), eager2)))
+    replays = gf.replays
+    gf.reset()                                               # graphs go before the communicator (RCCL's teardown waits for them)
+    del gf
+    torch.cuda.synchronize()
+    vdist.destroy_sequence_parallel()
+    q_out.put((same, replays))
+
+
+def test_graph_capture_of_a_sequence_parallel_forward():
+    """Round 4 could not record an SP forward (hipStreamEndCapture segfaulted with RCCL on a forked side stream).  With the
+    collectives on the capturing stream itself the whole Ulysses forward -- wire-layout kernels, head-group exchanges, all-gather --
+    replays from ONE hipGraph, bit-identical to the eager forward, also for another input.  The torch.distributed transport stays
+    refused (its collectives run on the process group's own stream)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_sp_graph_worker, args=(q,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    same, replays = q.get(timeout=5)
+    assert all(same) and replays == 3
 
 
 def test_fp8_linears_compose_with_ulysses():

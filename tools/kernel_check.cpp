@@ -563,11 +563,10 @@ int main(int argc, char** argv) {
         printf("%s (%d failures)\n", g_fail ? "CHECK FAILED" : "ALL CHECKS PASSED", g_fail);
     }
     if (mode == "attnarms") {     // check_attn under every dispatch arm of wan_attention_fwd
-        struct Arm { const char* name; int w4, fast, ref; };
-        for (Arm arm : {Arm{"w4 lazy, reference in the accumulator", 1, 0, 1}, Arm{"w4 lazy, packed shift", 1, 0, 2},
-                        Arm{"w4 max-free + fix-up", 1, 1, 1}, Arm{"8-wave running max", 0, 0, 1}}) {
+        struct Arm { const char* name; int fast, ref; };
+        for (Arm arm : {Arm{"lazy, reference in the accumulator", 0, 1}, Arm{"lazy, packed shift", 0, 2}, Arm{"max-free + fix-up", 1, 1}}) {
             printf("==== arm: %s\n", arm.name);
-            WAN(wan_set_tuning("attn_w4", arm.w4)); WAN(wan_set_tuning("attn_fast", arm.fast)); WAN(wan_set_tuning("attn_ref", arm.ref));
+            WAN(wan_set_tuning("attn_fast", arm.fast)); WAN(wan_set_tuning("attn_ref", arm.ref));
             check_attn();
             printf("  last variant 0x%x\n", wan_get_tuning("last_attn_variant"));
         }
@@ -812,9 +811,9 @@ int main(int argc, char** argv) {
         fill(q);
         const int64_t wsb = wan_attention_workspace_bytes(1, L, Lk, H, 128);
         Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
-        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp", "attn_w4", "attn_ref"};
-        const int nkeys = 6;
-        int defaults[6]; for (int i = 0; i < nkeys; ++i) defaults[i] = wan_get_tuning(keys[i]);
+        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp", "attn_ref"};
+        const int nkeys = 5;
+        int defaults[5]; for (int i = 0; i < nkeys; ++i) defaults[i] = wan_get_tuning(keys[i]);
         for (int round = 0; round < 2; ++round)
         for (int ai = first; ai < argc; ++ai) {
             for (int i = 0; i < nkeys; ++i) WAN(wan_set_tuning(keys[i], defaults[i]));

@@ -19,7 +19,7 @@ LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
 ATTN_VARIANT_NAMES = {1: "attn_fwd_w4_kernel<.,.,ref> (4-wave, lazy softmax reference)",
                       2: "attn_fwd_w4_kernel<.,false,0> (4-wave, max-free attempt) + attn_fwd_w4_kernel<.,false,1,true> (lazy-reference fix-up of flagged workgroups)",
-                      3: "attn_fwd_v2_kernel (8-wave, running max)",
+                      3: "(retired in round 5: the 8-wave running-max kernel)",
                       4: "attn_fwd_w4_kernel<0,.,1,false,true> (4-wave, lazy softmax reference, QK^T on the fp8 matrix pipe)",
                       5: "attn_fwd_f8_kernel (4-wave, QK^T and P.V on the fp8 matrix pipe, checked max-free softmax) + "
                          "attn_fwd_w4_kernel<0,false,1,true,true> (fp8-QK^T lazy-reference fix-up of flagged workgroups)"}
@@ -148,6 +148,7 @@ SIGNATURES = {
     "wan_attention_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "wan_gemm_plan": (c_int, [c_int, c_int, c_int]),
     "wan_gemm_ws_plan": (c_int, [c_int, c_int, c_int]),
+    "wan_gemm_ws_splits": (c_int, [c_int, c_int, c_int]),
     "wan_gemm_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "wan_gemm_pk_grid": (c_int, [c_int, c_int]),
     "wan_gemm_pk_segment": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),

@@ -56,7 +56,6 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"attn_exp", "WAN_ATTN_EXP", 0},            // experiment selector of the attention kernel (0 = product path)
     {"gemm_variant", "WAN_GEMM_VARIANT", 0},    // 1 = force the 128^2 GEMM, 2 = force the 256^2 GEMM, 0 = by shape
     {"conv_xcd", "WAN_CONV_XCD", 1},            // XCD slab rasterisation of wan_conv_cl
-    {"attn_w4", "WAN_ATTN_W4", 1},              // 4-wave / 64-rows-per-wave kernel (0 = the 8-wave running-max kernel, developer A/B)
     {"gemm_w4", "WAN_GEMM_W4", 1},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 K >= 4096, 2 K >= 8192, 3 whenever K % 128 == 0
     {"conv_fast", "WAN_CONV_FAST", 1},          // wan_conv_cl gather addresses on the branch-free 24-bit multiply path (0 = general 64-bit path)
     {"conv_patch", "WAN_CONV_PATCH", 1},        // causal 3x3x3 stride-1 convs with Cout % 96 == 0 on the LDS-patch kernel (0 = the gather kernel)
@@ -70,6 +69,8 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"gemm_pk_order", "WAN_GEMM_PK_ORDER", 0},          // 1 = whole tiles in lockstep order instead of by per-XCD ticket (developer A/B)
     {"gemm_pk_form", "WAN_GEMM_PK_FORM", 29},           // epilogues of the persistent GEMM, one bit per WAN_EPI_* value: 1 = from row-permuted operand tiles (a lane's accumulators contiguous in the output), 0 = the round-4 form (developer A/B)
     {"row_group", "WAN_ROW_GROUP", 2},                  // LN-modulate / RMSNorm+RoPE: token rows per workgroup (2 or 4: per-column parameters fetched once per group; 1 = the one-row kernels)
+    {"sp_inline", "WAN_SP_INLINE", 0},                  // library communicator: 1 = every collective on the caller's stream itself (no side stream); 0 = only while that stream is being captured
+    {"gemm_splitk", "WAN_GEMM_SPLITK", 1},              // split-K form of the 128^2 GEMM for small shapes that bring a workspace: 1 = by shape, 0 = never, 2..8 = force that many pieces (developer A/B)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

@@ -1,8 +1,9 @@
 // Flash-style non-causal attention for head_dim 128 on gfx950 (the kernel that replaces the
 // flash_attn / sageattention wheels behind attention(), attention_utils.py:152-211).
 //
-// Workgroup = 8 waves x 32 query rows = 256 queries of one (batch, head); KV tiles of 64 keys are
-// streamed through a double-buffered LDS ring by LDS-DMA.  Per wave and KV tile:
+// Workgroup = 4 waves x 64 query rows (two 32-query blocks per wave) = 256 queries of one (batch, head), one wave per SIMD
+// with the whole 512-register file; KV tiles of 64 keys are streamed through a double-buffered LDS ring by LDS-DMA.
+// Per wave, query block and KV tile:
 //
 //   S^T[key, q]  = K[key, :] . Q[q, :]        16 x v_mfma_f32_32x32x16_bf16  ("swapped" QK^T)
 //   online softmax in registers: lane (q = l&31, hi = l>>5) owns 32 of the 64 scores of its query
@@ -74,54 +75,15 @@ struct AttnArgs {
     int exp_nocheck;      // developer experiment (attn_exp & 2), TIMING ONLY: the lazy form skips its per-tile window check
 };
 
-// VARIANT (template parameter of the kernel below) only names the instantiation so profiles separate the two
+// VARIANT (template parameter of the kernels below) only names the instantiation so profiles separate the two
 // call sites:  0 = attn_self (long KV stream: self-attention, Lk ~ 1e4..1e5),
 //              1 = attn_cross (short KV: the 512 text tokens of WanT2VCrossAttention).
-// The first version of this kernel (one tile at a time: S, softmax, P.V, barrier; 1.00-1.07 PFLOP/s) was kept
-// as an in-process A/B partner through round 1 (profiles/r01/attn_variants_ab.log) and has been removed.
+// History: rounds 1-3 also carried an 8-wave kernel here (8 waves x 32 query rows, two waves per SIMD, running max per tile;
+// 1.18-1.28 PFLOP/s) -- the product kernel of round 1 and from round 3 on only the developer A/B partner behind "attn_w4" = 0.  It was
+// retired in round 5 (no product path reached it); what it taught is kept in DESIGN.md section 4.1 and in the A/B logs under
+// profiles/r01 - r03.  Its workgroup geometry survives in the constants above (a workgroup is still 256 queries of one head,
+// KV tiles are still 64 keys, the LDS images and the key permutation are the ones described at the top of this file).
 
-// ====================================================================================================
-// The software pipeline.  Per KV tile j a wave runs three straight-line segments:
-//   A  finish the row max of S(j) (its per-lane partial max was computed as filler of the previous
-//      tile), one lane^32 exchange, and the rare rescale of O (deferred: while the running max grows
-//      by less than 2^kDeferLog2 the old max is kept and O / l are not touched -- guide T13);
-//   B  the 16 MFMAs of S(j+1) = K(j+1).Q^T in the SAME basic block as the exp2 / convert work of the first
-//      key-tile of S(j), so the scheduler interleaves transcendentals with independent matrix work;
-//   C  the 16 MFMAs of O^T += V^T(j).P^T(j) with the exp2 / convert work of the second key-tile of S(j)
-//      as filler of its first two k-steps (the VALU stream is split evenly over the two MFMA segments).
-// S ping-pongs between two register sets (loop unrolled by two); the ragged last tile is peeled so the
-// steady-state loop carries no masking code.  K ring: 2 slots (K(j+1), K(j+2)); V^T ring: 2 slots.
-//
-// Measured alternatives that did NOT pay on MI355X (round 1, same harness, L = 67 080, 40 heads; kept out
-// of the source): (a) waves 4..7 running segment C one barrier late so every SIMD pairs a softmax
-// segment with an MFMA-only segment: 1076 vs 1080 TFLOP/s; (b) the 4-barrier "load | MFMA cluster |
-// softmax+load | MFMA cluster" phasing that gives the GEMM +30 %: 929 TFLOP/s; (c) 4-slot rings with one
-// barrier per tile pair: 1080 vs 1120; (d) v_pk_fma_f32 / v_pk_add_f32 for the exponent argument and the
-// row sum (half the instruction count): 1043 vs 1090 -- packed f32 ops beside MFMAs cost more than they
-// save, as the CDNA4 guide warns; (e) a 4-wave x 64-row one-wave-per-SIMD variant (K/V fragments shared by
-// two query blocks, O in AGPRs): hipcc spills (576 B/lane, 1500 v_accvgpr copies) and runs at 392 TFLOP/s --
-// that structure needs hand-managed AGPRs (inline asm), not attempted this round; (f) taking the softmax
-// denominator from the matrix pipe (one extra MFMA per k-step with an all-ones operand instead of 32
-// VALU adds per tile): 1047 vs 1091 -- the loop is co-limited, MFMA time is not free.  PMC shows why: per tile and wave ~195 VALU + 32 v_exp_f32 cost
-// ~1200 VALU-pipe cycles against 1024 MFMA-pipe cycles -- with two waves per SIMD the softmax VALU
-// work, not the matrix pipe, bounds the loop, so re-arranging who waits for whom moves nothing.
-// (g) a sched_group_barrier weave (1 MFMA : 1 ds_read : 4 VALU across the whole interval) changes the emitted
-// order thoroughly and the time not at all (78.07 vs 78.15 ms).  What does move the loop is REMOVING VALU work:
-// the PRE form below (-32 v_fma per wave and tile) gained 7-8 %, the 15 x v_max3 row max ~1 %.  Time per
-// interval tracks (MFMA cycles + VALU cycles) of the two waves of a SIMD, not their maximum.
-// (h) the first MFMA of each S chain as inline asm with D != C, so that the 16-register splat of -m is not copied
-// into the accumulator every tile (16 v_mov_b64 per tile): removes the copies, runs 2.7 % SLOWER (79.0 vs 76.9 ms).
-// (i) the row sum kept as a packed pair and accumulated with v_pk_add_f32: within noise (74.4 / 76.2 vs 75.3 ms).
-// (j) static s_setprio 1 for waves 4..7 (or 0..3): 73.1-73.8 vs 73.7-73.9 ms, noise.
-// (l) row sum of the packed bf16 P with v_dot2c_f32_bf16 (16 instead of 32 VALU): ~1 % faster but WRONG results (errors of
-// 10 %..100x in the harness; the instruction does not accumulate like two IEEE fmas for these operand ranges) -- not used.
-// (k) "zero mode": keep the softmax reference at 0 while all scores of the wave stay inside +-2^60 (always, for DiT
-// activations), start the S chains from the inline constant 0 and drop the 16 v_mov_b64 copies of -m per tile; the
-// wave-uniform branch around the two chain-start MFMAs costs more than the copies: 78.3 vs 74.2-75.8 ms.
-// ====================================================================================================
-constexpr float kDeferLog2 = 6.0f;
-constexpr int kVRing = 2;
-constexpr int kLdsBytesV2 = 2 * kKTileBytes + kVRing * kVTileBytes;   // 64 KiB
 
 // 32 scores -> 1.  Written as max(max(m, a), b) so that the DAG combiner has exactly one way to fuse each
 // step into v_max3_f32 (15 v_max3 + 1 v_max); max(m, max(a, b)) makes it fuse the wrong pair and emit 31 ops.
@@ -146,321 +108,6 @@ __device__ __forceinline__ float rowmax32(const f32x16 (&s)[2]) {
         m1 = max3f(m1, s[1][r], s[1][r + 1]);
     }
     return max3f(max3f(m0, s[0][15], s[1][15]), m1, m1);
-}
-
-// PRE: q arrives pre-multiplied by softmax_scale*log2(e) (in fp32, before its one bf16 rounding -- see
-// wan_rmsnorm_rope's x0_scale).  The running max then rides in the MFMA accumulator: S' = K.Q^T + (-m)
-// starts from a 16-register splat of -m instead of the inline constant 0, so p = exp2(S') needs no
-// per-score fma: 32 fewer VALU per wave and tile (+6..8 % end to end on this VALU-co-limited loop).
-// (Rounds 1-2 also instantiated this kernel max-free -- p = exp2(S) without a running max, checked at the end, flagged workgroups
-// redone by a second launch; that role has moved to the 4-wave kernel below, and this one is the developer A/B partner
-// behind the "attn_w4" = 0 switch.)
-template <int VARIANT, bool PRE, bool SPLIT = false>
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_v2_kernel(AttnArgs a) {
-    const int wg_linear = blockIdx.x;
-    int qblk_l, bh;
-    if (a.xcd_map) {
-        const int s_ = wg_linear >> 3, g_ = s_ / a.nqb;
-        qblk_l = s_ - g_ * a.nqb;
-        bh = g_ * 8 + (wg_linear & 7);
-    } else {
-        bh = wg_linear / a.nqb;
-        qblk_l = wg_linear - bh * a.nqb;
-    }
-    const int bz = bh / a.H;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5;
-    const int l31 = lane & 31;
-    const int qblk = qblk_l + (SPLIT ? a.qblk0 : 0), head = bh - bz * a.H;
-    const int batch = SPLIT ? bz / a.nsplit : bz;
-    const int split = SPLIT ? bz - batch * a.nsplit : 0;
-    const int t0 = split * a.tiles_per_split;                     // first KV tile of this split
-    const int Lk = SPLIT ? min(a.Lk - t0 * kKV, a.tiles_per_split * kKV) : a.Lk;
-    const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
-    const bf16_t* K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
-    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt + t0 * kKV;
-    bf16_t* O = a.o + batch * a.o_bs + head * kD;
-
-    const int qrow = qblk * kQPerWG + wid * kQPerWave + l31;
-    const int qrow_c = min(qrow, a.Lq - 1);
-    bf16x8 qf[8];
-    {
-        const bf16_t* qp = Q + (int64_t)qrow_c * a.ldq + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-    }
-    auto q_frag = [&](int ks) -> bf16x8 { return qf[ks]; };
-
-    char* const kring = smem;                       // K tile t -> slot t & 1
-    char* const vring = smem + 2 * kKTileBytes;     // V^T tile t -> slot t % 3
-    // Per-lane source addresses are "tile-0 address + a wave-uniform tile offset", so staging a tile costs one
-    // 64-bit add per piece; only the last tile, whose rows may run past Lk, is clamped per lane.
-    int k_row[2], k_col[2];
-    const bf16_t* k_src[2];
-    const bf16_t* v_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wid * 2 + j;
-        const int kr = p * 4 + (lane >> 4);
-        k_row[j] = kr;
-        k_col[j] = ((lane & 15) ^ (kr & 15)) * 8;
-        k_src[j] = K + (int64_t)kr * a.ldk + k_col[j];
-        const int vr = p * 8 + (lane >> 3);
-        const int vc = (lane & 7) ^ ((vr >> 1) & 7);
-        v_src[j] = VT + (int64_t)vr * a.ldvt + vc * 8;
-    }
-    const int nkv_ = (Lk + kKV - 1) / kKV;
-    auto stage_k = [&](int t) {
-        const int kv0 = (t & a.tile_mask) * kKV;
-        if (t == nkv_ - 1) {            // wave-uniform
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kr = min(kv0 + k_row[j], Lk - 1);
-                glds16(K + (int64_t)kr * a.ldk + k_col[j], kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
-            }
-        } else {
-            const int64_t off = (int64_t)kv0 * a.ldk;       // scalar
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(k_src[j] + off, kring + (t & 1) * kKTileBytes + (wid * 2 + j) * 1024);
-        }
-    };
-    auto stage_v = [&](int t) {
-        const int kv0 = (t & a.tile_mask) * kKV;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(v_src[j] + kv0, vring + (t % kVRing) * kVTileBytes + (wid * 2 + j) * 1024);
-    };
-
-    const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    const int k_rowoff = pi * 256, k_sw = pi & 15;
-    int k_off[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) k_off[ks] = k_rowoff + (((2 * ks + hi) ^ k_sw) << 4);
-    const int v_rowoff = l31 * 128, v_sw = (l31 >> 1) & 7;
-    int v_off[4];
-#pragma unroll
-    // the V ring's base (32 KiB) sits in the per-lane offset so that every ds_read immediate stays below 32 KiB
-    for (int t = 0; t < 4; ++t) v_off[t] = 2 * kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
-
-    f32x16 o_acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-    float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
-    const float c = a.scale_log2e;
-    const int nkv = (Lk + kKV - 1) / kKV;
-
-    // segment A: finish the row max, decide / apply the rescale; returns m*c (unused with PRE)
-    f32x16 negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-    bool first = true;
-    auto seg_a = [&](float mx_part, f32x16 (&sc)[2]) -> float {
-        const float mx = max_with_lane_xor32(mx_part);
-        if constexpr (PRE) {
-            // scores are already relative to m_run and in log2 units
-            if (first || !__all(mx <= kDeferLog2)) {           // wave-uniform; rare after the first tiles
-                const float delta = first ? mx : fmaxf(mx, 0.f);
-                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-                first = false;
-                m_run += delta;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)                 // this tile was accumulated on the old -m
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[kt][r] -= delta;
-                const float nm = -m_run;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] = nm;
-            }
-            return 0.f;
-        } else {
-            if (!__all((mx - m_run) * c <= kDeferLog2)) {     // wave-uniform; rare after the first tiles
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-            }
-            return m_run * c;
-        }
-    };
-    auto p_group = [&](const f32x16& sv, int t2, float mc, float& psum) -> bf16x8 {
-        float p[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            p[j] = PRE ? __builtin_amdgcn_exp2f(sv[8 * t2 + j]) : __builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 * t2 + j], c, -mc));
-            psum += p[j];
-        }
-        u32x4 w = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
-        return __builtin_bit_cast(bf16x8, w);
-    };
-    // segment C: O^T += V^T(t).P^T(t).  With BALANCED the exp2/convert work of the second key-tile
-    // (groups 2,3) runs here as filler of the first two k-steps instead of all of it in segment B.
-    // Ring slots are passed as literals from the 2x-unrolled loop (tile parity is known there), so every ds_read
-    // address is a loop-invariant VGPR + immediate offset.
-    auto pv = [&](int vslot, bf16x8 (&pf)[4], const f32x16* sc_late, float mc, float* psum_late) {
-        const char* vb = smem + vslot * kVTileBytes;        // + v_off (which includes the ring base)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_off[tt]);
-                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tt], o_acc[dt], 0, 0, 0);
-            }
-            if (sc_late != nullptr && tt < 2) pf[2 + tt] = p_group(*sc_late, tt, mc, *psum_late);
-        }
-    };
-    // segment B: S(t+1) -> sn from K(t+1); P(t) groups 0,1 (key-tile 0) -> pf; groups 2,3 follow in segment C
-    auto seg_b = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int kslot_next, float mc, bf16x8 (&pf)[4], float& psum) {
-        const char* kb = kring + kslot_next * kKTileBytes;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            if constexpr (!PRE) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 qv = q_frag(ks);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kt * 32 * 256 + k_off[ks]);
-                if (PRE && ks == 0) {
-                    sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, negm, 0, 0, 0);
-                } else {
-                    sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, sn[kt], 0, 0, 0);
-                }
-            }
-            if (ks == 3) pf[0] = p_group(sc[0], 0, mc, psum);
-            if (ks == 7) pf[1] = p_group(sc[0], 1, mc, psum);
-        }
-    };
-    auto prefetch = [&](int t) {        // issued at the top of interval t
-        if (t + 2 < nkv) stage_k(t + 2);    // slot of K(t), last read in interval t-1
-        stage_v(t + 1);                      // slot of V(t-1), last read in interval t-1
-    };
-    auto fence = [&]() {
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-    };
-
-    stage_k(0);
-    stage_v(0);
-    if (nkv > 1) stage_k(1);
-    fence();
-    f32x16 s0[2], s1[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s0[kt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kring + kt * 32 * 256 + k_off[ks]);
-            s0[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q_frag(ks), s0[kt], 0, 0, 0);
-        }
-    }
-    float mx_part = rowmax32(s0);
-    __syncthreads();            // everyone is done with K slot 0 before tile 2 lands in it
-
-    const int nfull = nkv - 1;  // tiles handled by the steady-state intervals; the last tile is peeled
-    bf16x8 pf[4];
-    int it = 0;
-    bool last_in_s1 = false;
-    // one interval: tile t lives in `sc`, S(t+1) is produced into `sn`
-    auto interval = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int kslot_next, int vslot) {
-        float mc = 0.f;
-        mc = seg_a(mx_part, sc);
-        float ps = 0.f;
-        seg_b(sc, sn, kslot_next, mc, pf, ps);
-        pv(vslot, pf, &sc[1], mc, &ps);
-        l_run += ps;
-        mx_part = rowmax32(sn);
-    };
-    for (; it + 2 <= nfull; it += 2) {          // `it` is even here: K(it+1) sits in slot 1, V(it) in slot 0
-        prefetch(it);
-        interval(s0, s1, 1, 0);
-        fence();
-        prefetch(it + 1);
-        interval(s1, s0, 0, 1);
-        fence();
-    }
-    if (it < nfull) {
-        prefetch(it);
-        interval(s0, s1, 1, 0);
-        fence();
-        ++it;
-        last_in_s1 = true;
-    }
-    // ---- peeled last tile (it == nkv-1): mask keys >= Lk, no prefetch, no next S
-    {
-        f32x16 sl[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) sl[kt] = last_in_s1 ? s1[kt] : s0[kt];
-        const int kv0 = it * kKV;
-        if (kv0 + kKV > Lk) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= Lk) sl[kt][r] = -INFINITY;
-                }
-            mx_part = rowmax32(sl);
-        }
-        float mc = 0.f;
-        mc = seg_a(mx_part, sl);
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) pf[2 * kt + t2] = p_group(sl[kt], t2, mc, psum);
-        l_run += psum;
-        pv(it & 1, pf, nullptr, 0.f, nullptr);
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if constexpr (SPLIT) {
-        // partial result of this KV range: un-normalised O, its reference max (log2 units) and its sum
-        if (qrow < a.Lq) {
-            const int64_t r = ((int64_t)(batch * a.nsplit + split) * a.H + head) * a.rows_tail + (qrow - a.row0);
-            float* wo = a.ws_o + r * kD + 4 * hi;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(wo + 32 * dt + 8 * g) =
-                        make_float4(o_acc[dt][4 * g + 0], o_acc[dt][4 * g + 1], o_acc[dt][4 * g + 2], o_acc[dt][4 * g + 3]);
-            if (hi == 0) {
-                a.ws_ml[2 * r] = PRE ? m_run : m_run * c;
-                a.ws_ml[2 * r + 1] = l_tot;
-            }
-        }
-    } else {
-        const float inv = 1.0f / l_tot;
-        if (qrow < a.Lq) {
-            bf16_t* op = O + (int64_t)qrow * a.ldo + 4 * hi;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2 w = {pack_bf16x2(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv),
-                               pack_bf16x2(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv)};
-                    *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g) = w;
-                }
-        }
-    }
 }
 
 // ====================================================================================================
@@ -1579,13 +1226,12 @@ int64_t flag_bytes(int batch, int Lq, int num_heads) {
 
 namespace {
 // The dispatch decision of wan_attention_fwd as host arithmetic (shared by the launcher and wan_attention_plan).
-struct AttnPlan { TailPlan tail; bool fast = false, w4 = true, ref2 = false, xcd = false; int variant = 0; };
+struct AttnPlan { TailPlan tail; bool fast = false, ref2 = false, xcd = false; int variant = 0; };
 
 AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int64_t workspace_bytes, bool qk8 = false, bool pv8 = false) {
     AttnPlan p;
     const bool self = Lk > 1024;
     const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
-    p.w4 = wan_tune(WAN_TUNE_ATTN_W4) != 0;
     // plain q always takes the packed-shift form (it applies softmax_scale exactly, in the same fma); pre-scaled q the
     // accumulator form unless the developer switch asks for the other
     p.ref2 = !pre || wan_tune(WAN_TUNE_ATTN_REF) == 2;
@@ -1596,7 +1242,7 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
         // attn_fast = 2 forces the attempt whenever there is scratch (tests)
         const int fast_mode = wan_tune(WAN_TUNE_ATTN_FAST);
         const bool long_launch = self && (int64_t)nqb_all * num_heads * batch >= 4LL * wan_cu_count();
-        p.fast = pre && p.w4 && !qk8 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
+        p.fast = pre && !qk8 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
         p.tail = plan_tail(batch, Lq, Lk, num_heads);
         if (p.tail.tq > 0 && workspace_bytes - fb < p.tail.ws_bytes) p.tail = TailPlan();
     }
@@ -1604,7 +1250,7 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
     p.xcd = wan_tune(WAN_TUNE_ATTN_XCD_MAP) != 0 && self && (num_heads * batch) % 8 == 0;
     if (qk8) p.ref2 = false;
     p.variant = (qk8 && pv8 && workspace_bytes >= fb) ? WAN_ATTN_VARIANT_W4_F8 : qk8 ? WAN_ATTN_VARIANT_W4_LAZY_QK8
-                    : (!p.w4 ? WAN_ATTN_VARIANT_W8_RUNNING_MAX : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY));
+                    : (p.fast ? WAN_ATTN_VARIANT_W4_MAXFREE : WAN_ATTN_VARIANT_W4_LAZY);
     if (p.xcd) p.variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (p.tail.tq > 0) p.variant |= WAN_ATTN_VARIANT_SPLIT_TAIL;
     return p;
@@ -1653,7 +1299,6 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
                         k_bstride % 16 == 0, WAN_ERR_INVALID, "wan_attention_fwd_qk8: e4m3 rows must be 16-byte aligned");
         WAN_REQUIRE(qk8->q_exp >= -100 && qk8->q_exp <= 100 && qk8->k_exp >= -100 && qk8->k_exp <= 100, WAN_ERR_INVALID,
                     "wan_attention_fwd_qk8: scale exponents (%d, %d) out of range", qk8->q_exp, qk8->k_exp);
-        WAN_REQUIRE(wan_tune(WAN_TUNE_ATTN_W4) != 0, WAN_ERR_UNSUPPORTED, "wan_attention_fwd_qk8: only the 4-wave kernel has an fp8 form");
     }
     const int64_t lk_pad = ((int64_t)Lk + kKV - 1) / kKV * kKV;
     WAN_REQUIRE(ldvt >= lk_pad && ldvt % 8 == 0, WAN_ERR_INVALID,
@@ -1670,10 +1315,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     if (Lq == 0) return WAN_OK;
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t ast = wan_once_per_device(attr_done, +[]() -> wan_status_t {
-        const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, false>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<1, true>),
-                             reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, false, true>), reinterpret_cast<const void*>(&attn_fwd_v2_kernel<0, true, true>),
-                             reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 0>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 0>),
+        const void* fns[] = {reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 0>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 0>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 1>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, true>), reinterpret_cast<const void*>(&attn_fwd_w4_kernel<1, false, 1, true>),
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, true, 1>),
@@ -1684,7 +1326,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
                              reinterpret_cast<const void*>(&attn_fwd_w4_kernel<0, false, 1, true, true>),
                              reinterpret_cast<const void*>(&attn_fwd_f8_kernel)};
         for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesV2);
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesW4);
             if (e != hipSuccess) {
                 wan_set_error("wan_attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
                 return WAN_ERR_LAUNCH;
@@ -1718,7 +1360,6 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     a.scale_log2e = pre ? 1.0f : softmax_scale * 1.4426950408889634f;
     a.qblk0 = 0; a.nsplit = 1; a.tiles_per_split = 0; a.row0 = 0; a.rows_tail = 0; a.ws_o = nullptr; a.ws_ml = nullptr; a.flags = nullptr;
     const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
-    dim3 block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     const bool self = Lk > 1024;
     a.tile_mask = (wan_tune(WAN_TUNE_ATTN_EXP) & 1) ? 15 : 0x7fffffff;
@@ -1751,7 +1392,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     const int64_t nwg = (int64_t)a.nqb * a.nbh;
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
     dim3 grid((unsigned)nwg);
-    const bool w4 = plan.w4, ref2 = plan.ref2;
+    const bool ref2 = plan.ref2;
     const dim3 block4(kW4Threads);
     int variant;
     if (pv8) {                       // fp8 QK^T and fp8 P.V (opt-in, lossy): checked max-free form, flagged workgroups redone by the fp8-QK^T lazy kernel
@@ -1762,7 +1403,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     } else if (qk8) {                // fp8 QK^T (opt-in, lossy): the lazy-reference kernel with its S product on the fp8 pipe
         variant = WAN_ATTN_VARIANT_W4_LAZY_QK8;
         hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, false, true>), grid, block4, kLdsBytesW4, st, a);
-    } else if (w4 && !fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
+    } else if (!fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
         variant = WAN_ATTN_VARIANT_W4_LAZY;
         if (ref2) {
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 2>), grid, block4, kLdsBytesW4, st, a);
@@ -1771,22 +1412,13 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1>), grid, block4, kLdsBytesW4, st, a);
             else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1>), grid, block4, kLdsBytesW4, st, a);
         }
-    } else if (w4) {                 // max-free attempt (2 % faster), then the lazy-reference kernel on the flagged workgroups only
+    } else {                         // max-free attempt (2 % faster), then the lazy-reference kernel on the flagged workgroups only
         variant = WAN_ATTN_VARIANT_W4_MAXFREE;
         if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 0>), grid, block4, kLdsBytesW4, st, a);
         else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 0>), grid, block4, kLdsBytesW4, st, a);
         WAN_CHECK_LAUNCH("wan_attention_fwd");
         if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, true>), grid, block4, kLdsBytesW4, st, a);
         else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1, true>), grid, block4, kLdsBytesW4, st, a);
-    } else {                         // developer A/B partner: the round-1 8-wave kernel, running max per tile
-        variant = WAN_ATTN_VARIANT_W8_RUNNING_MAX;
-        if (pre) {
-            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true>), grid, block, kLdsBytesV2, st, a);
-            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, true>), grid, block, kLdsBytesV2, st, a);
-        } else {
-            if (self) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false>), grid, block, kLdsBytesV2, st, a);
-            else hipLaunchKernelGGL((attn_fwd_v2_kernel<1, false>), grid, block, kLdsBytesV2, st, a);
-        }
     }
     if (a.xcd_map) variant |= WAN_ATTN_VARIANT_XCD_PINNED;
     if (tp.tq > 0) {
@@ -1799,10 +1431,8 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
         a.nqb = tp.tq; a.nbh = num_heads * batch * tp.nsplit; a.xcd_map = 0;
         dim3 tgrid((unsigned)((int64_t)a.nqb * a.nbh));
         if (qk8) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 1, false, true>), tgrid, block4, kLdsBytesW4, st, a);
-        else if (w4 && ref2) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 2>), tgrid, block4, kLdsBytesW4, st, a);
-        else if (w4) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 1>), tgrid, block4, kLdsBytesW4, st, a);
-        else if (pre) hipLaunchKernelGGL((attn_fwd_v2_kernel<0, true, true>), tgrid, block, kLdsBytesV2, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v2_kernel<0, false, true>), tgrid, block, kLdsBytesV2, st, a);
+        else if (ref2) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 2>), tgrid, block4, kLdsBytesW4, st, a);
+        else hipLaunchKernelGGL((attn_fwd_w4_kernel<0, true, 1>), tgrid, block4, kLdsBytesW4, st, a);
         WAN_CHECK_LAUNCH("wan_attention_fwd (tail)");
         hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)tp.rows_tail, (unsigned)num_heads, (unsigned)batch), dim3(kD), 0, st, a);
     }

@@ -19,6 +19,8 @@
 // resident on an XCD share 8 A-panels and 8 W-panels through its private L2.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 // gemm_bf16_pk.hip: the persistent stream-K form of the 4-wave 256 x 256 kernel (callers that bring a workspace)
@@ -48,6 +50,13 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int64_t sA, sW, sO;      // element strides between the problems of a batched launch (blockIdx.y)
+    // split-K form (SPLITK instantiation, round 5): blockIdx.y = split index s of `splitk`; a workgroup multiplies K tiles
+    // [s * nk / splitk, (s + 1) * nk / splitk) of its output tile, stores its fp32 accumulators to its slot of the caller's
+    // workspace and takes a ticket on the tile's arrival counter; the LAST arriver adds the pieces IN SPLIT ORDER (its own from
+    // registers) and runs the normal epilogue -- bitwise reproducible, nobody waits for anybody (as in gemm_bf16_pk.hip).
+    int splitk;
+    int* counters;           // workspace head: one arrival counter per output tile (zeroed by a memset node ahead of the launch)
+    char* slots;             // behind the counters: [tile][split] slots of 128 x 128 fp32, register-major
 };
 
 __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
@@ -68,7 +77,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn)
     tn = in / gm;
 }
 
-template <int EPI>
+template <int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool kTransposed = (EPI == WAN_EPI_BF16_T);
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     int tm, tn;
     tile_coords(g, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
-    if (gridDim.y > 1) {         // wan_gemm_bf16_batched: problem blockIdx.y
+    if (!SPLITK && gridDim.y > 1) {         // wan_gemm_bf16_batched: problem blockIdx.y
         g.A += blockIdx.y * g.sA;
         g.W += blockIdx.y * g.sW;
         g.out = (char*)g.out + blockIdx.y * g.sO * ((EPI == WAN_EPI_F32 || EPI == WAN_EPI_RESID_F32) ? 4 : 2);
@@ -126,13 +135,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / BK;
-    stage(0, 0);
+    const int nk_all = g.K / BK;
+    const int split = SPLITK ? (int)blockIdx.y : 0;
+    const int kt0 = SPLITK ? (int)((int64_t)split * nk_all / g.splitk) : 0;
+    const int nk = SPLITK ? (int)((int64_t)(split + 1) * nk_all / g.splitk) : nk_all;
+    stage(0, kt0);
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): tile 0 landed
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* sb = smem + cur * kStageBytes;
 #pragma unroll
@@ -156,6 +168,42 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
         __builtin_amdgcn_s_waitcnt(0);   // next tile landed (vmcnt) + our ds_reads retired
         __syncthreads();
+    }
+
+    if constexpr (SPLITK) {
+        // publish my piece with write-through (sc1) stores (no L2 write-back needed to make it visible: CDNA4 guide, "publish-large"),
+        // drain them, take a ticket; only the last arriver of the tile goes on
+        const int tile = tm * g.tiles_n + tn;
+        char* const tile_slots = g.slots + (int64_t)tile * g.splitk * (BM * BN * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tile_slots + (int64_t)split * (BM * BN * 4)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, ((i * 4 + j) * kThreads + tid) * 16, 0, /*sc1*/ 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        volatile int* const lds_flag = reinterpret_cast<volatile int*>(smem);
+        if (tid == 0) lds_flag[0] = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(lds_flag[0]) != g.splitk - 1) return;
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        f32x4 sum[4][4];
+        for (int sidx = 0; sidx < g.splitk; ++sidx) {            // in split order, whoever arrived last
+            const f32x4* src = reinterpret_cast<const f32x4*>(tile_slots + (int64_t)sidx * (BM * BN * 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 t = sidx == split ? acc[i][j] : src[(i * 4 + j) * kThreads + tid];
+                    sum[i][j] = sidx == 0 ? t : sum[i][j] + t;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = sum[i][j];
     }
 
     // ---- epilogue
@@ -262,9 +310,57 @@ wan_status_t launch(const GemmArgs& g, hipStream_t s, int batch = 1) {
     return WAN_OK;
 }
 
+// split-K launch of the 128^2 kernel (small shapes that bring a workspace: see wan_gemm_splitk below)
+template <int EPI>
+wan_status_t launch_splitk(const GemmArgs& g, hipStream_t s, int64_t counter_bytes) {
+    static std::atomic<uint64_t> attr_done{0};
+    const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) {
+            wan_set_error("wan_gemm_bf16_ws: cannot reserve %d B of LDS: %s", kLdsBytes, hipGetErrorString(e));
+            return WAN_ERR_LAUNCH;
+        }
+        return WAN_OK;
+    });
+    if (st != WAN_OK) return st;
+    if (hipMemsetAsync(g.counters, 0, (size_t)counter_bytes, s) != hipSuccess) {
+        wan_set_error("wan_gemm_bf16_ws: cannot clear the arrival counters: %s", hipGetErrorString(hipGetLastError()));
+        return WAN_ERR_LAUNCH;
+    }
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)g.splitk), block(kThreads);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true>), grid, block, kLdsBytes, s, g);
+    WAN_CHECK_LAUNCH("wan_gemm_bf16_ws (split-K)");
+    return WAN_OK;
+}
+
 }  // namespace
 
 bool wan_gemm256_uses_w4(int K);        // gemm_bf16_256.hip
+
+// Small shapes on the 128^2 kernel (configs[0]: M = 2 304 tokens): when its output tiles do not fill the chip's 2 x CUs workgroup
+// slots and K is deep enough, the K range of every tile is cut into `splits` pieces (2 .. 4) so that the launch is (close to) one
+// full round of shorter workgroups -- ffn.2 at M = 2 304 (N = 1 536, K = 8 960) is 216 tiles of 140 serial K steps on 256 CUs, the
+// same product as 432 workgroups of 70.  Needs the caller's workspace (wan_gemm_bf16_ws); 1 = no split.
+static int wan_gemm_splitk(int M, int N, int K) {
+    if (wan_tune(WAN_TUNE_GEMM_SPLITK) == 0) return 1;
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int slots = 2 * wan_cu_count();
+    const int nk = K / BK;
+    if (const int f = wan_tune(WAN_TUNE_GEMM_SPLITK); f > 1) return (f <= 8 && nk >= 2 * f) ? f : 1;      // developer override
+    if (tiles * 4 > (int64_t)slots * 3 || nk < 16) return 1;                // >= 3/4 of a round already, or nothing to cut
+    int splits = (int)std::min<int64_t>(slots / tiles, 4);
+    while (splits > 1 && nk / splits < 8) --splits;                        // at least 8 K tiles per piece
+    return splits < 2 ? 1 : splits;
+}
+static int64_t splitk_counter_bytes(int M, int N) {
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    return (tiles * 4 + 4095) / 4096 * 4096;
+}
+static int64_t splitk_workspace_bytes(int M, int N, int splits) {
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    return splitk_counter_bytes(M, N) + tiles * splits * (int64_t)(BM * BN * 4);
+}
 
 // Which kernel family wan_gemm_bf16 dispatches a shape to (host arithmetic, no GPU needed).  Large shapes -> the 256^2 tile
 // (one workgroup per CU: 8-wave phased kernel, or its 4-wave form for deep K), unless its tiles would leave more than half of
@@ -289,20 +385,62 @@ extern "C" int wan_gemm_plan(int M, int N, int K) {
 extern "C" int wan_gemm_ws_plan(int M, int N, int K) {
     const int pk = wan_tune(WAN_TUNE_GEMM_PK);
     const int base = wan_gemm_plan(M, N, K);
-    if (pk == 1 && base != WAN_GEMM_VARIANT_128 && K % 128 == 0 && K >= 1024) return WAN_GEMM_VARIANT_256_PK;
+    // (shallow K only with at least four rounds of tiles: at M = 2 304 the K = 1536 ffn.0 of the 1.3B model is 315 tiles on 256 CUs --
+    // mostly stream-K pieces, whose fix-up traffic costs more than the per-tile pipeline fill it saves: 0.095 vs 0.086 ms)
+    const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    if (pk == 1 && base != WAN_GEMM_VARIANT_128 && K % 128 == 0 && (K >= 4096 || (K >= 1024 && tiles256 >= 4 * (int64_t)wan_cu_count())))
+        return WAN_GEMM_VARIANT_256_PK;
     if (pk == 2 && K % 128 == 0 && M >= 256 && N >= 256) return WAN_GEMM_VARIANT_256_PK;
     return base;
 }
 
 extern "C" int64_t wan_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return wan_gemm_ws_plan(M, N, K) == WAN_GEMM_VARIANT_256_PK ? wan_gemm_pk_workspace_bytes(M, N) : 0;
+    const int plan = wan_gemm_ws_plan(M, N, K);
+    if (plan == WAN_GEMM_VARIANT_256_PK) return wan_gemm_pk_workspace_bytes(M, N);
+    if (plan == WAN_GEMM_VARIANT_128 && K % BK == 0) {
+        const int splits = wan_gemm_splitk(M, N, K);
+        if (splits > 1) return splitk_workspace_bytes(M, N, splits);
+    }
+    return 0;
+}
+
+// how many pieces wan_gemm_bf16_ws cuts the K range of this shape's tiles into (1: no split; host arithmetic)
+extern "C" int wan_gemm_ws_splits(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || wan_gemm_ws_plan(M, N, K) != WAN_GEMM_VARIANT_128) return 1;
+    return wan_gemm_splitk(M, N, K);
 }
 
 extern "C" wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                          void* out, int64_t ldo, int M, int N, int K, int epilogue,
                                          const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes,
                                          void* stream) {
+    // small shapes: the 128^2 kernel with its K range cut into pieces when that fills the chip (the arguments are validated by
+    // wan_gemm_bf16 first: a split launch of an invalid call must not happen)
+    if (workspace != nullptr && M > 0 && N > 0 && K > 0 && K % BK == 0 && wan_gemm_ws_plan(M, N, K) == WAN_GEMM_VARIANT_128) {
+        const int splits = wan_gemm_splitk(M, N, K);
+        if (splits > 1 && workspace_bytes >= splitk_workspace_bytes(M, N, splits) && ((uintptr_t)workspace & 15) == 0 && A && W && out &&
+            N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ldo % 4 == 0 &&
+            (epilogue == WAN_EPI_BF16_T ? ldo >= M : ldo >= N) && (gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0))) {
+            GemmArgs g;
+            g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
+            g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+            g.M = M; g.N = N; g.K = K;
+            g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+            g.sA = g.sW = g.sO = 0;
+            g.splitk = splits; g.counters = (int*)workspace; g.slots = (char*)workspace + splitk_counter_bytes(M, N);
+            hipStream_t s = (hipStream_t)stream;
+            const int64_t cb = splitk_counter_bytes(M, N);
+            switch (epilogue) {
+                case WAN_EPI_BF16: return launch_splitk<WAN_EPI_BF16>(g, s, cb);
+                case WAN_EPI_GELU_BF16: return launch_splitk<WAN_EPI_GELU_BF16>(g, s, cb);
+                case WAN_EPI_F32: return launch_splitk<WAN_EPI_F32>(g, s, cb);
+                case WAN_EPI_RESID_F32: return launch_splitk<WAN_EPI_RESID_F32>(g, s, cb);
+                case WAN_EPI_BF16_T: return launch_splitk<WAN_EPI_BF16_T>(g, s, cb);
+                default: break;          // wan_gemm_bf16 reports it
+            }
+        }
+    }
     // (a gate whose samples are shorter than a wave's 128 rows: the persistent kernel's epilogue allows one sample seam per wave)
     if (workspace == nullptr || M <= 0 || N <= 0 || K <= 0 || wan_gemm_ws_plan(M, N, K) != WAN_GEMM_VARIANT_256_PK ||
         (gate != nullptr && rows_per_batch < 128))
@@ -348,6 +486,7 @@ extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W,
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.sA = g.sW = g.sO = 0;
+    g.splitk = 1; g.counters = nullptr; g.slots = nullptr;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case WAN_EPI_BF16: return launch<WAN_EPI_BF16>(g, s);
@@ -380,6 +519,7 @@ extern "C" wan_status_t wan_gemm_bf16_batched(const void* A, int64_t lda, int64_
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.sA = strideA; g.sW = strideW; g.sO = strideO;
+    g.splitk = 1; g.counters = nullptr; g.slots = nullptr;
     hipStream_t s = (hipStream_t)stream;
     return epilogue == WAN_EPI_BF16 ? launch<WAN_EPI_BF16>(g, s, batch) : launch<WAN_EPI_F32>(g, s, batch);
 }

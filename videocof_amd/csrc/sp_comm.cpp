@@ -80,7 +80,20 @@ struct wan_sp_comm {
     hipEvent_t done[kRing] = {};
     int64_t ticket = 0;                              // exchanges started so far
     int64_t waited = 0;                              // every ticket <= waited has been joined by a wait on the caller's stream
+    // Exchanges that ran INLINE on the caller's stream (round 5: when that stream is being captured into a hipGraph -- or the
+    // developer switch sp_inline is on -- the collective is enqueued on the caller's stream itself: no side stream, no event fork /
+    // join; a forked side stream under capture is what made hipStreamEndCapture segfault in round 4).  Such a ticket needs no wait.
+    bool inline_slot[kRing] = {};
+    bool captured = false;                           // some collective of this communicator was recorded into a hipGraph
 };
+
+// true: enqueue on the caller's stream (the stream is capturing, or sp_inline = 1)
+static bool sp_runs_inline(wan_sp_comm* c, hipStream_t cs) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(cs, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+    if (st == hipStreamCaptureStatusActive) { c->captured = true; return true; }
+    return wan_tune(WAN_TUNE_SP_INLINE) != 0;
+}
 
 #define WAN_SP_HIP(call, what)                                                              \
     do {                                                                                    \
@@ -159,10 +172,17 @@ static wan_status_t a2a_start(wan_sp_comm* c, const void* send, void* recv, int6
                 what, (long long)bytes_total, c->world);
     WAN_REQUIRE(send != recv, WAN_ERR_INVALID, "%s: in-place exchange is not supported (persistent send / receive pairs)", what);
     hipStream_t cs = (hipStream_t)compute_stream;
+    if (sp_runs_inline(c, cs)) {           // in stream order on the caller's stream: nothing to fork, nothing to join
+        WAN_SP_NCCL(rccl().AllToAll(send, recv, (size_t)(bytes_total / c->world), ncclInt8, c->comm, cs), what);
+        ++c->ticket;
+        c->inline_slot[c->ticket % wan_sp_comm::kRing] = true;
+        return WAN_OK;
+    }
     WAN_SP_HIP(hipEventRecord(c->ready, cs), what);                 // everything enqueued on the compute stream so far ...
     WAN_SP_HIP(hipStreamWaitEvent(c->side, c->ready, 0), what);     // ... precedes the exchange
     WAN_SP_NCCL(rccl().AllToAll(send, recv, (size_t)(bytes_total / c->world), ncclInt8, c->comm, c->side), what);
     ++c->ticket;
+    c->inline_slot[c->ticket % wan_sp_comm::kRing] = false;
     WAN_SP_HIP(hipEventRecord(c->done[c->ticket % wan_sp_comm::kRing], c->side), what);
     return WAN_OK;
 }
@@ -180,10 +200,17 @@ extern "C" wan_status_t wan_sp_a2a_gather_heads(wan_sp_comm* c, const void* send
 extern "C" wan_status_t wan_sp_all_gather(wan_sp_comm* c, const void* send, void* recv, int64_t bytes_per_rank, void* compute_stream) {
     WAN_REQUIRE(c != nullptr && send != nullptr && recv != nullptr && bytes_per_rank > 0, WAN_ERR_INVALID, "wan_sp_all_gather: bad argument");
     hipStream_t cs = (hipStream_t)compute_stream;
+    if (sp_runs_inline(c, cs)) {
+        WAN_SP_NCCL(rccl().AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, c->comm, cs), "wan_sp_all_gather");
+        ++c->ticket;
+        c->inline_slot[c->ticket % wan_sp_comm::kRing] = true;
+        return WAN_OK;
+    }
     WAN_SP_HIP(hipEventRecord(c->ready, cs), "wan_sp_all_gather");
     WAN_SP_HIP(hipStreamWaitEvent(c->side, c->ready, 0), "wan_sp_all_gather");
     WAN_SP_NCCL(rccl().AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, c->comm, c->side), "wan_sp_all_gather");
     ++c->ticket;
+    c->inline_slot[c->ticket % wan_sp_comm::kRing] = false;
     WAN_SP_HIP(hipEventRecord(c->done[c->ticket % wan_sp_comm::kRing], c->side), "wan_sp_all_gather");
     return WAN_OK;
 }
@@ -199,7 +226,11 @@ extern "C" wan_status_t wan_sp_wait_for(wan_sp_comm* c, int64_t ticket, void* co
     WAN_REQUIRE(ticket >= 0 && ticket <= c->ticket, WAN_ERR_INVALID, "wan_sp_wait_for: ticket %lld of %lld started", (long long)ticket, (long long)c->ticket);
     if (ticket == 0) return WAN_OK;
     // an event slot recycled by later exchanges marks a LATER point of the in-order side stream: waiting on it is still correct
-    const int64_t t = ticket + wan_sp_comm::kRing <= c->ticket ? c->ticket : ticket;
+    int64_t t = ticket + wan_sp_comm::kRing <= c->ticket ? c->ticket : ticket;
+    // an exchange that ran inline on the caller's stream is already ordered; what may still need a join is the latest SIDE-stream
+    // exchange at or before it (only the ring's span is known: older ones than that were recycled, i.e. joined or superseded)
+    while (t > c->waited && t > c->ticket - wan_sp_comm::kRing && c->inline_slot[t % wan_sp_comm::kRing]) --t;
+    if (t <= c->waited || t <= c->ticket - wan_sp_comm::kRing || c->inline_slot[t % wan_sp_comm::kRing]) return WAN_OK;
     WAN_SP_HIP(hipStreamWaitEvent((hipStream_t)compute_stream, c->done[t % wan_sp_comm::kRing], 0), "wan_sp_wait_for");
     if (t > c->waited) c->waited = t;
     return WAN_OK;
@@ -213,6 +244,11 @@ extern "C" wan_status_t wan_sp_wait(wan_sp_comm* c, void* compute_stream) {
 
 extern "C" wan_status_t wan_sp_destroy(wan_sp_comm* c) {
     if (c == nullptr) return WAN_OK;
+    // A communicator whose collectives were recorded into hipGraphs: RCCL's teardown (ncclCommDestroy and ncclCommAbort alike,
+    // RCCL 2.26 / ROCm 7.0: profiles/r05/sp_graph_capture_inline.log) blocks for good while a graph that holds one of its kernels is
+    // alive, and the library cannot know whether the caller has dropped its graphs (GraphedForward.reset()).  Such a communicator is
+    // therefore LEFT ALONE -- its RCCL resources go with the process -- rather than risking a hang at interpreter exit.
+    if (c->captured) return WAN_OK;
     (void)hipStreamSynchronize(c->side);
     if (c->owns_comm && c->comm) (void)rccl().CommDestroy(c->comm);
     if (c->ready) (void)hipEventDestroy(c->ready);

@@ -31,12 +31,19 @@ __all__ = ["GraphedForward", "GraphedLoop"]
 
 
 def _check_capturable(model) -> None:
-    """Single device only.  Recording a sequence-parallel forward was tried in round 4 over the library-owned communicator (RCCL calls on
-    a side stream forked from and joined back into the capturing stream by events -- the fork / join pattern of stream capture): the
-    eager warm-up call is fine, `hipStreamEndCapture` then segfaults inside the runtime (ROCm 7.2, one rank, both capture-error modes;
-    profiles/r04/sp_graph_capture_rccl_segfault.log).  Until that is understood the collectives stay eager."""
+    """Single device, or a sequence-parallel model whose collectives run on the communicator the LIBRARY owns (``LibraryComm``).
+    Round 4 recorded an SP forward with the RCCL calls on a side stream forked from and joined back into the capturing stream by events
+    (the fork / join pattern of stream capture): the eager warm-up call was fine, `hipStreamEndCapture` then segfaulted inside the
+    runtime (ROCm 7.2, one rank, both capture-error modes; profiles/r04/sp_graph_capture_rccl_segfault.log).  Round 5: while the
+    caller's stream is being captured the library communicator enqueues every collective on THAT stream (csrc/sp_comm.cpp,
+    `sp_runs_inline`: no side stream, no events -- at P = 8 an exchange is < 1 % of a layer, so the overlap it gives up inside a
+    replayed graph is small), which is what this check admits.  torch.distributed's process group stays eager: its collectives run
+    on a stream of its own."""
     if model.sp_world_size != 1 or getattr(model, "force_ulysses", False):
-        raise NotImplementedError("graph capture covers the single-device forward (collectives stay eager)")
+        from .dist import LibraryComm
+        if not isinstance(getattr(model, "_sp", None), LibraryComm):
+            raise NotImplementedError("graph capture of a sequence-parallel forward needs the library-owned communicator "
+                                      "(init_sequence_parallel(backend=\"library\")); torch.distributed collectives stay eager")
 
 
 class _Entry:
