@@ -416,6 +416,13 @@ wan_status_t wan_dit_block_forward(float* x, const float* emod, const void* ctx_
                                    const wan_block_weights* w, const wan_block_workspace* ws,
                                    const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
                                    int batch, int64_t rows_per_batch, int64_t valid_tokens, void* stream);
+/* The token-local part of a block -- everything behind the self-attention output projection (wan_transformer3d.py:504-511:
+ * norm3, cross-attention over the text tokens, FFN) -- as one call: the tail of wan_dit_block_forward, and what a
+ * sequence-parallel host calls after its own self-attention part (it drives the exchanges itself; dist/wan_xfuser.py:68-111).
+ * Uses ws->h, att, cq, ff, attn_ws_cross, gemm_ws only (qk / vt may be NULL).  ABI 8. */
+wan_status_t wan_dit_block_tail_forward(float* x, const float* emod, const void* ctx_k, const void* ctx_vt,
+                                        const wan_block_weights* w, const wan_block_workspace* ws,
+                                        int batch, int64_t rows_per_batch, void* stream);
 wan_status_t wan_dit_block_workspace_bytes(int dim, int ffn_dim, int batch, int64_t rows_per_batch, int64_t valid_tokens,
                                            int64_t* bytes /* [6]: h, qk, att, cq, ff, vt */, int64_t* ldvt);
 

@@ -733,7 +733,7 @@ def test_persistent_gemm_row_permuted_epilogues_equal_the_round4_epilogues_bitwi
 
 
 @pytest.mark.parametrize("splits", [0, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(2304, 1536, 8960), (515, 196, 1024), (1000, 520, 2560)])
+@pytest.mark.parametrize("M,N,K", [(2304, 1536, 8960), (515, 196, 4096), (1000, 520, 6144)])
 def test_split_k_form_of_the_small_shape_gemm(M, N, K, splits):
     """wan_gemm_bf16_ws on shapes the 128^2 kernel takes and whose tiles do not fill the chip (BASELINE configs[0]: M = 2 304): the
     K range of every tile cut into pieces (by shape: splits = 0 here -> wan_gemm_ws_splits; or forced 2 / 3 / 4), fp32 pieces in the

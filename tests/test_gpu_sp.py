@@ -154,6 +154,10 @@ def _rccl_ws1_worker(port, q_out):
         one_group = m(lat, t, ctx, 420, **kw)
         assert torch.equal(one_group, sharded), "head-group pipelining changed the result"
         m.sp_head_groups = 2
+        m.use_block_composite = False                     # the token-local part of every layer op by op instead of wan_dit_block_tail_forward
+        per_op = m(lat, t, ctx, 420, **kw)
+        assert torch.equal(per_op, sharded), "the tail composite is not the per-op launch sequence"
+        m.use_block_composite = True
         m._comm_events = comm
         lat2 = det_uniform("sp.lat2", (2, 16, 7, 12, 20), 1.0).cuda()
         other = m(lat2, t, ctx, 420, **kw)                # other data through the same buffers ...

@@ -522,8 +522,10 @@ int main(int argc, char** argv) {
                 WAN(wan_gemm_bf16_ws(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi, g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, ws.p, wsb, nullptr));
                 HIP(hipDeviceSynchronize());
                 std::vector<int> h(1024); HIP(hipMemcpy(h.data(), ws.p, 4096, hipMemcpyDeviceToHost));
-                double a = 0, b = 0, c = 0; for (int w = 0; w < 128; ++w) { a += h[640 + 3 * w]; b += h[641 + 3 * w]; c += h[642 + 3 * w]; }
-                printf("  cycles[%-18s] segment start %.1f %%, K loop %.1f %%, epilogue + switch %.1f %%  (total %.0f x16 ticks per workgroup)\n", g.what, 100 * a / (a + b + c), 100 * b / (a + b + c), 100 * c / (a + b + c), (a + b + c) / 128);
+                double a = 0, b = 0, c = 0, d = 0, e = 0; for (int w = 0; w < 64; ++w) { a += h[640 + 5 * w]; b += h[641 + 5 * w]; c += h[642 + 5 * w]; d += h[643 + 5 * w]; e += h[644 + 5 * w]; }
+                const double tot = a + b + c + d + e;
+                printf("  cycles[%-18s] segment start %.1f %%, K loop %.1f %%, epilogue + switch %.1f %%, forced wait before the epilogue %.1f %%, forced drain after it %.1f %%  (total %.0f x16 ticks per workgroup; form mask %d)\n",
+                       g.what, 100 * a / tot, 100 * b / tot, 100 * c / tot, 100 * d / tot, 100 * e / tot, tot / 64, wan_get_tuning("gemm_pk_form"));
             }
             double best[2] = {1e30, 1e30};
             for (int round = 0; round < 5; ++round)
@@ -537,6 +539,42 @@ int main(int argc, char** argv) {
                    best[0], 2.0 * g.M * g.N * g.K / best[0] / 1e9, best[1], 2.0 * g.M * g.N * g.K / best[1] / 1e9, best[0] / best[1]);
             fflush(stdout);
             WAN(wan_set_tuning("gemm_pk_form", 31));
+        }
+    }
+    if (mode == "gemmcyc") {      // `make EXPERIMENTS=1` builds: where a persistent-GEMM workgroup's cycles go, per epilogue form, with the forced waits
+        if (wan_get_tuning("dev_experiments") != 1) { printf("gemmcyc needs a `make EXPERIMENTS=1` build\n"); return 2; }
+        const int L = 67080;
+        struct G { int M, N, K; int epi; const char* what; };
+        std::vector<G> gs = {{L, 10240, 5120, WAN_EPI_BF16, "qk proj"}, {L, 13824, 5120, WAN_EPI_GELU_BF16, "ffn.0+gelu"},
+                             {L, 5120, 5120, WAN_EPI_RESID_F32, "o proj+gate+resid"}, {L, 5120, 5120, WAN_EPI_BF16_T, "v proj (T)"},
+                             {L, 3072, 1536, WAN_EPI_BF16, "1.3B qk proj"}, {L, 8960, 1536, WAN_EPI_GELU_BF16, "1.3B ffn.0+gelu"}};
+        for (auto g : gs) {
+            auto hA = to_bf(randn((size_t)4096 * 64));
+            Dev<bf16> A((size_t)g.M * g.K), W((size_t)g.N * g.K);
+            for (size_t off = 0; off < A.n; off += hA.size()) HIP(hipMemcpy(A.p + off, hA.data(), std::min(hA.size(), A.n - off) * 2, hipMemcpyHostToDevice));
+            for (size_t off = 0; off < W.n; off += hA.size()) HIP(hipMemcpy(W.p + off, hA.data(), std::min(hA.size(), W.n - off) * 2, hipMemcpyHostToDevice));
+            Dev<float> bias(g.N), gate(g.N); bias.zero(); gate.zero();
+            const int64_t ldo = g.epi == WAN_EPI_BF16_T ? (g.M + 63) / 64 * 64 : g.N;
+            const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
+            Dev<char> out(osz); out.zero();
+            const int64_t wsb = wan_gemm_workspace_bytes(g.M, g.N, g.K);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            for (int form : {31})
+                for (int ex : {0, 4096, 0, 4096, 64 | 4096}) {
+                    WAN(wan_set_tuning("gemm_pk_form", form)); WAN(wan_set_tuning("gemm_exp", ex));
+                    auto run = [&] { WAN(wan_gemm_bf16_ws(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi, g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, ws.p, wsb, nullptr)); };
+                    const double ms = time_ms(run, 6, 2);
+                    printf("  %-18s form %2d exp %4d: %.3f ms %5.0f TF/s", g.what, form, ex, ms, 2.0 * g.M * g.N * g.K / ms / 1e9);
+                    if (ex & 64) {
+                        HIP(hipDeviceSynchronize());
+                        std::vector<int> h(1024); HIP(hipMemcpy(h.data(), ws.p, 4096, hipMemcpyDeviceToHost));
+                        double a = 0, b = 0, c = 0, d = 0, e = 0; for (int w = 0; w < 64; ++w) { a += h[640 + 5 * w]; b += h[641 + 5 * w]; c += h[642 + 5 * w]; d += h[643 + 5 * w]; e += h[644 + 5 * w]; }
+                        const double tot = a + b + c + d + e;
+                        printf("   start %.1f %% | K loop %.1f %% | epilogue+switch %.1f %% | wait before %.1f %% | drain after %.1f %%  (%.0f x16 ticks / workgroup)", 100 * a / tot, 100 * b / tot, 100 * c / tot, 100 * d / tot, 100 * e / tot, tot / 64);
+                    }
+                    printf("\n"); fflush(stdout);
+                }
+            WAN(wan_set_tuning("gemm_pk_form", 29)); WAN(wan_set_tuning("gemm_exp", 0));
         }
     }
     if (mode == "sp") {           // the library-owned communicator from a C host: one rank, a pattern through both collectives

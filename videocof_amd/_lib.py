@@ -105,6 +105,8 @@ SIGNATURES = {
     "wan_sp_unpack_heads_split": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_dit_block_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockWeights), POINTER(BlockWorkspace),
                                       c_void_p, c_void_p, POINTER(RopeParams), c_int, c_int64, c_int64, c_void_p]),
+    "wan_dit_block_tail_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockWeights), POINTER(BlockWorkspace),
+                                           c_int, c_int64, c_void_p]),
     "wan_dit_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                 POINTER(DitWeights), POINTER(DitWorkspace), c_void_p, c_void_p, POINTER(RopeParams),
                                 c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),

@@ -15,6 +15,10 @@ inline char* at(void* p, int64_t bytes) { return (char*)p + bytes; }
         if (st__ != WAN_OK) return st__; \
     } while (0)
 
+extern "C" wan_status_t wan_dit_block_tail_forward(float* x, const float* emod, const void* ctx_k, const void* ctx_vt,
+                                                   const wan_block_weights* w, const wan_block_workspace* ws,
+                                                   int batch, int64_t rows_per_batch, void* stream);
+
 extern "C" wan_status_t wan_dit_block_forward(float* x, const float* emod, const void* ctx_k, const void* ctx_vt,
                                               const wan_block_weights* w, const wan_block_workspace* ws,
                                               const float* rope_cos, const float* rope_sin, const wan_rope_params* rp,
@@ -40,7 +44,6 @@ extern "C" wan_status_t wan_dit_block_forward(float* x, const float* emod, const
     const float qs = (float)(0.08838834764831845 * 1.4426950408889634);   // 1/sqrt(128) * log2(e) (WAN_ATTN_QSCALE), folded into q by the norm kernel
     const int64_t bC = (int64_t)batch * C;                        // one modulation row block [B][C]
     const float* shift_msa = emod, *scale_msa = emod + bC, *gate_msa = emod + 2 * bC;
-    const float* shift_mlp = emod + 3 * bC, *scale_mlp = emod + 4 * bC, *gate_mlp = emod + 5 * bC;
     void* qk = ws->qk;
     void* kpart = at(qk, (int64_t)C * 2);                         // k columns of the fused q|k rows (bf16)
     wan_rope_params rope = *rp;
@@ -57,6 +60,32 @@ extern "C" wan_status_t wan_dit_block_forward(float* x, const float* emod, const
                               batch, (int)Ll, (int)valid_tokens, H, 128, 0.f, WAN_ATTN_Q_PRESCALED, ws->attn_ws_self,
                               ws->attn_ws_self_bytes, stream));
     WAN_TRY(wan_gemm_bf16_ws(ws->att, C, w->w_o, C, w->b_o, x, C, (int)M, C, C, WAN_EPI_RESID_F32, gate_msa, Ll, GWS, GWSB, stream));
+    // ---- cross-attention (:504) and FFN (:507-511): the token-local part of the block
+    return wan_dit_block_tail_forward(x, emod, ctx_k, ctx_vt, w, ws, batch, rows_per_batch, stream);
+}
+
+// The token-local two thirds of a WanAttentionBlock -- everything behind the self-attention's output projection
+// (videox_fun/models/wan_transformer3d.py:504-511: norm3 -> cross-attention over the text tokens -> FFN) -- as ONE C call.  The tail of
+// wan_dit_block_forward, and what a sequence-parallel host calls after its own self-attention part (whose exchanges it drives
+// itself): an Ulysses layer is then ~20 FFI crossings instead of ~30.  Needs ws->h, att, cq, ff, attn_ws_cross, gemm_ws only.
+extern "C" wan_status_t wan_dit_block_tail_forward(float* x, const float* emod, const void* ctx_k, const void* ctx_vt,
+                                                   const wan_block_weights* w, const wan_block_workspace* ws,
+                                                   int batch, int64_t rows_per_batch, void* stream) {
+    WAN_REQUIRE(x && emod && ctx_k && ctx_vt && w && ws, WAN_ERR_INVALID, "wan_dit_block_tail_forward: null argument");
+    WAN_REQUIRE(batch > 0 && rows_per_batch > 0, WAN_ERR_INVALID, "wan_dit_block_tail_forward: batch=%d rows_per_batch=%lld", batch,
+                (long long)rows_per_batch);
+    const int C = w->dim, F = w->ffn_dim, H = w->num_heads, T = w->text_len;
+    WAN_REQUIRE(C > 0 && H > 0 && C == H * 128 && F > 0 && T > 0, WAN_ERR_UNSUPPORTED,
+                "wan_dit_block_tail_forward: dim=%d heads=%d (head_dim must be 128) ffn=%d text_len=%d", C, H, F, T);
+    WAN_REQUIRE(ws->h && ws->att && ws->cq && ws->ff, WAN_ERR_INVALID, "wan_dit_block_tail_forward: null workspace");
+    void* const GWS = ws->gemm_ws;
+    const int64_t GWSB = ws->gemm_ws_bytes;
+    const int64_t Ll = rows_per_batch, M = (int64_t)batch * Ll;
+    WAN_REQUIRE(M <= 0x7fffffff, WAN_ERR_UNSUPPORTED, "wan_dit_block_tail_forward: too many rows");
+    const float eps = w->eps;
+    const float qs = (float)(0.08838834764831845 * 1.4426950408889634);
+    const int64_t bC = (int64_t)batch * C;
+    const float* shift_mlp = emod + 3 * bC, *scale_mlp = emod + 4 * bC, *gate_mlp = emod + 5 * bC;
     // ---- cross-attention over the text tokens (:504; rows are not masked, context_lens = None)
     WAN_TRY(wan_ln_modulate(x, w->norm3_w, w->norm3_b, 0, ws->h, M, C, M, eps, stream));
     WAN_TRY(wan_gemm_bf16_ws(ws->h, C, w->w_cq, C, w->b_cq, ws->cq, C, (int)M, C, C, WAN_EPI_BF16, nullptr, 0, GWS, GWSB, stream));

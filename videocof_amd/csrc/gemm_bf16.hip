@@ -348,9 +348,11 @@ static int wan_gemm_splitk(int M, int N, int K) {
     const int slots = 2 * wan_cu_count();
     const int nk = K / BK;
     if (const int f = wan_tune(WAN_TUNE_GEMM_SPLITK); f > 1) return (f <= 8 && nk >= 2 * f) ? f : 1;      // developer override
-    if (tiles * 4 > (int64_t)slots * 3 || nk < 16) return 1;                // >= 3/4 of a round already, or nothing to cut
+    if (tiles * 4 > (int64_t)slots * 3 || nk < 64) return 1;                // >= 3/4 of a round already, or nothing to cut
+    // measured at M = 2 304 (profiles/r05/gemm_yardstick_small_splitk.log): K = 8 960 in two pieces 0.105 -> 0.087 ms; K = 1 536 in two pieces
+    // 0.027 -> 0.033 ms -- the counter memset, the 64 KB round trip per piece and the second launch wave cost more than 12 K tiles
     int splits = (int)std::min<int64_t>(slots / tiles, 4);
-    while (splits > 1 && nk / splits < 8) --splits;                        // at least 8 K tiles per piece
+    while (splits > 1 && nk / splits < 32) --splits;                       // at least 32 K tiles per piece
     return splits < 2 ? 1 : splits;
 }
 static int64_t splitk_counter_bytes(int M, int N) {

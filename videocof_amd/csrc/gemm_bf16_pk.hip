@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 
 #if WAN_DEV_EXPERIMENTS
-    long long t_start = 0, t_loop = 0, t_epi = 0, t_mark = __builtin_readcyclecounter();
+    long long t_start = 0, t_loop = 0, t_epi = 0, t_wait = 0, t_drain = 0, t_mark = __builtin_readcyclecounter();
 #define GP_STAMP(ACC) do { if (g.exp & 64) { const long long n_ = __builtin_readcyclecounter(); ACC += n_ - t_mark; t_mark = n_; } } while (0)
 #else
 #define GP_STAMP(ACC) do { } while (0)
@@ -422,6 +422,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
 
 #if WAN_DEV_EXPERIMENTS
+        if (g.exp & 512) {      // TIMING ONLY: drain everything in flight (the next segment's first K tiles) before the epilogue starts -> t_wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GP_STAMP(t_wait);
+        }
         if ((g.exp & 32) == 0)
 #endif
         if (!cur.partial || reduce) {
@@ -489,7 +493,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                         const int m = mw + 16 * i + r;
                         if (m >= g.M) continue;
                         bf16_t* op = (bf16_t*)g.out + (int64_t)m * g.ldo + nb;
+#if WAN_DEV_EXPERIMENTS
+                        if (g.exp & 2048) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }      // TIMING ONLY: everything but the stores
+#endif
                         if (aligned && c1) {
+#if WAN_DEV_EXPERIMENTS
+                            if (g.exp & 4096) { __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(op)); continue; }      // A/B: streaming (nt) stores
+#endif
                             *reinterpret_cast<u32x4*>(op) = o;
                         } else {
                             if (c0) *reinterpret_cast<u32x2*>(op) = u32x2{o[0], o[1]};
@@ -791,6 +801,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
 
         GP_STAMP(t_epi);
+#if WAN_DEV_EXPERIMENTS
+        if (g.exp & 1024) {     // TIMING ONLY: wait for the epilogue's own stores (and loads) to complete -> t_drain
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GP_STAMP(t_drain);
+        }
+#endif
         // ---- advance the stream
         if (!nxt.valid) break;
         cur = nxt; pc = pn;
@@ -808,8 +824,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // zero-length requests past the last segment still write LDS: let them finish
 #if WAN_DEV_EXPERIMENTS
-    if ((g.exp & 64) && tid == 0 && blockIdx.x < 128) {          // counters words [640, 1024) are free
-        g.counters[640 + 3 * blockIdx.x] = (int)(t_start >> 4); g.counters[641 + 3 * blockIdx.x] = (int)(t_loop >> 4); g.counters[642 + 3 * blockIdx.x] = (int)(t_epi >> 4);
+    if ((g.exp & 64) && tid == 0 && blockIdx.x < 64) {          // counters words [640, 1024) are free
+        int* const o_ = g.counters + 640 + 5 * blockIdx.x;
+        o_[0] = (int)(t_start >> 4); o_[1] = (int)(t_loop >> 4); o_[2] = (int)(t_epi >> 4); o_[3] = (int)(t_wait >> 4); o_[4] = (int)(t_drain >> 4);
     }
 #endif
 #undef GP_STAMP

@@ -271,7 +271,8 @@ def gemm_workspace(dev: torch.device, M: int, N: int, K: int) -> Optional[torch.
     caller's side stream) can never meet in one buffer.  Launches recorded under stream capture share one per-device
     "capture" workspace (the capturing stream is a pool stream that differs from capture to capture; a graph bakes the
     address in and the entry stays alive with this table); like the model's activation buffers it is owned by the graphs
-    of that device, whose replays must not overlap each other.  The buffer is NOT cleared here -- the launch clears the
+    of that device, whose replays must not overlap each other; when a capture asks for more than the capture workspace holds, a new
+    buffer is allocated and the old one stays alive for the launches already recorded.  The buffer is NOT cleared here -- the launch clears the
     4 KiB of counters it uses with a memset node of its own.  None when the shape does not use a workspace
     (``wan_gemm_workspace_bytes`` == 0)."""
     need = int(_lib.load().wan_gemm_workspace_bytes(M, N, K))
@@ -282,12 +283,20 @@ def gemm_workspace(dev: torch.device, M: int, N: int, K: int) -> Optional[torch.
     key = (index, "capture" if capturing else int(torch.cuda.current_stream(index).cuda_stream))
     ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() < need:
-        if ws is not None and capturing:
-            # growing it would free memory an already captured graph of this device still writes to
-            raise RuntimeError("the GEMM workspace of captured graphs would have to grow during a capture; capture the largest shape first")
+        if capturing:
+            # a graph bakes addresses in: launches already recorded keep the buffer they were given (a workspace only has to live
+            # through its own launch), so a grown request gets a NEW buffer and the old one is kept alive for the recorded nodes.
+            # The first capture buffer of a device is sized like the largest eager workspace (the eager warm-up call of
+            # GraphedForward / GraphedLoop has run every shape), so this branch is normally taken once.
+            if ws is not None:
+                _GEMM_WS_RETIRED.append(ws)
+            need = max([need] + [t.numel() for (i, _), t in _GEMM_WS.items() if i == index])
         ws = torch.empty(need, device=torch.device("cuda", index), dtype=torch.uint8)
         _GEMM_WS[key] = ws
     return ws
+
+
+_GEMM_WS_RETIRED = []
 
 
 class AttentionWorkspace:

@@ -951,6 +951,19 @@ class WanTransformer3DModel(nn.Module):
             ops.gemm_fp8(bufs.attq, bufs.atts, *f8["o"], blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
         else:
             ops.gemm(o_in, blk.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
+        if usp and not f8 and self._attn_events is None and self.use_block_composite:
+            # the token-local two thirds of the layer (norm3 -> cross-attention -> FFN) as ONE C call (wan_dit_block_tail_forward):
+            # the same launches as below, bit for bit
+            from ._lib import check, load
+            import ctypes
+            self._block_cw(blk)
+            self._block_cws(bufs, bufs, B, Ll, L)
+            ck, cvt = ctx_kv
+            check(load().wan_dit_block_tail_forward(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(em.data_ptr()),
+                                                    ctypes.c_void_p(ck.data_ptr()), ctypes.c_void_p(cvt.data_ptr()),
+                                                    ctypes.byref(blk._cw), ctypes.byref(bufs.cws), B, Ll, ops._stream()),
+                  "wan_dit_block_tail_forward")
+            return
         # ---- cross attention (:504), text rows are NOT masked (context_lens=None, :936)
         if "cq" in f8:
             ops.ln_modulate_fp8(xs, blk.n3w, blk.n3b, False, M, self.eps, out=bufs.hq, out_scale=bufs.rs)
@@ -999,8 +1012,9 @@ class WanTransformer3DModel(nn.Module):
             H = self.num_heads
             bufs.nself = int(lib.wan_attention_workspace_bytes(B, Ll, L, H, 128))
             bufs.ncross = int(lib.wan_attention_workspace_bytes(B, Ll, self.text_len, H, 128))
-            holder.cws = BlockWorkspace(p(bufs.h), p(bufs.qk), p(bufs.att), p(bufs.cq), p(bufs.ff), p(bufs.vt), bufs.vt.stride(1),
-                                        None, bufs.nself, None, bufs.ncross, None, 0)
+            vt = getattr(bufs, "vt", None)                       # (None under Ulysses: the tail composite does not touch qk / vt)
+            holder.cws = BlockWorkspace(p(bufs.h), p(bufs.qk), p(bufs.att), p(bufs.cq), p(bufs.ff), p(vt) if vt is not None else None,
+                                        vt.stride(1) if vt is not None else 0, None, bufs.nself, None, bufs.ncross, None, 0)
         # the attention scratches belong to the call sites (AttentionWorkspace objects that may be re-allocated when another
         # shape asks for more): take their CURRENT addresses on every call, never a cached pointer
         holder.cws.attn_ws_self = self._ws_self.get(self._device, max(bufs.nself, 16)).data_ptr()
