@@ -123,6 +123,13 @@ def _worker(rank, world, port, L, H, q_out):
         y = torch.randn(B, Lp, 64)
         full = sp.all_gather_tokens(y[:, sl])
         assert torch.equal(full, y)
+        # --- the reduction the ranks agree their fp8 attention exponents with (round 5): every rank measures ITS heads, the
+        # element-wise maximum over the group is what a single device would have measured over all heads
+        torch.manual_seed(7)
+        per_head = torch.rand(H, 2) * 10                      # (max |q|, max |k - mean|) of every head, the same table on every rank
+        mine = per_head[rank * Hs:(rank + 1) * Hs].amax(dim=0)
+        agreed = sp.all_reduce_max(mine.clone())
+        assert torch.equal(agreed, per_head.amax(dim=0))
         q_out.put((rank, err, str(dev)))
     finally:
         dist.destroy_process_group()
