@@ -653,6 +653,21 @@ def test_unipc_12_step_trajectory_on_device(golden):
         assert rel_l2(cur.float(), g["traj"][11]) < tol
 
 
+def test_unipc_order_3_and_bh1_on_device(golden):
+    """solver_order 3 / solver_type bh1 on CUDA tensors (updates of up to five terms: four go through the fused wan_lincomb, the
+    five-term corrector through the fp32 torch chain) against the trajectories captured from the reference (fixture g7c)."""
+    g = golden("dit_g7c_unipc_orders")
+    for tag, order, st in (("o3_bh2", 3, "bh2"), ("o2_bh1", 2, "bh1")):
+        s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=order, solver_type=st)
+        s.set_timesteps(9, device=DEV, shift=5.0)
+        cur = torch.from_numpy(g["x"]).to(DEV)
+        for i, t in enumerate(s.timesteps):
+            cur = s.step(torch.from_numpy(g["v"][i]).to(DEV), t, cur, return_dict=False)[0]
+            if np.isfinite(g[f"traj_{tag}"][i]).all():          # (the reference's own last bh1 step is NaN: fm_solvers_unipc.py:473)
+                assert rel_l2(cur, g[f"traj_{tag}"][i]) < 5e-6, (tag, i)
+        assert torch.isfinite(cur).all()
+
+
 def test_merge_lora_in_place_on_the_loaded_model(golden, tmp_path):
     """merge_lora(pipeline, path, multiplier, ...) with the reference's signature (lora_utils.py:371), applied to the
     packed device weights: the merged weights equal fixture g12 (captured from the reference's merge_lora on the same

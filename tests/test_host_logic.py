@@ -175,10 +175,37 @@ def test_model_rejects_other_families():
         WanTransformer3DModel(dim=256, num_heads=4)     # head_dim 64
 
 
-def test_unipc_rejects_orders_it_does_not_build():
-    with pytest.raises(NotImplementedError, match="solver_order=3"):
-        FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=3)
-    FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=1)
+def test_unipc_orders_and_solver_types_beyond_the_clis(golden):
+    """solver_order 3 (the solved predictor coefficients and the five-term corrector, fm_solvers_unipc.py:443-445, 590-600) and
+    solver_type bh1 (:402-403) against 9-step trajectories captured from the reference scheduler (oracle/gen_golden_unipc_long.py);
+    order 1 and orders above 3 run too (same formulas); a solver type the reference does not know is refused like there (:42-43)."""
+    g = golden("dit_g7c_unipc_orders")
+    for tag, order, st in (("o3_bh2", 3, "bh2"), ("o2_bh1", 2, "bh1"), ("o3_bh1", 3, "bh1")):
+        s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=order, solver_type=st)
+        s.set_timesteps(9, device="cpu", shift=5.0)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g["timesteps"])
+        cur, orders = torch.from_numpy(g["x"]), []
+        for i, t in enumerate(s.timesteps):
+            cur = s.step(torch.from_numpy(g["v"][i]), t, cur, return_dict=False)[0]
+            orders.append(s.this_order)
+            if st == "bh1" and i == 8:
+                # the reference's own last bh1 step is NaN: with sigma_t = 0 it evaluates alpha_t * B_h * pred_res = 1 * (-inf) * 0
+                # (:473, B_h = hh = -inf); here the vanishing term is dropped, which is the limit sigma_t -> 0: the step returns m0
+                assert not np.isfinite(g[f"traj_{tag}"][i]).any() and torch.isfinite(cur).all()
+                continue
+            assert rel_l2(cur, g[f"traj_{tag}"][i]) < 5e-6, (tag, i)
+        assert orders == g[f"orders_{tag}"].tolist()
+    for order in (1, 4):
+        s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=order)
+        s.set_timesteps(6, device="cpu", shift=3.0)
+        cur = torch.from_numpy(g["x"])
+        for i, t in enumerate(s.timesteps):
+            cur = s.step(torch.from_numpy(g["v"][i]), t, cur, return_dict=False)[0]
+        assert torch.isfinite(cur).all()
+    with pytest.raises(NotImplementedError, match="not implemented"):
+        FlowUniPCMultistepScheduler(solver_type="dpm")
+    with pytest.raises(ValueError):
+        FlowUniPCMultistepScheduler(solver_order=0)
 
 
 def test_teacache_host_logic():

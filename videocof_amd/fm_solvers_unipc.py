@@ -4,12 +4,15 @@ Same contract as ``FlowUniPCMultistepScheduler`` of
 ``videox_fun/utils/fm_solvers_unipc.py`` (diffusers ``SchedulerMixin`` style):
 ``set_timesteps(n, device=, shift=)``, ``.timesteps`` (int64, truncated,
 :208-211), ``.sigmas``, ``.order``, ``step(model_output, timestep, sample,
-return_dict=False)[0]``, ``scale_model_input``.  Supported configuration is the one
-the VideoCoF entry points build (fast_infer.py:328-337): ``flow_prediction``,
-``predict_x0``, ``solver_type='bh2'``, ``solver_order`` 1 or 2 (every reference entry point builds 2;
-order 3 is rejected in the constructor), ``lower_order_final``.
+return_dict=False)[0]``, ``scale_model_input``.  Supported configuration: ``flow_prediction``,
+``predict_x0`` (what every VideoCoF entry point builds, fast_infer.py:328-337), ``solver_type`` ``'bh1'`` or ``'bh2'``
+(:402-407), ANY ``solver_order`` >= 1 (the reference's CLIs use 2; round 5 added the general form of :430-445 /
+:590-600 -- the rho coefficients of order p come from the p - 1 (predictor) / p (corrector) Vandermonde system),
+``lower_order_final``.  One deliberate difference: with ``bh1`` the reference's LAST step (sigma_t = 0) evaluates
+``alpha_t * B_h * pred_res`` = 1 * (-inf) * 0 = NaN (:473); here the vanishing term is dropped (the limit), so the step
+returns the x0 prediction as ``bh2`` does.
 
-Own formulation: every UniP / UniC update is a linear combination of at most four
+Own formulation: every UniP / UniC update is a linear combination of at most p + 2
 tensors, so the per-step scalar algebra (:378-470, :520-612) is done once in
 float64 on the host and each update is applied in one fused fp32 pass
 (``torch.add``-chains on the device, no host sync), instead of the reference's
@@ -50,16 +53,17 @@ class FlowUniPCMultistepScheduler:
                  steps_offset: int = 0, final_sigmas_type: Optional[str] = "zero"):
         if solver_type in ("midpoint", "heun", "logrho"):
             solver_type = "bh2"                                                  # :97-99
-        if solver_type != "bh2" or prediction_type != "flow_prediction" or not predict_x0:
-            raise NotImplementedError("only flow_prediction / predict_x0 / bh2 is built (fast_infer.py:328-337)")
-        if solver_order not in (1, 2):
-            raise NotImplementedError(f"solver_order={solver_order}: orders 1 and 2 are built (the reference's CLIs use 2, "
-                                      "fast_infer.py:328-337); order 3 needs a five-term update (:430-445, :590-600)")
+        if solver_type not in ("bh1", "bh2"):
+            raise NotImplementedError(f"{solver_type} is not implemented for {self.__class__}")   # :42-43
+        if prediction_type != "flow_prediction" or not predict_x0:
+            raise NotImplementedError("only flow_prediction / predict_x0 is built (fast_infer.py:328-337)")
+        if int(solver_order) < 1:
+            raise ValueError(f"solver_order={solver_order} must be >= 1")
         if use_dynamic_shifting or thresholding or solver_p is not None or final_sigmas_type != "zero":
             raise NotImplementedError("dynamic shifting / thresholding / solver_p / sigma_min are not on the VideoCoF path")
         self.config = type("Config", (), dict(
             num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type,
-            shift=shift, use_dynamic_shifting=False, thresholding=False, predict_x0=True, solver_type="bh2",
+            shift=shift, use_dynamic_shifting=False, thresholding=False, predict_x0=True, solver_type=solver_type,
             lower_order_final=lower_order_final, final_sigmas_type="zero"))()
         self.predict_x0 = True
         self.disable_corrector = list(disable_corrector)
@@ -110,59 +114,49 @@ class FlowUniPCMultistepScheduler:
         return sample
 
     # ------------------------------------------------------------------ scalar algebra (float64, host)
-    def _coeffs(self, i_t: int, i_s0: int, i_prev: Optional[int], order: int, corrector: bool):
-        """Return (a, b0, b_prev, b_new): x_t = a*x + b0*m0 + b_prev*m_prev + b_new*m_new
-        for a step from sigma[i_s0] to sigma[i_t] (m_prev at sigma[i_prev])."""
+    def _coeffs(self, i_t: int, i_s0: int, i_prevs: List[int], order: int, corrector: bool):
+        """Return (a, b0, b_prevs, b_new): x_t = a * x + b0 * m0 + sum_k b_prevs[k] * m_k + b_new * m_new for a step from
+        sigma[i_s0] to sigma[i_t]; m_k is the model output at sigma[i_prevs[k]] (order - 1 of them, nearest first).
+        multistep_uni_p_bh_update (:406-470) and multistep_uni_c_bh_update (:560-612) in one place."""
         s = self.sigmas.double()
         sigma_t, sigma_s0 = s[i_t].item(), s[i_s0].item()
         alpha_t = 1.0 - sigma_t
         h = _lam(sigma_t) - _lam(sigma_s0)
         hh = -h
         h_phi_1 = math.expm1(hh) if hh > -math.inf else -1.0
-        B_h = h_phi_1                                                             # bh2 (:407-408)
+        B_h = h_phi_1 if self.config.solver_type == "bh2" else hh                 # :402-407
         a = sigma_t / sigma_s0
         b0 = -alpha_t * h_phi_1
+        assert len(i_prevs) == order - 1
+        rks = [(_lam(s[i].item()) - _lam(sigma_s0)) / h for i in i_prevs]
         rhos: List[float] = []
-        rk = None
-        if order >= 2:
-            rk = (_lam(s[i_prev].item()) - _lam(sigma_s0)) / h
-        if not corrector:
-            if order == 2:
-                rhos = [0.5]                                                      # :437-438
-        else:
-            if order == 1:
-                rhos = [0.5]                                                      # :597-598
-            else:
-                rks = np.array([rk, 1.0])
-                R, bvec = [], []
-                h_phi_k = h_phi_1 / hh - 1.0
-                fact = 1
-                for i in range(1, order + 1):
-                    R.append(rks ** (i - 1))
-                    bvec.append(h_phi_k * fact / B_h)
-                    fact *= i + 1
-                    h_phi_k = h_phi_k / hh - 1.0 / fact
-                rhos = list(np.linalg.solve(np.stack(R), np.array(bvec)))          # :600
+        if (not corrector and order >= 3) or (corrector and order >= 2):
+            rk_all = np.array(rks + [1.0])
+            R, bvec = [], []
+            h_phi_k = h_phi_1 / hh - 1.0
+            fact = 1
+            for i in range(1, order + 1):
+                R.append(rk_all ** (i - 1))
+                bvec.append(h_phi_k * fact / B_h)
+                fact *= i + 1
+                h_phi_k = h_phi_k / hh - 1.0 / fact
+            R, bvec = np.stack(R), np.array(bvec)
+            rhos = list(np.linalg.solve(R, bvec) if corrector else np.linalg.solve(R[:-1, :-1], bvec[:-1]))     # :600 / :443-445
+        elif not corrector and order == 2:
+            rhos = [0.5]                                                          # :437-438
+        elif corrector and order == 1:
+            rhos = [0.5]                                                          # :597-598
         k = -alpha_t * B_h
-        b_prev = b_new = 0.0
-        if not corrector:
-            if order == 2:
-                b_prev = k * rhos[0] / rk
-                b0 -= b_prev
-        else:
-            if order == 1:
-                b_new = k * rhos[0]
-                b0 -= b_new
-            else:
-                b_prev = k * rhos[0] / rk
-                b_new = k * rhos[1]
-                b0 -= b_prev + b_new
-        return a, b0, b_prev, b_new
+        b_prevs = [k * rhos[j] / rks[j] for j in range(order - 1)]                # D1s[j] = (m_j - m0) / rk_j
+        b_new = k * rhos[-1] if corrector else 0.0                                # D1_t = model_t - m0
+        b0 -= sum(b_prevs) + b_new
+        return a, b0, b_prevs, b_new
 
     @staticmethod
     def _combine(dtype, terms: List[Tuple[float, Optional[torch.Tensor]]]) -> torch.Tensor:
         live = [(c, t) for c, t in terms if t is not None and c != 0.0]
-        if live and live[0][1].is_cuda and dtype in (torch.float32, torch.bfloat16) and math.isfinite(sum(c for c, _ in live)):
+        # (the fused kernel takes up to four terms -- everything orders 1 and 2 produce; higher orders take the torch chain below)
+        if live and len(live) <= 4 and live[0][1].is_cuda and dtype in (torch.float32, torch.bfloat16) and math.isfinite(sum(c for c, _ in live)):
             from . import ops                      # fused single-pass HIP kernel (wan_lincomb)
             return ops.lincomb(live, dtype)
         acc = None
@@ -189,9 +183,10 @@ class FlowUniPCMultistepScheduler:
         x0 = self._combine(sample.dtype, [(1.0, sample), (-sig_i, model_output)])      # convert_model_output :318-320
         use_corrector = i > 0 and (i - 1) not in self.disable_corrector and self.last_sample is not None
         if use_corrector:
-            a, b0, bp, bn = self._coeffs(i, i - 1, i - 2 if self.this_order >= 2 else None, self.this_order, True)
-            sample = self._combine(sample.dtype, [(a, self.last_sample), (b0, self.model_outputs[-1]),
-                                                  (bp, self.model_outputs[-2]), (bn, x0)])
+            p = self.this_order
+            a, b0, bps, bn = self._coeffs(i, i - 1, [i - 1 - k for k in range(1, p)], p, True)
+            sample = self._combine(sample.dtype, [(a, self.last_sample), (b0, self.model_outputs[-1])] +
+                                   [(bps[k - 1], self.model_outputs[-(k + 1)]) for k in range(1, p)] + [(bn, x0)])
         self.model_outputs = self.model_outputs[1:] + [x0]
         self.timestep_list = self.timestep_list[1:] + [timestep]
         if self.config.lower_order_final:
@@ -201,9 +196,10 @@ class FlowUniPCMultistepScheduler:
         self.this_order = min(this_order, self.lower_order_nums + 1)                               # :720
         assert self.this_order > 0
         self.last_sample = sample
-        a, b0, bp, _ = self._coeffs(i + 1, i, i - 1 if self.this_order >= 2 else None, self.this_order, False)
-        prev_sample = self._combine(sample.dtype, [(a, sample), (b0, x0),
-                                                   (bp, self.model_outputs[-2] if self.this_order >= 2 else None)])
+        p = self.this_order
+        a, b0, bps, _ = self._coeffs(i + 1, i, [i - k for k in range(1, p)], p, False)
+        prev_sample = self._combine(sample.dtype, [(a, sample), (b0, x0)] +
+                                    [(bps[k - 1], self.model_outputs[-(k + 1)]) for k in range(1, p)])
         if self.lower_order_nums < self.config.solver_order:
             self.lower_order_nums += 1
         self._step_index += 1
