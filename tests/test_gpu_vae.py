@@ -244,10 +244,12 @@ def test_full_resolution_resample_convs_vs_torch_fp32(vae, vae_sd):
     (64, 192, 2, 21, 70, 2, False),      # two output-channel slices
     (96, 384, 1, 9, 33, 2, True),
 ])
-def test_lds_patch_conv_vs_torch_and_vs_gather_kernel(cin, cout, T, H, W, nh, resid):
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_lds_patch_conv_vs_torch_and_vs_gather_kernel(cin, cout, T, H, W, nh, resid, mfma):
     """The LDS-patch kernel of the causal 3x3x3 / stride-1 convolution (conv3_patch_kernel), forced on shapes smaller than
     its dispatch threshold: against torch's fp32 conv3d on the same bf16 inputs (<= 4e-3, bf16 output rounding) and against the
-    implicit-GEMM gather kernel (same arithmetic, another summation order)."""
+    implicit-GEMM gather kernel (same arithmetic, another summation order).  mfma = 16: the same loop on v_mfma_f32_16x16x32_bf16
+    (conv_mfma = 16, the round-5 A/B partner of the product's 32x32x16 form)."""
     g = torch.Generator(device=DEV).manual_seed(cin + cout + H)
     x = torch.randn(T, H, W, cin, device=DEV, generator=g).bfloat16()
     hist = torch.randn(nh, H, W, cin, device=DEV, generator=g).bfloat16() if nh else None
@@ -261,12 +263,14 @@ def test_lds_patch_conv_vs_torch_and_vs_gather_kernel(cin, cout, T, H, W, nh, re
     old = ops.get_tuning("conv_patch")
     try:
         ops.set_tuning("conv_patch", 2)
+        ops.set_tuning("conv_mfma", mfma)
         got = run()
         assert torch.equal(run(), got)          # persistent workgroups, fixed tile walk: bitwise reproducible
         ops.set_tuning("conv_patch", 0)
         gather = run()
     finally:
         ops.set_tuning("conv_patch", old)
+        ops.set_tuning("conv_mfma", 0)
     frames = torch.cat([torch.zeros(2 - nh, H, W, cin, device=DEV, dtype=torch.bfloat16)] + ([hist] if nh else []) + [x])
     ref = torch.nn.functional.conv3d(frames.float().permute(3, 0, 1, 2)[None], wt.float(), b, padding=(0, 1, 1))[0].permute(1, 2, 3, 0)
     if resid:

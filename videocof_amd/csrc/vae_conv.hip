@@ -360,7 +360,16 @@ constexpr int kPatchBytes = 1024 * 64;
 constexpr int kWSlice = 96 * 64, kWRing = 5;
 constexpr int kPatchLds = 2 * kPatchBytes + kWRing * kWSlice + 2048;       // all 163 840 B (2 KiB: the dummy DMA target)
 
+// MI = 32: v_mfma_f32_32x32x16_bf16, wave tile 2 x 3 tiles (rounds 2-4; still what under-filled launches run).  MI = 16 (round 5): the same
+// loop on v_mfma_f32_16x16x32_bf16 -- wave tile 4 pixel groups x 6 channel groups, ONE MFMA of K = 32 per (group, group) and tap, the
+// same ten fragment reads per step (one per two MFMAs), the same LDS images (a lane reads chunk lane >> 4 of pixel / channel row lane & 15).
+// The bare instruction sustains 2.0 PF/s at the power limit where 32x32x16 sustains 1.6-1.78 (tools/probe/mfma_power.hip); whether
+// THIS loop -- one barrier per 384 MFMA cycles -- can use that was measured: the clock rises by 12 %, the
+// matrix-pipe occupancy falls from 57 to 52 % (24 issue slots of 16 cycles carry the step's ~45 other instructions worse than 12 of
+// 32), net +0.4 ... +3.4 % on the full launches.
+template <int MI>
 __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
+    static_assert(MI == 32 || MI == 16, "32x32x16 or 16x16x32");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wring = smem + 2 * kPatchBytes;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -461,6 +470,19 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
         const int px = pb[i] + shift;
         return (px << 6) | (((hi1 ^ (px >> 2)) & 3) << 4);
     };
+    // MI == 16: lane -> (row l15 of a 16-row group, 16-byte chunk kg of its 64-byte record); pixel group gq = 16 columns of row gq >> 1
+    const int l15 = lane & 15, kg = lane >> 4;
+    // (the second group of a row is 16 pixels = 1024 bytes further with the SAME swizzle: (px + 16) >> 2 = (px >> 2) + 4 -- one address per row)
+    int pb16[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pb16[i] = (2 * wid + i) * PP_W + l15;
+    const int woff16 = (l15 << 6) | (((kg ^ (l15 >> 2)) & 3) << 4);          // channel group jj adds jj * 1024
+    f32x4 acc16[4][6];
+    bf16x8 af16[2][4], wf16[2][6];            // [set][group]
+    auto a_addr16 = [&](int i, int shift) {                 // row i of the wave, pixel group 0; group 1 of the row: + 1024
+        const int px = pb16[i] + shift;
+        return (px << 6) | (((kg ^ (px >> 2)) & 3) << 4);
+    };
     TileDesc cur = describe(tile);
     WPtr wcur = wptr(cur.n0);
     {
@@ -473,16 +495,23 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (MI == 32) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int a0 = a_addr(i, 0);
-            af[0][i][0] = *reinterpret_cast<const bf16x8*>(smem + a0);
-            af[0][i][1] = *reinterpret_cast<const bf16x8*>(smem + (a0 ^ 32));
-        }
+            for (int i = 0; i < 2; ++i) {
+                const int a0 = a_addr(i, 0);
+                af[0][i][0] = *reinterpret_cast<const bf16x8*>(smem + a0);
+                af[0][i][1] = *reinterpret_cast<const bf16x8*>(smem + (a0 ^ 32));
+            }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            wf[0][j][0] = *reinterpret_cast<const bf16x8*>(wring + woff0 + j * 2048);
-            wf[0][j][1] = *reinterpret_cast<const bf16x8*>(wring + (woff0 ^ 32) + j * 2048);
+            for (int j = 0; j < 3; ++j) {
+                wf[0][j][0] = *reinterpret_cast<const bf16x8*>(wring + woff0 + j * 2048);
+                wf[0][j][1] = *reinterpret_cast<const bf16x8*>(wring + (woff0 ^ 32) + j * 2048);
+            }
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) af16[0][gq] = *reinterpret_cast<const bf16x8*>(smem + a_addr16(gq >> 1, 0) + (gq & 1) * 1024);
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) wf16[0][jj] = *reinterpret_cast<const bf16x8*>(wring + woff16 + jj * 1024);
         }
     }
     int slot_use = 0;          // ring slot of the current step's slice; the slice issued now goes 4 slots further
@@ -506,16 +535,33 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
                 const int tnext = s == 26 ? 0 : s + 1;
                 const int shift = (tnext / 9) * PP_FR + ((tnext / 3) % 3) * PP_W + (tnext % 3);
                 const char* wb = wring + slot_next * kWSlice;
-                const int an[2] = {a_addr(0, shift), a_addr(1, shift)};
+                if constexpr (MI == 32) {
+                    const int an[2] = {a_addr(0, shift), a_addr(1, shift)};
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    const int ks = k / 6, i = (k % 6) / 3, j = k % 3;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cs][j][ks], af[cs][i][ks], acc[i][j], 0, 0, 0);
-                    if (k < 10) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (k < 4) af[nx][k >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(pnext + (an[k >> 1] ^ ((k & 1) << 5)));
-                        else wf[nx][(k - 4) >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(wb + ((woff0 ^ ((k & 1) << 5)) + ((k - 4) >> 1) * 2048));
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < 12; ++k) {
+                        const int ks = k / 6, i = (k % 6) / 3, j = k % 3;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cs][j][ks], af[cs][i][ks], acc[i][j], 0, 0, 0);
+                        if (k < 10) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (k < 4) af[nx][k >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(pnext + (an[k >> 1] ^ ((k & 1) << 5)));
+                            else wf[nx][(k - 4) >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(wb + ((woff0 ^ ((k & 1) << 5)) + ((k - 4) >> 1) * 2048));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+                    // 24 MFMAs of 16 cycles; the next step's ten fragments one per TWO MFMAs (the same reads per matrix-pipe cycle)
+                    const int an16[2] = {a_addr16(0, shift), a_addr16(1, shift)};
+#pragma unroll
+                    for (int k = 0; k < 24; ++k) {
+                        const int gq = k / 6, jj = k % 6;
+                        acc16[gq][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf16[cs][jj], af16[cs][gq], acc16[gq][jj], 0, 0, 0);
+                        if (k < 20 && (k & 1) == 0) {
+                            const int f = k >> 1;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (f < 4) af16[nx][f] = *reinterpret_cast<const bf16x8*>(pnext + an16[f >> 1] + (f & 1) * 1024);
+                            else wf16[nx][f - 4] = *reinterpret_cast<const bf16x8*>(wb + woff16 + (f - 4) * 1024);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
@@ -542,20 +588,34 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
             slot_use = slot_next;
         }
         // 27 steps per chunk: the set prefetched by the last step is set 1, the next chunk starts on set 0
+        if constexpr (MI == 32) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { af[0][i][0] = af[1][i][0]; af[0][i][1] = af[1][i][1]; }
+            for (int i = 0; i < 2; ++i) { af[0][i][0] = af[1][i][0]; af[0][i][1] = af[1][i][1]; }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { wf[0][j][0] = wf[1][j][0]; wf[0][j][1] = wf[1][j][1]; }
+            for (int j = 0; j < 3; ++j) { wf[0][j][0] = wf[1][j][0]; wf[0][j][1] = wf[1][j][1]; }
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) af16[0][gq] = af16[1][gq];
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) wf16[0][jj] = wf16[1][jj];
+        }
         ++gc;
     };
 
     for (; tile < tile_end; tile += tile_step) {
+        if constexpr (MI == 32) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) acc16[gq][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         for (int c = 0; c + 1 < nch; ++c) run_chunk(wcur, c, cur, wcur, c + 1);
         // the last chunk prefetches this workgroup's next tile (past the end: an all-invalid patch -- zero-page reads -- and this
         // tile's slices again, into ring slots nobody reads any more)
@@ -581,12 +641,21 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
                 constexpr bool HAS_BIAS = decltype(has_bias)::value, HAS_RESID = decltype(has_resid)::value;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    if constexpr (MI == 32) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
+                        for (int j = 0; j < 3; ++j)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<f32x4*>(stg + m32 * kStgPx + (j * 32 + q * 8 + hi1 * 4) * 4) =
-                                f32x4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                            for (int q = 0; q < 4; ++q)
+                                *reinterpret_cast<f32x4*>(stg + m32 * kStgPx + (j * 32 + q * 8 + hi1 * 4) * 4) =
+                                    f32x4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                    } else {
+                        // D = mfma(weights, pixels): lane (l15, kg) holds channels 16 jj + 4 kg .. + 3 of pixel l15 of its group
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                            for (int jj = 0; jj < 6; ++jj)
+                                *reinterpret_cast<f32x4*>(stg + (gg * 16 + l15) * kStgPx + (jj * 16 + kg * 4) * 4) = acc16[2 * i + gg][jj];
+                    }
                     const int h = cur.h0 + 2 * wid + i;
                     const int64_t orow0 = ((int64_t)cur.t0 * g.H_out + h) * g.W_out + cur.w0;
                     f32x4 lo[6], hi[6];
@@ -643,8 +712,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3_patch_kernel(ConvArgs g) {
 wan_status_t launch_conv3_patch(ConvArgs g, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel<32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds);
         if (e != hipSuccess) {
             wan_set_error("wan_conv_cl: cannot reserve %d B of LDS: %s", kPatchLds, hipGetErrorString(e));
             return WAN_ERR_LAUNCH;
@@ -665,7 +736,13 @@ wan_status_t launch_conv3_patch(ConvArgs g, hipStream_t s) {
         cus[dev].store(ncu, std::memory_order_relaxed);
     }
     const int64_t nwg = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL(conv3_patch_kernel, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
+    // conv_mfma: 0 (default) = by shape -- the 16x16x32 form when the launch fills the chip (>= one tile per CU: +0.4 ... +3.4 % on the
+    // decoder / encoder stages at 480p, sustained clock 1.58 -> 1.78 GHz at 57 -> 52 % matrix-pipe occupancy), the 32x32x16 form
+    // for under-filled launches (one latent frame: 128 tiles, where the 16x16x32 form is 7 % slower); 32 / 16 force one
+    // (profiles/r05/vae_conv_mfma16_ab.log)
+    const int mi = wan_tune(WAN_TUNE_CONV_MFMA);
+    if (mi == 16 || (mi == 0 && ntiles >= ncu)) hipLaunchKernelGGL(conv3_patch_kernel<16>, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
+    else hipLaunchKernelGGL(conv3_patch_kernel<32>, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
     WAN_CHECK_LAUNCH("wan_conv_cl");
     return WAN_OK;
 }
