@@ -153,6 +153,23 @@ def test_decode_chunking_is_bit_identical(vae):
     assert rel_l2(outs[4][0], orc.decode(z[0].cpu())) < 3e-2
 
 
+def test_decode_chunking_is_bit_identical_at_480p(vae):
+    """The same property at the production plane (60 x 104 latents -> 480 x 832): here the convolution launcher picks its MFMA
+    form by shape, and the rule may only look at the per-frame plane -- a rule on the launch's tile count would run the 1-frame
+    launches on 32x32x16 and the 2-frame launches on 16x16x32 MFMAs, which differ in the last bit."""
+    z = det_uniform("vae.chunk480.z", (1, 16, 3, 60, 104), 1.5).to(DEV)
+    outs = {}
+    old = vae.decode_chunk
+    try:
+        for n in (1, 2):
+            vae.decode_chunk = n
+            outs[n] = vae.decode(z).sample
+    finally:
+        vae.decode_chunk = old
+    assert outs[1].shape == (1, 3, 9, 480, 832)
+    assert torch.equal(outs[2], outs[1])
+
+
 def test_vae_vs_oracle_other_shape(vae):
     """Non-square, T = 5 (chunks 1,4): HIP encode->mode vs oracle, then HIP decode vs oracle."""
     orc = WanVAEOracle(deterministic_vae_state_dict())

@@ -1,5 +1,6 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." || exit 1
-o=gpurun_out/r5n; mkdir -p $o
-timeout 900 python -m pytest tests/test_gpu_vae.py -q > $o/pytest_vae.log 2>&1; echo "pytest vae rc=$?"; tail -3 $o/pytest_vae.log
-for mi in 0 32 0 32; do WAN_CONV_MFMA=$mi timeout 300 python tools/bench_vae.py --iters 2 2>/dev/null | grep workload | cut -c60-260; done
+# Round 5, call N: VAE suite with the frame-count-independent MFMA form rule + VAE bench line
+set -x
+mkdir -p gpurun_out/r05n
+timeout 900 python -m pytest tests/test_gpu_vae.py -q -m gpu -x 2>&1 | tail -5 | tee gpurun_out/r05n/pytest_vae.log
+timeout 600 python tools/bench_vae.py 2>&1 | tail -12 | tee gpurun_out/r05n/bench_vae.log

@@ -736,12 +736,15 @@ wan_status_t launch_conv3_patch(ConvArgs g, hipStream_t s) {
         cus[dev].store(ncu, std::memory_order_relaxed);
     }
     const int64_t nwg = ntiles < ncu ? ntiles : ncu;
-    // conv_mfma: 0 (default) = by shape -- the 16x16x32 form when the launch fills the chip (>= one tile per CU: +0.4 ... +3.4 % on the
-    // decoder / encoder stages at 480p, sustained clock 1.58 -> 1.78 GHz at 57 -> 52 % matrix-pipe occupancy), the 32x32x16 form
-    // for under-filled launches (one latent frame: 128 tiles, where the 16x16x32 form is 7 % slower); 32 / 16 force one
-    // (profiles/r05/vae_conv_mfma16_ab.log)
+    // conv_mfma: 0 (default) = by the PER-FRAME shape -- the 16x16x32 form when a chunk of four frames fills the chip (>= one tile
+    // per CU: +0.4 ... +3.4 % on the decoder / encoder stages at 480p, sustained clock 1.58 -> 1.78 GHz at 57 -> 52 % matrix-pipe
+    // occupancy), the 32x32x16 form for small planes; 32 / 16 force one (profiles/r05/vae_conv_mfma16_ab.log).  The rule must
+    // not look at T_out: the two forms add the 32 channels of a tap in different groupings, so they differ in the last bf16 bit,
+    // and a decode in chunks of 1, 2, 4 ... frames has to give the same bits (wan_vae.py decode(); the one-latent-frame launch of
+    // a 60 x 104 plane pays 7 % for that, 0.082 -> 0.088 ms)
     const int mi = wan_tune(WAN_TUNE_CONV_MFMA);
-    if (mi == 16 || (mi == 0 && ntiles >= ncu)) hipLaunchKernelGGL(conv3_patch_kernel<16>, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
+    const int64_t tiles_frame = (int64_t)g.pth * g.ptw * g.tiles_n;
+    if (mi == 16 || (mi == 0 && tiles_frame * 4 >= ncu)) hipLaunchKernelGGL(conv3_patch_kernel<16>, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
     else hipLaunchKernelGGL(conv3_patch_kernel<32>, dim3((unsigned)nwg), dim3(kThreads), kPatchLds, s, g);
     WAN_CHECK_LAUNCH("wan_conv_cl");
     return WAN_OK;
