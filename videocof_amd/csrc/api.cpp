@@ -71,7 +71,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"row_group", "WAN_ROW_GROUP", 2},                  // LN-modulate / RMSNorm+RoPE: token rows per workgroup (2 or 4: per-column parameters fetched once per group; 1 = the one-row kernels)
     {"sp_inline", "WAN_SP_INLINE", 0},                  // library communicator: 1 = every collective on the caller's stream itself (no side stream); 0 = only while that stream is being captured
     {"gemm_splitk", "WAN_GEMM_SPLITK", 1},              // split-K form of the 128^2 GEMM for small shapes that bring a workspace: 1 = by shape, 0 = never, 2..8 = force that many pieces (developer A/B)
-    {"conv_mfma", "WAN_CONV_MFMA", 0},                  // matrix instruction of the VAE's LDS-patch convolution: 0 = by shape (16x16x32 when the launch fills the chip), 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16
+    {"conv_mfma", "WAN_CONV_MFMA", 0},                  // matrix instruction of the VAE's LDS-patch convolution: 0 = by the per-frame plane (16x16x32 when four frames of it fill the chip; never by frame count -- chunked decodes stay bit-identical), 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];
