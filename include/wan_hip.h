@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 8      /* 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
+#define WAN_ABI_VERSION 9      /* 9: wan_attention_fwd_varlen (ragged batches in one launch); 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -212,6 +212,22 @@ wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_bstride,
                                int batch, int Lq, int Lk, int num_heads, int head_dim,
                                float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
                                void* stream);
+/* The same product over a RAGGED batch in one launch: batch b attends keys [0, k_lens[b]) of its k / vt.
+ *     replaces: the cu_seqlens packing of flash_attention() (attention_utils.py:95-146: k of every sample cut to k_lens[b],
+ *               concatenated, one flash_attn_varlen_func call) -- here the samples stay where they are ([B][Lk][..], Lk = the
+ *               padded length) and every workgroup reads ITS sample's key count: no packing copy, no host read of k_lens.
+ *     k_lens  int32 [B] in DEVICE memory, read by the kernel (values are clamped to [1, Lk]; a caller that wants the
+ *             reference's all-zero rows for an EMPTY sample zeroes them afterwards, as videocof_amd/attention_utils.py does)
+ *     vt      columns [k_lens[b], roundup(k_lens[b], 64)) of sample b must be finite (zeros) -- the same contract per sample
+ *     Everything else as wan_attention_fwd; the split-KV tail round is not used (it divides ONE key count), the max-free
+ *     attempt and the XCD pinning are. */
+wan_status_t wan_attention_fwd_varlen(const void* q, int64_t ldq, int64_t q_bstride,
+                                      const void* k, int64_t ldk, int64_t k_bstride,
+                                      const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                      void* out, int64_t ldo, int64_t o_bstride,
+                                      int batch, int Lq, int Lk, const int32_t* k_lens, int num_heads, int head_dim,
+                                      float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
+                                      void* stream);
 /* Optional scratch for wan_attention_fwd (16-byte aligned device memory whose first 16 bytes are ZERO when it is first used,
  * otherwise of irrelevant content; reusable across calls on one stream).  Header words (int32): [0] sticky "max-free attempt
  * off", [1] workgroups redone by the last call, [2] repair events of the lazy softmax reference since the caller last cleared

@@ -217,6 +217,54 @@ def test_attention_k_lens_masks_keys_and_q_lens_zero_rows():
     assert out32.dtype == torch.float32 and rel_l2(out32, _attn_ref(q, k, v)) < 6e-3
 
 
+def test_attention_ragged_batch_runs_as_one_launch():
+    """flash_attention() with ragged k_lens (attention_utils.py:95-146 packs the samples behind cu_seqlens): here ONE
+    wan_attention_fwd_varlen launch whose workgroups read their sample's key count from device memory.  Same bits as one call per
+    sample on the cut tensors; NaN in the padding of k and v never enters; a sample without keys gives zero rows."""
+    g = torch.Generator().manual_seed(5)
+    B, Lq, Lk, H = 3, 300, 1500, 2
+    kl = [1500, 777, 64]
+    q = bf(torch.randn(B, Lq, H, 128, generator=g))
+    k = bf(torch.randn(B, Lk, H, 128, generator=g))
+    v = bf(torch.randn(B, Lk, H, 128, generator=g) + torch.arange(128) * 0.01)
+    kp, vp = k.clone(), v.clone()
+    for b in range(B):
+        kp[b, kl[b]:] = float("nan")
+        vp[b, kl[b]:] = float("nan")
+    out = attention(q.to(DEV), kp.to(DEV), vp.to(DEV), k_lens=torch.tensor(kl, device=DEV))        # lengths stay on the device
+    assert ops.get_tuning("last_attn_variant") & _lib.ATTN_VARIANT_SPLIT_TAIL == 0
+    assert torch.isfinite(out.float()).all()
+    for b in range(B):
+        one = attention(q[b:b + 1].to(DEV), k[b:b + 1, :kl[b]].to(DEV), v[b:b + 1, :kl[b]].to(DEV))
+        assert torch.equal(out[b:b + 1], one), b
+        assert rel_l2(out[b:b + 1], _attn_ref(q[b:b + 1], k[b:b + 1], v[b:b + 1], kl[b])) < 6e-3
+    out_l = attention(q.to(DEV), kp.to(DEV), vp.to(DEV), k_lens=kl, q_lens=[300, 10, 300])           # host list: same launch
+    assert torch.equal(out_l[0], out[0]) and torch.equal(out_l[2], out[2]) and torch.equal(out_l[1, :10], out[1, :10])
+    assert float(out_l[1, 10:].abs().max()) == 0.0
+    out0 = attention(q[:2].to(DEV), kp[:2].to(DEV), vp[:2].to(DEV), k_lens=torch.tensor([777, 0], device=DEV))
+    assert float(out0[1].abs().max()) == 0.0
+    assert rel_l2(out0[:1], _attn_ref(q[:1], k[:1], v[:1], 777)) < 6e-3
+
+
+def test_attention_ragged_batch_long_launch_skips_the_split_tail():
+    """A shape whose uniform launch takes the split-KV tail round (5 heads x 53 query blocks = 265 workgroups on 256 CUs): the
+    ragged form walks the per-sample key count in every workgroup instead, and agrees with the uniform call within tolerance."""
+    g = torch.Generator().manual_seed(6)
+    L, H, kv = 13568, 5, 10000
+    q = bf(torch.randn(1, L, H * 128, generator=g)).to(DEV)
+    k = bf(torch.randn(1, L, H * 128, generator=g)).to(DEV)
+    v = bf(torch.randn(1, L, H * 128, generator=g)).to(DEV)
+    vt = torch.stack([ops.transpose_pad(v[0, :kv], ops.round_up(L, 64))])
+    uni = ops.attention_fwd(q, k, vt, H, k_len=kv)
+    tail = ops.get_tuning("last_attn_variant") & _lib.ATTN_VARIANT_SPLIT_TAIL
+    rag = ops.attention_fwd(q, k, vt, H, k_lens=torch.tensor([kv], device=DEV, dtype=torch.int32))
+    assert ops.get_tuning("last_attn_variant") & _lib.ATTN_VARIANT_SPLIT_TAIL == 0
+    assert tail != 0, "the uniform launch of this shape is expected to take the tail round (256-CU part)"
+    assert rel_l2(rag, uni) < 2e-3
+    with pytest.raises(ValueError):
+        ops.attention_fwd(q, k, vt, H, k_lens=torch.tensor([kv, kv], device=DEV, dtype=torch.int32))
+
+
 def test_attention_online_softmax_rescale_branch():
     """A key tile whose scores jump far above the running max forces the rescale path
     (guide rule 26): spike one key against every query late in the sequence."""

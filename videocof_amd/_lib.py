@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
@@ -119,6 +119,9 @@ SIGNATURES = {
     "wan_attention_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_attention_fwd_varlen": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                         c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
     "wan_attention_fwd_qk8": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int,
                                       c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                       c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),

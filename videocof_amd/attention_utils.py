@@ -25,7 +25,9 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
 
     Semantics of the flash-attn branch (attention_utils.py:85-149): inputs that
     are not half precision are cast to ``dtype``; keys beyond ``k_lens`` are not
-    attended; query rows beyond ``q_lens`` come back as zeros.
+    attended; query rows beyond ``q_lens`` come back as zeros.  A ragged ``k_lens`` runs as ONE launch
+    (``wan_attention_fwd_varlen``: the kernel reads the per-sample key counts from device memory); lengths given as a device
+    tensor are never read by the host.
     """
     if dtype not in (torch.bfloat16,):
         raise NotImplementedError("the gfx950 attention kernel computes in bfloat16 only")
@@ -46,26 +48,43 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
         qb = qb.contiguous()
     if not kb.is_contiguous():
         kb = kb.contiguous()
-    klen = None
+    klen, kl_dev = None, None
     if k_lens is not None:
-        kl = [int(x) for x in (k_lens.tolist() if torch.is_tensor(k_lens) else k_lens)]
-        if len(set(kl)) != 1:
-            # ragged batches: run sample by sample (the reference builds cu_seqlens, :95-100)
-            outs = [flash_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1],
-                                    None if q_lens is None else q_lens[i:i + 1], [kl[i]],
-                                    softmax_scale=softmax_scale, dtype=dtype) for i in range(B)]
-            return torch.cat(outs)
-        klen = kl[0]
-    ldvt = ops.round_up(Lk if klen is None else klen, 64)
-    vt = torch.empty(B, N * D, ldvt, device=q.device, dtype=torch.bfloat16)
-    for b in range(B):
-        ops.transpose_pad(vb[b][: (klen or Lk)], ldvt, out=vt[b])
-    out = ops.attention_fwd(qb, kb, vt, N, k_len=klen, softmax_scale=softmax_scale)
-    out = out.view(B, Lq, N, D)
-    if q_lens is not None:
-        ql = [int(x) for x in (q_lens.tolist() if torch.is_tensor(q_lens) else q_lens)]
+        if torch.is_tensor(k_lens) and k_lens.is_cuda:
+            kl_dev = k_lens.to(torch.int32).contiguous()             # stays on the device: no host read of the lengths
+        else:
+            kl = [int(x) for x in (k_lens.tolist() if torch.is_tensor(k_lens) else k_lens)]
+            if len(kl) != B or min(kl) < 0 or max(kl) > Lk:
+                raise ValueError(f"k_lens={kl} for a batch of {B} with {Lk} keys")
+            if len(set(kl)) == 1 and kl[0] > 0:
+                klen = kl[0]
+            else:
+                kl_dev = torch.tensor(kl, dtype=torch.int32).to(q.device, non_blocking=True)
+    if kl_dev is not None:
+        # ragged batch: ONE launch, every workgroup reads its sample's key count (the reference packs the samples behind
+        # cu_seqlens, :95-146).  V rows past a sample's length are zeroed so that the V^T pad columns the last tile touches are finite
+        if kl_dev.shape != (B,):
+            raise ValueError(f"k_lens must hold {B} lengths")
+        keep = torch.arange(Lk, device=q.device)[None, :] < kl_dev[:, None]
+        vb = torch.where(keep[..., None], vb, torch.zeros((), device=q.device, dtype=vb.dtype))
+        ldvt = ops.round_up(Lk, 64)
+        vt = torch.empty(B, N * D, ldvt, device=q.device, dtype=torch.bfloat16)
         for b in range(B):
-            out[b, ql[b]:] = 0
+            ops.transpose_pad(vb[b], ldvt, out=vt[b])
+        out = ops.attention_fwd(qb, kb, vt, N, softmax_scale=softmax_scale, k_lens=kl_dev)
+        out = out.view(B, Lq, N, D)
+        out.masked_fill_((kl_dev <= 0)[:, None, None, None], 0)      # flash-attn: a sample without keys gives zero rows
+    else:
+        ldvt = ops.round_up(Lk if klen is None else klen, 64)
+        vt = torch.empty(B, N * D, ldvt, device=q.device, dtype=torch.bfloat16)
+        for b in range(B):
+            ops.transpose_pad(vb[b][: (klen or Lk)], ldvt, out=vt[b])
+        out = ops.attention_fwd(qb, kb, vt, N, k_len=klen, softmax_scale=softmax_scale)
+        out = out.view(B, Lq, N, D)
+    if q_lens is not None:
+        ql = q_lens.to(device=q.device, dtype=torch.int64) if torch.is_tensor(q_lens) else \
+            torch.tensor([int(x) for x in q_lens], dtype=torch.int64).to(q.device, non_blocking=True)
+        out.masked_fill_((torch.arange(Lq, device=q.device)[None, :] >= ql[:, None])[..., None, None], 0)
     return out.type(out_dtype)
 
 

@@ -71,6 +71,9 @@ struct AttnArgs {
     // scale bytes [B][H][tiles][64 lanes][4 d-blocks] (vs8_hs = bytes per head), both written by wan_vt_quantize_mx
     const unsigned char* v8; int64_t ldv8, v8_bs;
     const unsigned char* vs8; int64_t vs8_hs;
+    // packed ragged batches (wan_attention_fwd_varlen): keys of batch b end at klens[b] (device memory, clamped to [1, Lk]); NULL =
+    // every batch attends Lk keys.  The reference packs such batches behind cu_seqlens (attention_utils.py:95-146)
+    const int* klens;
     int tile_mask;        // developer experiment (attn_exp & 1): staging reads tile (t & tile_mask); 0x7fffffff in product
     int exp_nocheck;      // developer experiment (attn_exp & 2), TIMING ONLY: the lazy form skips its per-tile window check
 };
@@ -222,7 +225,9 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int Lk = SPLIT ? min(a.Lk - t0 * kKV, a.tiles_per_split * kKV) : a.Lk;
+    int Lk;
+    if constexpr (SPLIT) Lk = min(a.Lk - t0 * kKV, a.tiles_per_split * kKV);
+    else Lk = a.klens != nullptr ? max(1, min(a.klens[batch], a.Lk)) : a.Lk;        // scalar: one s_load per workgroup
     const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
     const bf16_t* K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
     const unsigned char* K8 = QK8 ? a.k8 + batch * a.k8_bs + head * kD + (int64_t)t0 * kKV * a.ldk8 : nullptr;
@@ -1284,7 +1289,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
                                        void* out, int64_t ldo, int64_t o_bstride,
                                        int batch, int Lq, int Lk, int num_heads, int head_dim,
                                        float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
-                                       void* stream, const Qk8Operands* qk8) {
+                                       void* stream, const Qk8Operands* qk8, const int* klens = nullptr) {
     WAN_REQUIRE(q && k && vt && out, WAN_ERR_INVALID, "wan_attention_fwd: null tensor");
     WAN_REQUIRE((flags & ~WAN_ATTN_Q_PRESCALED) == 0, WAN_ERR_INVALID, "wan_attention_fwd: unknown flags 0x%x", flags);
     WAN_REQUIRE(head_dim == kD, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: head_dim=%d (only 128 is built)", head_dim);
@@ -1353,7 +1358,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     }
     a.vt = (const bf16_t*)vt; a.ldvt = ldvt; a.vt_bs = vt_bstride;
     a.o = (bf16_t*)out; a.ldo = ldo; a.o_bs = o_bstride;
-    a.Lq = Lq; a.Lk = Lk; a.H = num_heads;
+    a.Lq = Lq; a.Lk = Lk; a.H = num_heads; a.klens = klens;
     const bool pre = (flags & WAN_ATTN_Q_PRESCALED) != 0;
     WAN_REQUIRE(pre || (softmax_scale > 0.f && softmax_scale < 1e30f), WAN_ERR_INVALID,
                 "wan_attention_fwd: softmax_scale=%g must be positive and finite", (double)softmax_scale);
@@ -1364,7 +1369,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     const bool self = Lk > 1024;
     a.tile_mask = (wan_tune(WAN_TUNE_ATTN_EXP) & 1) ? 15 : 0x7fffffff;
     a.exp_nocheck = (wan_tune(WAN_TUNE_ATTN_EXP) & 2) ? 1 : 0;
-    if (wan_tune(WAN_TUNE_DEBUG_CHECKS) != 0) {       // synchronising contract check, developer builds / bring-up only
+    if (wan_tune(WAN_TUNE_DEBUG_CHECKS) != 0 && klens == nullptr) {       // synchronising contract check, developer builds / bring-up only
         const wan_status_t cs = check_vt_padding(a, batch, lk_pad, st);
         if (cs != WAN_OK) return cs;
     }
@@ -1383,7 +1388,11 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
             ws_tail = (char*)workspace + fb;
         }
     }
-    const AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable, qk8 != nullptr, qk8 != nullptr && qk8->v8 != nullptr);
+    AttnPlan plan = plan_attention(batch, Lq, Lk, num_heads, pre, ws_usable, qk8 != nullptr, qk8 != nullptr && qk8->v8 != nullptr);
+    if (klens != nullptr && plan.tail.tq > 0) {        // ragged batches: the split-KV tail round divides ONE key count; every workgroup walks its own
+        plan.tail = TailPlan();
+        plan.variant &= ~WAN_ATTN_VARIANT_SPLIT_TAIL;
+    }
     const TailPlan& tp = plan.tail;
     const bool fast = plan.fast;
     a.nqb = tp.tq > 0 ? tp.main_qb : nqb_all;
@@ -1450,6 +1459,18 @@ extern "C" wan_status_t wan_attention_fwd(const void* q, int64_t ldq, int64_t q_
                                           void* stream) {
     return attention_fwd_impl(q, ldq, q_bstride, k, ldk, k_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, batch, Lq, Lk, num_heads,
                               head_dim, softmax_scale, flags, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" wan_status_t wan_attention_fwd_varlen(const void* q, int64_t ldq, int64_t q_bstride,
+                                                 const void* k, int64_t ldk, int64_t k_bstride,
+                                                 const void* vt, int64_t ldvt, int64_t vt_bstride,
+                                                 void* out, int64_t ldo, int64_t o_bstride,
+                                                 int batch, int Lq, int Lk, const int32_t* k_lens, int num_heads, int head_dim,
+                                                 float softmax_scale, int flags, void* workspace, int64_t workspace_bytes,
+                                                 void* stream) {
+    WAN_REQUIRE(k_lens != nullptr && ((uintptr_t)k_lens & 3) == 0, WAN_ERR_INVALID, "wan_attention_fwd_varlen: k_lens must be a device array of batch int32");
+    return attention_fwd_impl(q, ldq, q_bstride, k, ldk, k_bstride, vt, ldvt, vt_bstride, out, ldo, o_bstride, batch, Lq, Lk, num_heads,
+                              head_dim, softmax_scale, flags, workspace, workspace_bytes, stream, nullptr, k_lens);
 }
 
 extern "C" wan_status_t wan_attention_fwd_qk8(const void* q8, int64_t ldq8, int64_t q8_bstride, int q_exp,

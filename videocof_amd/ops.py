@@ -438,11 +438,14 @@ _ATTN_WS = {}          # ad-hoc callers without their own workspace: one per (de
 @_on_tensor_device
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads: int, k_len: Optional[int] = None,
                   softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
-                  q_prescaled: bool = False, workspace: Optional[AttentionWorkspace] = None) -> torch.Tensor:
+                  q_prescaled: bool = False, workspace: Optional[AttentionWorkspace] = None,
+                  k_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q bf16 [B,Lq,H*128], k bf16 [B,Lk,H*128], vt bf16 [B,H*128,ldvt] (V transposed, ldvt >=
     roundup(k_len,64), finite padding) -> bf16 [B,Lq,H*128].  Keys >= k_len are masked.
     ``q_prescaled``: q already carries softmax_scale*log2(e) (see ``rmsnorm_rope_``'s x0_scale).
-    ``workspace``: the call site's ``AttentionWorkspace`` (default: one per device and stream)."""
+    ``workspace``: the call site's ``AttentionWorkspace`` (default: one per device and stream).
+    ``k_lens``: int32 [B] ON THE DEVICE -- a ragged batch in one launch (``wan_attention_fwd_varlen``): sample b attends keys
+    [0, k_lens[b]); the kernel reads the counts, the host never does."""
     for nm, t in (("q", q), ("k", k), ("vt", vt)):
         _need(t, torch.bfloat16, "attention." + nm)
         if t.dim() != 3:
@@ -467,6 +470,16 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, num_heads:
             if workspace is None:
                 workspace = _ATTN_WS[key] = AttentionWorkspace()
         ws = workspace.get(q.device, ws_bytes)
+    if k_lens is not None:
+        _need(k_lens, torch.int32, "attention.k_lens")
+        if k_lens.shape != (B,) or not k_lens.is_contiguous():
+            raise ValueError(f"attention.k_lens must be a contiguous int32 [{B}]")
+        _lib.check(lib.wan_attention_fwd_varlen(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
+                                                _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
+                                                B, Lq, Lk, _p(k_lens), num_heads, head_dim, float(scale),
+                                                _lib.ATTN_Q_PRESCALED if q_prescaled else 0, _p(ws),
+                                                ws_bytes if ws is not None else 0, _stream()), "wan_attention_fwd_varlen")
+        return out
     _lib.check(lib.wan_attention_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
                                      _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
                                      B, Lq, Lk, num_heads, head_dim, float(scale),
