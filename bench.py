@@ -56,6 +56,13 @@ WORKLOADS = {
                     desc="Wan2.1-T2V-14B plain T2V layout, 81f@480p"),
     "14b-720p": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=0, g=0, ft=21, h=90, w=160,
                      desc="Wan2.1-T2V-14B plain T2V layout, 81f@720p (BASELINE configs[3] shape; 50-step in the reference)"),
+    "14b-cof-33f": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=9, g=1, ft=9, h=60, w=104,
+                        desc="Wan2.1-T2V-14B + VideoCoF layout, 4-step, 33 source frames @ 480x832 -- the demo configuration of the reference "
+                             "(scripts/obj_rem.sh:13 --num_frames 33 --source_frames 33 --reasoning_frames 4), the one its README quotes "
+                             "'~30s/video on H100' for (README.md:124; the demo runs at the clip's native resolution, unstated)"),
+    "14b-cof-720p": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=21, g=1, ft=21, h=90, w=160,
+                         desc="Wan2.1-T2V-14B + VideoCoF layout, 81f@720p (BASELINE configs[3] shape in the CoF layout, one sample: "
+                              "L = 154 800)"),
     "14b-cof-321f-720p": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, fs=81, g=1, ft=81, h=90, w=160,
                               desc="Wan2.1-T2V-14B + VideoCoF layout, 321f@720p length extrapolation (BASELINE configs[4] shape; "
                                    "586 800 tokens -- meant for --gpus 8)"),
@@ -71,27 +78,64 @@ def dit_flops(L, C, ffn, layers, Lc=512):
     return lin + attn + 4 * L * 64 * C, layers * 4 * L * L * C
 
 
-def pmc_traffic(workload, shards):
+# committed PMC summaries by workload (tools/profile_bench.sh -> tools/pmc_summary.py), and the kernel instantiation each dispatcher
+# variant code (wan_get_tuning("last_attn_variant") & 15) launches as its MAIN self-attention kernel
+PMC_SUMMARY_OF_WORKLOAD = {"14b-cof": "bench14b_pmc_summary.json", "14b-cof-720p": "bench14b_cof_720p_pmc_summary.json",
+                           "14b-cof-321f-720p": "bench14b_cof_321f_720p_pmc_summary.json", "14b-cof-33f": "bench14b_cof_33f_pmc_summary.json"}
+PMC_KERNEL_OF_VARIANT = {1: "attn_fwd_w4_kernel<0, false, 1,", 2: "attn_fwd_w4_kernel<0, false, 0,"}
+
+
+def pmc_traffic(workload, shards, variant_code=None):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/profile_bench.sh -> tools/pmc_summary.py; FETCH_SIZE x2 per the
     gfx950 correction of the microarch guide).  Counters cannot be read live from inside the process, so this is null
-    for shapes that were not profiled.  ONE source of truth: the newest profiles/r*/bench14b_pmc_summary.json."""
-    if workload != "14b-cof" or shards != 1:
+    for shapes that were not profiled -- and null when the kernel the dispatcher launched in THIS run (`variant_code`) is not
+    the kernel the committed pass profiled (a stale profile must not be attributed to a new kernel).
+    ONE source of truth per workload: the newest profiles/r*/<PMC_SUMMARY_OF_WORKLOAD[workload]>."""
+    if workload not in PMC_SUMMARY_OF_WORKLOAD or shards != 1:
         return None, None
     import glob
-    alg = 4 * 67080 * 5120 * 2
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench14b_pmc_summary.json")), reverse=True):
+    wl = WORKLOADS[workload]
+    L = (wl["fs"] + wl["g"] + wl["ft"]) * (wl["h"] // 2) * (wl["w"] // 2)
+    alg = 4 * L * wl["dim"] * 2
+    want = None if variant_code is None else PMC_KERNEL_OF_VARIANT.get(int(variant_code) & 15)
+    if variant_code is not None and want is None:
+        return None, {"note": f"no committed PMC pass for attention variant {int(variant_code) & 15}"}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", PMC_SUMMARY_OF_WORKLOAD[workload])), reverse=True):
         try:
             with open(path) as f:
                 cands = {k: v for k, v in json.load(f).items() if "attn_fwd" in k and "<0" in k and "fetch" in v and "write" in v}
-            d = max(cands.values(), key=lambda v: v["fetch"]["avg_ms"])        # the self-attention MAIN launch (not tail / fix-up)
+            name, d = max(cands.items(), key=lambda kv: kv[1]["fetch"]["avg_ms"])        # the self-attention MAIN launch (not tail / fix-up)
+            if want is not None and not name.startswith(want):
+                return None, {"note": f"stale profile: {os.path.relpath(path, ROOT)} profiled {name}, this run launched {want}...>"}
             fetch, write = d["fetch"]["avg_counter"] * 1024 * 2, d["write"]["avg_counter"] * 1024
             return fetch + write, {"fetch_bytes_x2_corrected": fetch, "write_bytes": write, "algorithmic_bytes": alg,
-                                   "note": "L2->fabric requests; includes Infinity-Cache hits",
+                                   "note": "L2->fabric requests; includes Infinity-Cache hits", "profiled_kernel": name,
                                    "source": os.path.relpath(path, ROOT)}
         except Exception:
             continue
     return None, None
+
+
+# The box fingerprint (wan_box_probe, include/wan_hip.h): a FIXED calibration workload run before and after the timed region.  The
+# workload is MFMA-bound and the chips of this pool are power-limited in it, so the clock a box holds -- which differs by ~3.5 %
+# between boxes, more than a round of kernel work moves the headline -- shows up 1:1 in `value`; `value_normalised` = value x
+# (reference probe rate / this box's probe rate) is the figure to compare ACROSS boxes and rounds.  The reference rate is a constant
+# (the mean over the round-6 boxes, profiles/r06/box_probe_*.json), not a peak.
+BOX_REFERENCE_MFMA_MIX_TFLOPS = 1500.0
+
+
+def box_object(box):
+    if box is None:
+        return None
+    b, a = box["before"], box["after"]
+    mean = 0.5 * (b["mfma_mix_tflops"] + a["mfma_mix_tflops"])
+    return {"mfma_mix_tflops": round(mean, 1), "copy_tbps": round(0.5 * (b["copy_tbps"] + a["copy_tbps"]), 3),
+            "before": b, "after": a, "reference_mfma_mix_tflops": BOX_REFERENCE_MFMA_MIX_TFLOPS,
+            "rel_to_reference": round(mean / BOX_REFERENCE_MFMA_MIX_TFLOPS, 4),
+            "what": "wan_box_probe on rank 0: 32x32x16 bf16 MFMAs + LDS fragment reads + softmax VALU stream on random operands, one "
+                    "4-wave workgroup per CU, ~0.2 s measured after ~0.1 s of the same (chip at its power limit), and a 256 MiB copy; "
+                    "before = after the warm-up steps, after = right after the timed region; the same kernels every round"}
 
 
 def host_threads():
@@ -261,6 +305,23 @@ def verify_last_block(model, wl, lat, t, ctx, seq_len, fsi, gfi, out, L):
             "tolerance": {"rel_l2": 1e-2, "cosine": 0.9999}, "ok": bool(rel < 1e-2 and cos > 0.9999)}
 
 
+def exposed_comm(comm, steps, layers):
+    """The N > 1 line's split of the communication time the compute stream actually waited for (rank 0's HIP events, tagged by the
+    model: videocof_amd/wan_transformer3d.py `_comm_pair`), per step and per exchange."""
+    if not comm:
+        return None
+    by = {}
+    for tag, a, b in comm:
+        by[tag] = by.get(tag, 0.0) + a.elapsed_time(b)
+    total = sum(by.values())
+    return {"per_step": round(total / steps, 3), "per_layer": round(total / steps / layers, 4),
+            "per_step_by_exchange": {k: round(v / steps, 3) for k, v in sorted(by.items())},
+            "what": "HIP events on rank 0's compute stream around: q_g0 = wait_k / wait_v / V^T unpack / wait for the FIRST head group "
+                    "of q before attention (k and V^T travel under the V and q projections, the second head group of q under the first "
+                    "group's attention); o_g1 = the inverse exchange of the LAST head group (the first group's leaves under the second "
+                    "group's attention); all_gather = the one all-gather of the head output per forward"}
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, rendezvous
     on a free port of 127.0.0.1 (the container hostname may not resolve).  Rank 0's JSON line goes to the inherited stdout."""
@@ -311,7 +372,7 @@ def e2e_edit(model, wl, dev):
     model._comm_events = None
     pipe = WanPipeline(tokenizer=_ToyTokenizer(tcfg["vocab"]), text_encoder=t5, vae=vae, transformer=model,
                        scheduler=FlowUniPCMultistepScheduler(shift=1))
-    frames, height, width = 81, wl["h"] * 8, wl["w"] * 8
+    frames, height, width = (wl["fs"] - 1) * 4 + 1, wl["h"] * 8, wl["w"] * 8
     g = torch.Generator(device=dev).manual_seed(0)
     video = (torch.rand(1, 3, frames, height, width, device=dev, generator=g) * 2 - 1).bfloat16()
     prompt = "remove the red cup from the wooden table and keep everything else unchanged"
@@ -328,7 +389,7 @@ def e2e_edit(model, wl, dev):
     st = {k: round(v, 4) for k, v in pipe.stage_seconds.items()}
     pipe.stage_seconds = None
     return {"sec_per_video": round(total, 3), "stages_s": st, "other_s": round(total - sum(st.values()), 4),
-            "what": "VideoCoF edit end to end on one GPU: umT5-XXL + WanVAE encode (81f@480x832) + WanPipeline 4-step CoF loop "
+            "what": f"VideoCoF edit end to end on one GPU: umT5-XXL + WanVAE encode ({frames}f@{height}x{width}) + WanPipeline 4-step CoF loop "
                     "(guidance 1.0, pipeline defaults: cache_context, skip_source_prediction) + WanVAE decode (grounding + edit)",
             "edit_video_shape": list(out.edit_videos.shape), "ground_video_shape": list(out.ground_videos.shape),
             "finite": bool(np.isfinite(out.edit_videos).all()) if hasattr(out.edit_videos, "shape") else None,
@@ -342,12 +403,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="14b-cof", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="sp", choices=["sp", "dp"], help="N>1: Ulysses sequence parallel or replicas")
+    ap.add_argument("--layers", type=int, default=0,
+                    help="PROFILING ONLY: run the first N blocks of the architecture (per-launch counters of a kernel do not depend on "
+                         "the layer count; a PMC pass over 40 layers at L = 586 800 would take an hour).  The line says so in "
+                         "config.layers_override and its value is never a headline number.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (host-staged exchanges) only to exercise the N>1 code path on a box "
                          "whose ranks share one GPU -- its numbers are meaningless")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-box-probe", action="store_true",
+                    help="skip the ~0.4 s box fingerprint (wan_box_probe) before and after the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) oracle check of the last block")
     ap.add_argument("--fp8-layers", default="qkv,ffn",
                     help="with --fp8: comma-separated subset of qkv,ffn,o,cross (all four = every per-token Linear of a block), attn "
@@ -405,7 +472,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.layers > 0:
+        wl["num_layers"] = min(args.layers, wl["num_layers"])
     sp = world > 1 and args.mode == "sp"
     if sp and wl["num_heads"] % world:
         raise SystemExit(f"{wl['num_heads']} heads cannot be split over {world} GPUs (Ulysses)")
@@ -501,35 +570,59 @@ def main():
         comm.clear()
     if model._ws_self.buf is not None:
         model._ws_self.buf[8:12].zero_()          # scratch header word [2]: repair events of the lazy softmax reference
+    box = None
+    if not args.no_box_probe:
+        from videocof_amd import ops as vops
+        box = {"before": vops.box_probe(dev)}     # the warm-up steps above have brought the chip to temperature
     fence()
     t0 = time.perf_counter()
     out = run(args.steps)
     fence()
     wall = time.perf_counter() - t0
+    if box is not None:
+        box["after"] = vops.box_probe(dev)
+    rank_walls = None
     if world > 1:
-        tw = torch.tensor([wall], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
+        # every rank's own wall time of the timed region: the line's time is the MAX; the list and max / min show a straggler
+        tws = [torch.zeros(1, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tws, torch.tensor([wall], device=tws[0].device, dtype=torch.float64))
+        rank_walls = [float(v.item()) for v in tws]
+        wall = max(rank_walls)
     assert torch.isfinite(out.float()).all(), "non-finite latents"
 
-    # ---------------- parity of this run's own forward (untimed): probe the last block, compare with the oracle
+    # ---------------- parity of this run's own forward (untimed): probe the last block, compare with the oracle.
+    # Under sequence parallelism EVERY rank runs the probed forward (it contains collectives); each rank's probe is its token shard
+    # of the residual stream entering the last block, gathered over the SP group (the group's own all-gather), and rank 0 checks the
+    # sharded forward's output -- exchanges, rank-offset RoPE, padded-key masking, final all-gather and all -- against the oracle's
+    # single-device block + head + unpatchify on the gathered stream.
     parity = None
-    if not args.no_verify and not sp and rank == 0 and not args.graph_loop:
+    if not args.no_verify and (rank == 0 or sp) and not args.graph_loop:
         model._attn_events = None
+        model._comm_events = None
         model.mask_source_frames = 0
         model._probe_layer = wl["num_layers"] - 1
         tv = sched.timesteps[:1]
-        v = model(latents, tv.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
-        model._probe_layer = None
         try:
-            parity = verify_last_block(model, wl, latents, tv, ctx, seq_len, fsi, gfi, v, L)
-            if args.fp8:        # the lossy mode is reported against its own stated bound (tests/test_gpu_fp8.py), not the bf16 one
-                parity["tolerance"] = {"rel_l2": 8e-2, "cosine": 0.995}
-                parity["ok"] = bool(parity["rel_l2"] < 8e-2 and parity["cosine"] > 0.995)
-        except Exception as e:      # the check must never take the measured number down with it, but it must be visible
-            parity = {"error": repr(e), "ok": False}
+            v = model(latents, tv.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+            if sp:
+                grp = vdist.get_sp_group()
+                model._probe = grp.all_gather_tokens(model._probe.view(1, -1, wl["dim"]))[0].clone()
+        finally:
+            model._probe_layer = None
+        if rank == 0:
+            try:
+                parity = verify_last_block(model, wl, latents, tv, ctx, seq_len, fsi, gfi, v, L)
+                if sp:
+                    parity["what"] = ("sequence-parallel forward over %d ranks: " % world) + parity["what"] + \
+                                     " (the probes are the ranks' token shards, gathered)"
+                if args.fp8:        # the lossy mode is reported against its own stated bound (tests/test_gpu_fp8.py), not the bf16 one
+                    parity["tolerance"] = {"rel_l2": 8e-2, "cosine": 0.995}
+                    parity["ok"] = bool(parity["rel_l2"] < 8e-2 and parity["cosine"] > 0.995)
+            except Exception as e:      # the check must never take the measured number down with it, but it must be visible
+                parity = {"error": repr(e), "ok": False}
         model._probe = None
         model._attn_events = prof
+        model._comm_events = comm
 
     # ---------------- dominant kernel: self-attention launches inside the timed region
     roof = None
@@ -541,9 +634,9 @@ def main():
         Lq = model._last_attn_rows
         flop = 4.0 * Lq * Lk * heads_local * 128
         ach = flop / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1)
         from videocof_amd import _lib
         vcode = int(model._last_attn_variant)
+        traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1, vcode)
         hdr = model._ws_self.buf[:16].view(torch.int32).tolist() if model._ws_self.buf is not None else [None] * 4
         repairs = hdr[2]
         roof = {"kernel": "self-attention wan_attention_fwd: " + _lib.attn_variant_name(vcode), "variant_code": vcode,
@@ -585,6 +678,7 @@ def main():
         "config": {"workload": wl["desc"], "layout": "VideoCoF (src|ground|tgt)" if cof else "T2V",
                    "latent": [1, 16, Ftot, wl["h"], wl["w"]], "grid": [Ftot, wl["h"] // 2, wl["w"] // 2],
                    "tokens_per_sample": L, "global_batch": units, "guidance_scale": 1.0,
+                   "layers_override": (wl["num_layers"] if args.layers > 0 else None),
                    "parallelism": ("ulysses-sp%d" % world) if sp else ("replicas-dp%d" % world if world > 1 else "single")},
         "tokens_per_s_per_gpu": round(value / world, 1),
         "sec_per_video_4step": round(wall / args.steps * 4, 3),
@@ -592,19 +686,20 @@ def main():
         "model_tflops_per_s": round(units * tot_flop * args.steps / wall / 1e12, 1),
         "mfma_frac_whole_step": round(units * tot_flop * args.steps / wall / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": roof,
+        "box": box_object(box),
+        "value_normalised": None if box is None else round(value * BOX_REFERENCE_MFMA_MIX_TFLOPS / (0.5 * (box["before"]["mfma_mix_tflops"] + box["after"]["mfma_mix_tflops"])), 1),
         "ranks_seen": dist.get_world_size() if world > 1 else 1,
         "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (host-staged, numbers meaningless)")) if world > 1 else None,
-        "exposed_comm_ms": None if not comm else {
-            "per_step": round(sum(a.elapsed_time(b) for a, b in comm) / args.steps, 3),
-            "per_layer": round(sum(a.elapsed_time(b) for a, b in comm) / args.steps / wl["num_layers"], 4),
-            "what": "HIP events on the compute stream around (i) wait_k / wait_v / V^T unpack / wait_q before attention and "
-                    "(ii) the inverse (o) exchange; the k and V^T exchanges themselves run under the V and q projections"},
+        "exposed_comm_ms": exposed_comm(comm, args.steps, wl["num_layers"]),
+        "rank_wall_s": None if rank_walls is None else {
+            "per_rank": [round(v, 4) for v in rank_walls], "max_over_min": round(max(rank_walls) / min(rank_walls), 4),
+            "what": "each rank's own wall clock of the timed region (between the two barriers); the line's time is the max"},
         "parity": parity,
         "graph": "loop" if args.graph_loop else bool(args.graph),
         "attn_stress": bool(args.attn_stress),
         "fp8_attn_smooth_k": (not args.fp8_no_smooth_k) if (args.fp8 and "attn" in args.fp8_layers.split(",")) else None,
     }
-    if rank == 0 and world == 1 and not args.no_e2e and args.workload == "14b-cof" and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
+    if rank == 0 and world == 1 and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
         try:        # the metric's second half (sec / video of a whole edit); separate from the timed region above, never takes it down
             res["e2e"] = e2e_edit(model, wl, dev)
         except Exception as e:

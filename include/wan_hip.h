@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 9      /* 9: wan_attention_fwd_varlen (ragged batches in one launch); 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
+#define WAN_ABI_VERSION 10     /* 10: wan_box_probe (the benchmark's box fingerprint); 9: wan_attention_fwd_varlen (ragged batches in one launch); 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -567,6 +567,23 @@ wan_status_t wan_t5_softmax_bias(const float* scores, int64_t lds, const float* 
 
 /* gated-GELU feed-forward product fc1(x) * gelu(gate(x)) (wan_text_encoder.py:125-126): out = a * b, bf16, n % 8 == 0. */
 wan_status_t wan_mul_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Box fingerprint for benchmarks (no reference counterpart: the reference has no benchmark harness).  A FIXED calibration
+ * workload, independent of the product kernels: (a) ~target_ms of 32x32x16 bf16 MFMAs on random operands beside LDS fragment
+ * reads and a softmax VALU stream (the instruction mix of a flash-attention tile), one 4-wave workgroup per CU -- what the
+ * matrix pipes of THIS box hold at its power limit; (b) 40 passes of a 256 MiB -> 256 MiB copy.  Unlike every other entry
+ * point this call SYNCHRONISES the stream (it reads HIP events) -- it is a measurement, never part of a timed region.
+ * scratch: device memory of >= wan_box_probe_scratch_bytes(), caller-owned.  target_ms <= 0 selects 300.
+ * bench.py runs it before and after the timed region (`box` object, `value_normalised`).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    float mfma_mix_tflops;   /* issued MFMA FLOP / time of the last two of three equal launches */
+    float copy_tbps;         /* (read + write) bytes / time */
+    float mfma_ms, copy_ms;  /* the measured intervals */
+} wan_box_probe_result;
+int64_t wan_box_probe_scratch_bytes(void);
+wan_status_t wan_box_probe(wan_box_probe_result* result, void* scratch, int64_t scratch_bytes, int target_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,11 @@ def test_workloads_are_the_baseline_configs():
     assert tokens(w["1.3b-small"]) == 2304                                            # configs[0]: 9 x 32 x 32 latent
     assert tokens(w["14b-720p"]) == 75600                                             # configs[3]: 21 x 45 x 80
     assert tokens(w["14b-cof-321f-720p"]) == 586800                                   # configs[4]
+    assert tokens(w["14b-cof-720p"]) == 154800                                        # configs[3] in the CoF layout, per sample
+    # the reference's demo configuration (scripts/obj_rem.sh:13: --num_frames 33 --source_frames 33 --reasoning_frames 4):
+    # condition_count = (33 - 1) // 4 + 1 = 9 source latents, G = (4 - 1) // 4 + 1 = 1, 9 target latents (pipeline_wan.py:411-417)
+    w33 = w["14b-cof-33f"]
+    assert (w33["fs"], w33["g"], w33["ft"]) == ((33 - 1) // 4 + 1, (4 - 1) // 4 + 1, (33 - 1) // 4 + 1) and tokens(w33) == 19 * 30 * 52
     for name in ("14b-cof", "14b-t2v", "14b-720p", "14b-cof-321f-720p"):
         assert (w[name]["dim"], w[name]["ffn_dim"], w[name]["num_heads"], w[name]["num_layers"]) == (5120, 13824, 40, 40)
     assert (w["1.3b-cof"]["dim"], w["1.3b-cof"]["ffn_dim"], w["1.3b-cof"]["num_heads"], w["1.3b-cof"]["num_layers"]) == (1536, 8960, 12, 30)
@@ -44,6 +49,37 @@ def test_pmc_traffic_reads_the_newest_committed_profile():
     assert d["algorithmic_bytes"] == 4 * 67080 * 5120 * 2                                   # q, k, v read + o written, bf16
     assert 1.0 < total / d["algorithmic_bytes"] < 10.0
     assert bench.pmc_traffic("14b-cof", 8) == (None, None) and bench.pmc_traffic("1.3b-small", 1) == (None, None)
+    # the profile is attributed only to the kernel it was taken of: variant 2 (max-free attempt) is what the committed pass profiled;
+    # a run that launched the lazy reference (variant 1) or an fp8 family gets null + the reason, never a stale number
+    tot2, d2 = bench.pmc_traffic("14b-cof", 1, 2 | 16 | 32)
+    assert tot2 == total and d2["profiled_kernel"].startswith(bench.PMC_KERNEL_OF_VARIANT[2])
+    tot1, d1 = bench.pmc_traffic("14b-cof", 1, 1)
+    assert tot1 is None and "stale profile" in d1["note"]
+    tot5, d5 = bench.pmc_traffic("14b-cof", 1, 5)
+    assert tot5 is None and "no committed PMC pass" in d5["note"]
+
+
+def test_exposed_comm_split_and_box_object():
+    """The N > 1 line's per-exchange split (tags set by the model's `_comm_pair`) and the box fingerprint object."""
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    comm = []
+    for _ in range(2 * 3):                                   # 2 steps x 3 layers
+        comm += [("q_g0", Ev(0.0), Ev(1.5)), ("o_g1", Ev(0.0), Ev(0.5))]
+    comm += [("all_gather", Ev(0.0), Ev(0.25)), ("all_gather", Ev(1.0), Ev(1.25))]
+    d = bench.exposed_comm(comm, steps=2, layers=3)
+    assert d["per_step_by_exchange"] == {"all_gather": 0.25, "o_g1": 1.5, "q_g0": 4.5}
+    assert d["per_step"] == 6.25 and abs(d["per_layer"] - 6.25 / 3) < 1e-3
+    assert bench.exposed_comm([], 2, 3) is None and bench.exposed_comm(None, 2, 3) is None
+    assert bench.box_object(None) is None
+    probe = lambda tf, tb: {"mfma_mix_tflops": tf, "copy_tbps": tb, "mfma_ms": 200.0, "copy_ms": 9.0}
+    b = bench.box_object({"before": probe(1520.0, 5.0), "after": probe(1480.0, 5.2)})
+    assert b["mfma_mix_tflops"] == 1500.0 and b["copy_tbps"] == 5.1
+    assert b["rel_to_reference"] == round(1500.0 / bench.BOX_REFERENCE_MFMA_MIX_TFLOPS, 4)
 
 
 def test_timing_helper_and_host_threads():

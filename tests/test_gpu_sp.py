@@ -164,7 +164,8 @@ def _rccl_ws1_worker(port, q_out):
         third = m(lat, t, ctx, 420, **kw)                 # ... and back
         torch.cuda.synchronize()
         n_ev = len(comm)
-        ms = sum(a.elapsed_time(b) for a, b in comm)
+        ms = sum(a.elapsed_time(b) for _, a, b in comm)
+        assert {tag for tag, _, _ in comm} == {"q_g0", "o_g1", "all_gather"}
         from videocof_amd import GraphedForward
         try:                                              # this transport's collectives run on the process group's own stream: not captured
             GraphedForward(m)
@@ -197,7 +198,7 @@ def test_sp_async_path_over_rccl_on_one_gpu():
     assert rel < 2e-3, rel
     assert again and third, "the Ulysses forward does not repeat bitwise: a wire buffer is reused before its consumer finished"
     assert not other_equal and plain_ok
-    assert n_ev == 2 * layers * 4                        # 4 forwards x (waits before attention + inverse exchange) per layer
+    assert n_ev == (2 * layers + 1) * 4                  # 4 forwards x ((waits before attention + inverse exchange) per layer + the all-gather)
     print(f"rccl world_size=1: rel={rel:.2e} bitwise_vs_single={bitwise_single} exposed_comm={ms:.2f} ms over {n_ev} windows")
 
 
@@ -576,3 +577,32 @@ def test_sp_layers_allocate_nothing():
         assert p.exitcode == 0
     for rank, (c2, c6) in sorted(q.get(timeout=5) for _ in range(2)):
         assert c6 == c2, (rank, c2, c6)
+
+
+def test_bench_line_under_sequence_parallelism_is_self_validating():
+    """`bench.py --gpus 2` (two ranks on this GPU, host-staged gloo exchanges: the N > 1 code path of the bench, its numbers
+    meaningless): the line must CHECK the sharded forward it timed -- `parity` = the ranks' probes gathered, the last block + head
+    + unpatchify against the oracle on rank 0 -- and carry the per-rank wall clocks and the exposed-communication split per exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                        "--workload", "1.3b-small", "--layers", "3", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["config"]["parallelism"] == "ulysses-sp2"
+    assert line["config"]["layers_override"] == 3
+    p = line["parity"]
+    assert p is not None and p.get("ok") is True, p
+    assert p["rel_l2"] < 1e-2 and p["cosine"] > 0.9999 and "sequence-parallel forward over 2 ranks" in p["what"]
+    rw = line["rank_wall_s"]
+    assert len(rw["per_rank"]) == 2 and rw["max_over_min"] >= 1.0
+    assert abs(max(rw["per_rank"]) * 1e3 / line["steps"] - line["ms_per_step"]) < 0.5          # the line's time is the slowest rank's
+    ec = line["exposed_comm_ms"]
+    assert set(ec["per_step_by_exchange"]) == {"q_g0", "o_g1", "all_gather"}
+    assert abs(sum(ec["per_step_by_exchange"].values()) - ec["per_step"]) < 0.01
+    assert line["box"] is not None and line["box"]["mfma_mix_tflops"] > 100 and line["value_normalised"] > 0

@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
@@ -44,6 +44,11 @@ class RopeParams(Structure):
     _fields_ = [("F", c_int), ("Hp", c_int), ("Wp", c_int), ("mode", c_int), ("f_src", c_int),
                 ("ground_end", c_int), ("token_offset", c_int64), ("rows_per_batch", c_int64),
                 ("max_pos", c_int)]
+
+
+class BoxProbeResult(Structure):
+    """``wan_box_probe_result`` of include/wan_hip.h."""
+    _fields_ = [("mfma_mix_tflops", c_float), ("copy_tbps", c_float), ("mfma_ms", c_float), ("copy_ms", c_float)]
 
 
 class ConvParams(Structure):
@@ -83,6 +88,8 @@ class DitWorkspace(Structure):
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "wan_abi_version": (c_int, []),
+    "wan_box_probe_scratch_bytes": (c_int64, []),
+    "wan_box_probe": (c_int, [POINTER(BoxProbeResult), c_void_p, c_int64, c_int, c_void_p]),
     "wan_last_error": (c_char_p, []),
     "wan_set_tuning": (c_int, [c_char_p, c_int]),
     "wan_get_tuning": (c_int, [c_char_p]),

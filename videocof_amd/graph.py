@@ -23,6 +23,7 @@ bit-identical (``tests/test_gpu_dit.py::test_graph_replay_is_bit_identical``).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -38,12 +39,21 @@ def _check_capturable(model) -> None:
     caller's stream is being captured the library communicator enqueues every collective on THAT stream (csrc/sp_comm.cpp,
     `sp_runs_inline`: no side stream, no events -- at P = 8 an exchange is < 1 % of a layer, so the overlap it gives up inside a
     replayed graph is small), which is what this check admits.  torch.distributed's process group stays eager: its collectives run
-    on a stream of its own."""
+    on a stream of its own.
+    EVIDENCE: capture + bit-identical replay of that path has only ever run with ONE rank (tests/test_gpu_sp.py::
+    test_graph_capture_of_a_sequence_parallel_forward; the development boxes have one GPU).  RCCL kernels of several ranks inside
+    graphs that the ranks replay in lockstep are untested, so world_size > 1 is refused unless ``WAN_SP_GRAPH_MULTI_RANK=1`` opts in
+    (for whoever has two GPUs to run the check on).  A communicator that was captured once is deliberately NOT destroyed by
+    wan_sp_destroy (the graphs hold its RCCL kernels); it lives until the process exits."""
     if model.sp_world_size != 1 or getattr(model, "force_ulysses", False):
         from .dist import LibraryComm
         if not isinstance(getattr(model, "_sp", None), LibraryComm):
             raise NotImplementedError("graph capture of a sequence-parallel forward needs the library-owned communicator "
                                       "(init_sequence_parallel(backend=\"library\")); torch.distributed collectives stay eager")
+        if model.sp_world_size != 1 and os.environ.get("WAN_SP_GRAPH_MULTI_RANK", "0") != "1":
+            raise NotImplementedError("graph capture of a sequence-parallel forward is verified with one rank only; more ranks "
+                                      "replaying RCCL collectives from graphs in lockstep are untested (set WAN_SP_GRAPH_MULTI_RANK=1 "
+                                      "to try)")
 
 
 class _Entry:

@@ -49,6 +49,25 @@ def get_tuning(key: str) -> int:
     return int(_lib.load().wan_get_tuning(key.encode()))
 
 
+def box_probe(device=None, target_ms: int = 300) -> dict:
+    """``wan_box_probe`` (include/wan_hip.h): the fixed calibration workload of the library -- what the matrix pipes of this box hold
+    at the power limit under a flash-attention instruction mix, and its plain copy rate.  SYNCHRONISES; a measurement for benchmarks
+    (bench.py's `box` object), never part of the product path.  The 512 MiB scratch is allocated here and freed on return."""
+    import ctypes
+    dev = torch.device(device if device is not None else torch.cuda.current_device())
+    if dev.type != "cuda":
+        raise RuntimeError("box_probe needs a GPU")
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        n = int(lib.wan_box_probe_scratch_bytes())
+        scratch = torch.empty(n, device=dev, dtype=torch.uint8)
+        res = _lib.BoxProbeResult()
+        _lib.check(lib.wan_box_probe(ctypes.byref(res), ctypes.c_void_p(scratch.data_ptr()), n, int(target_ms), _stream()), "wan_box_probe")
+        del scratch
+    return {"mfma_mix_tflops": round(float(res.mfma_mix_tflops), 1), "copy_tbps": round(float(res.copy_tbps), 3),
+            "mfma_ms": round(float(res.mfma_ms), 2), "copy_ms": round(float(res.copy_ms), 2)}
+
+
 def _need(t: torch.Tensor, dtype, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path has no CPU fallback")

@@ -191,8 +191,9 @@ class WanPipeline:
                  source_latents: Optional[torch.Tensor] = None, device=None,
                  weight_dtype: torch.dtype = torch.bfloat16, cache_context: bool = True,
                  skip_source_prediction: bool = True, capture_graph=False):
-        if timesteps is not None:
-            raise NotImplementedError("custom `timesteps` are not supported (the reference's CLIs never pass them)")
+        # `timesteps`: with a FlowUniPCMultistepScheduler the reference never looks at it (pipeline_wan.py:613-615 calls
+        # set_timesteps(num_inference_steps, device=, shift=) and takes scheduler.timesteps); accepted and ignored here too.
+        del timesteps
         if num_videos_per_prompt != 1:
             raise NotImplementedError("num_videos_per_prompt must be 1 (as in fast_infer.py / inference.py)")
         self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)

@@ -670,16 +670,19 @@ class WanTransformer3DModel(nn.Module):
             self._last_attn_rows = rows
             self._last_attn_variant = ops.get_tuning("last_attn_variant")      # what the dispatcher launched for THIS call
 
-    def _comm_pair(self):
+    def _comm_pair(self, tag):
+        """HIP events on the compute stream around one EXPOSED stretch of the Ulysses exchanges; ``_comm_events`` collects
+        (tag, start, end) with tag in "q_g0" (the waits before attention: k, V^T -- normally complete under the projections --
+        and the first head group of q), "o_g1" (the inverse exchange of the last head group) and "all_gather" (the head output)."""
         if self._comm_events is None:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        return a, b
+        return tag, a, b
 
     def _comm_done(self, ev):
         if ev is not None:
-            ev[1].record()
+            ev[2].record()
             self._comm_events.append(ev)
 
     def _rope_map(self, grid, frame_split_indices, ground_frame_indices, token_offset, rows):
@@ -873,7 +876,7 @@ class WanTransformer3DModel(nn.Module):
                 wait_q1 = sp.exchange(bufs.qw_r[n0:], bufs.qw_s[n0:], async_op=True)
             else:
                 wait_q = sp.exchange(bufs.qw_r, bufs.qw_s, async_op=True)
-            cev = self._comm_pair()             # exposed: whatever of the exchanges the projections did not cover (q: group 0 only)
+            cev = self._comm_pair("q_g0")       # exposed: whatever of the exchanges the projections did not cover (q: group 0 only)
             wait_k()
             wait_v()
             ops.sp_unpack_vt(bufs.vw_r, bufs.vt_full, P, Ll)
@@ -938,7 +941,7 @@ class WanTransformer3DModel(nn.Module):
                 if gi + 1 < len(groups):        # ... the output of group 0 leaves under the attention of group 1
                     wait_o.append(sp.exchange(bufs.ow_r[off:off + Lt * B * cg], bufs.ow_s[off:off + Lt * B * cg], async_op=True))
             self._event_done(ev, B * seq_len)
-            cev = self._comm_pair()             # exposed: the inverse exchange sits between attention and the o projection (group 1 only)
+            cev = self._comm_pair("o_g1")       # exposed: the inverse exchange sits between attention and the o projection (group 1 only)
             c0, cg, hg, off = groups[-1]
             sp.exchange(bufs.ow_r[off:off + Lt * B * cg], bufs.ow_s[off:off + Lt * B * cg])
             for w_ in wait_o:
@@ -1236,7 +1239,9 @@ class WanTransformer3DModel(nn.Module):
             ops.ln_modulate(xs, ehead[1], ehead[0], True, Ll, self.eps, out=h)
             yt = ops.gemm(h, w["head_w"], w["head_b"], ops.EPI_F32).view(B, Ll, -1)
         if usp:
+            cev = self._comm_pair("all_gather")
             yt = self._sp.all_gather_tokens(yt)                                        # :1085-1086
+            self._comm_done(cev)
         out_dtype = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
         out = torch.empty(B, self.out_dim, grid[0] * pt, grid[1] * ph, grid[2] * pw, device=dev, dtype=out_dtype)
         for b in range(B):
