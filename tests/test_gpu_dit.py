@@ -744,3 +744,21 @@ def test_module_surface_state_dict_partial_load_and_pipeline_to(model):
     assert pipe.enable_model_cpu_offload(device=DEV) is None and pipe.enable_sequential_cpu_offload(device=DEV) is None
     with pytest.raises(RuntimeError, match="loaded on"):
         pipe.to("cpu")
+
+
+def test_ingest_of_a_14b_width_sharded_checkpoint_with_three_rank128_loras():
+    """SURVEY 8f-2 at the real WIDTH (the full 40-layer run is tools/bench_ingest.py, profiles/r06/ingest_14b.json): a sharded bf16
+    safetensors directory with config.json goes through from_pretrained (wan_transformer3d.py:1157-1299), three rank-128 LoRA files
+    with ComfyUI names through merge_lora (lora_utils.py:371-500; the three merges of fast_infer.py:366-386); sampled rows of sampled
+    Linears must equal W0 + sum m * alpha / r * up @ down evaluated in fp64 from the files (one bf16 rounding per merge call)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_ingest.py"), "--layers", "2", "--shards", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["check"]["ok"] and d["check"]["sampled_linears"] == 6 and d["lora_layers_merged"] == [20, 20, 20]
+    assert d["load_s"] > 0 and d["merge_s"] > 0 and d["checkpoint_bytes"] > 1.4e9

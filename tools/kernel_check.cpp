@@ -541,6 +541,44 @@ int main(int argc, char** argv) {
             WAN(wan_set_tuning("gemm_pk_form", 31));
         }
     }
+    if (mode == "gemmgm") {       // persistent GEMM: the rasterisation group GM (M tiles per group = the shape of the 32 tiles in flight on an XCD: GM x 32/GM) swept in one process
+        WAN(wan_set_tuning("gemm_pk", 1));
+        const int L = 67080;
+        struct G { int M, N, K; int epi; const char* what; };
+        std::vector<G> gs = {{L, 13824, 5120, WAN_EPI_GELU_BF16, "ffn.0+gelu"}, {L, 10240, 5120, WAN_EPI_BF16, "qk proj"},
+                             {L, 5120, 5120, WAN_EPI_RESID_F32, "o proj+gate+resid"}, {L, 5120, 13824, WAN_EPI_RESID_F32, "ffn.2+resid"},
+                             {L, 5120, 5120, WAN_EPI_BF16_T, "v proj (T)"}};
+        std::vector<int> gms = {0, 1, 2, 3, 4, 6, 8, 16};
+        if (argc > 2 && strchr(argv[2], ',')) { gms.clear(); for (char* t = strtok(argv[2], ","); t; t = strtok(nullptr, ",")) gms.push_back(atoi(t)); }
+        const bool once = argc > 3 && !strcmp(argv[3], "once");       // one launch per (shape, gm): the form a rocprofv3 --pmc pass wants
+        for (auto g : gs) {
+            auto hA = to_bf(randn((size_t)4096 * 64));
+            Dev<bf16> A((size_t)g.M * g.K), W((size_t)g.N * g.K);
+            for (size_t off = 0; off < A.n; off += hA.size()) HIP(hipMemcpy(A.p + off, hA.data(), std::min(hA.size(), A.n - off) * 2, hipMemcpyHostToDevice));
+            for (size_t off = 0; off < W.n; off += hA.size()) HIP(hipMemcpy(W.p + off, hA.data(), std::min(hA.size(), W.n - off) * 2, hipMemcpyHostToDevice));
+            Dev<float> bias(g.N), gate(g.N); bias.zero(); gate.zero();
+            const int64_t ldo = g.epi == WAN_EPI_BF16_T ? (g.M + 63) / 64 * 64 : g.N;
+            const size_t osz = (size_t)(g.epi == WAN_EPI_BF16_T ? g.N : g.M) * ldo * ((g.epi == WAN_EPI_F32 || g.epi == WAN_EPI_RESID_F32) ? 4 : 2);
+            Dev<char> out(osz); out.zero();
+            const int64_t wsb = wan_gemm_workspace_bytes(g.M, g.N, g.K);
+            Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
+            std::vector<double> best(gms.size(), 1e30);
+            for (int round = 0; round < (once ? 1 : 4); ++round)
+                for (size_t a = 0; a < gms.size(); ++a) {
+                    WAN(wan_set_tuning("gemm_gm", gms[a]));
+                    auto launch = [&] { WAN(wan_gemm_bf16_ws(A.p, g.K, W.p, g.K, bias.p, out.p, ldo, g.M, g.N, g.K, g.epi,
+                                                             g.epi == WAN_EPI_RESID_F32 ? gate.p : nullptr, g.M, ws.p, wsb, nullptr)); };
+                    if (once) { launch(); HIP(hipDeviceSynchronize()); continue; }
+                    double ms = time_ms(launch, 6, 2);
+                    if (round > 0) best[a] = std::min(best[a], ms);
+                }
+            if (once) continue;
+            printf("  gemm %-18s M=%d N=%d K=%d:", g.what, g.M, g.N, g.K);
+            for (size_t a = 0; a < gms.size(); ++a) printf("  gm=%d %.3f ms %.0f TF/s |", gms[a], best[a], 2.0 * g.M * g.N * g.K / best[a] / 1e9);
+            printf("\n"); fflush(stdout);
+        }
+        WAN(wan_set_tuning("gemm_gm", 0));
+    }
     if (mode == "gemmcyc") {      // `make EXPERIMENTS=1` builds: where a persistent-GEMM workgroup's cycles go, per epilogue form, with the forced waits
         if (wan_get_tuning("dev_experiments") != 1) { printf("gemmcyc needs a `make EXPERIMENTS=1` build\n"); return 2; }
         const int L = 67080;

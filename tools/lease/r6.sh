@@ -16,6 +16,33 @@ case $stage in
     timeout 1200 $B --gpus 4 --backend gloo --share-gpu --workload 14b-cof --steps 1 --warmup 1 2>$out/bench_sp4.err | json > $out/bench_sp4_gloo_shared_gpu_14b.json
     timeout 900 $B --workload 14b-cof-720p --steps 1 --warmup 1 --no-cpu-baseline 2>$out/bench_720p.err | json > $out/bench_14b_cof_720p.json
     ;;
+  b)  # GEMM rasterisation sweep (+ FETCH_SIZE per arm), the mixed-MFMA-shape probe, the 321f@720p length-extrapolation config on one GPU, whole GPU suite
+    free -g | head -2; df -h /tmp | tail -1; nproc
+    timeout 300 tools/probe/mfma_power > $out/mfma_power_mixed.log 2>&1; grep -E "MIXED|softmax VALU" $out/mfma_power_mixed.log
+    timeout 600 tools/kernel_check gemmgm > $out/gemm_gm_sweep.log 2>&1; grep "gemm " $out/gemm_gm_sweep.log
+    ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$out/pmc_gm -- $OLDPWD/tools/kernel_check gemmgm 0,1,2,3,4,6,8,16 once > $OLDPWD/$out/pmc_gm.log 2>&1 )
+    python - $out <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+rows = []
+for f in glob.glob(out + "/pmc_gm/**/*counter_collection.csv", recursive=True):
+    rows += [r for r in csv.DictReader(open(f)) if "gemm_pk_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+gms = [0, 1, 2, 3, 4, 6, 8, 16]
+shapes = ["ffn.0+gelu", "qk proj", "o proj+gate+resid", "ffn.2+resid", "v proj (T)"]
+with open(out + "/gemm_gm_fetch.log", "w") as fo:
+    for i, r in enumerate(rows):
+        line = "%-18s gm=%-2d FETCH_SIZE x2 = %.2f GB  (%.3f ms under the counter pass)" % (shapes[i // len(gms)] if i // len(gms) < len(shapes) else "?", gms[i % len(gms)],
+               float(r["Counter_Value"]) * 1024 * 2 / 1e9, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        print(line); fo.write(line + "\n")
+PY
+    rm -rf $out/pmc_gm
+    timeout 1500 $B --workload 14b-cof-321f-720p --steps 1 --warmup 0 --no-cpu-baseline 2>$out/bench_321f.err | json > $out/bench_14b_cof_321f_720p.json
+    PASSES="trace FETCH_SIZE" PASS_TIMEOUT=900 bash tools/profile_bench.sh 14b_cof_321f_720p_2layers --workload 14b-cof-321f-720p --layers 2 > $out/prof_321f.log 2>&1
+    PASSES="trace FETCH_SIZE WRITE_SIZE" PASS_TIMEOUT=900 bash tools/profile_bench.sh 14b_cof_720p_4layers --workload 14b-cof-720p --layers 4 > $out/prof_720p.log 2>&1
+    timeout 900 python tools/bench_ingest.py --layers 40 2>$out/ingest.err | json > $out/ingest_14b.json; cat $out/ingest_14b.json
+    timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'

@@ -65,6 +65,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// Round 6: the MIXED body the round-5 review asked about -- QK^T on 32x32x16 (its S^T layout feeds the softmax lane-locally), P.V on
+// 16x16x32 (the shape that sustains more FLOP/s per watt on its own) -- with the same LDS fragment reads and softmax stream PER FLOP as the
+// rows above: per iteration 8 MFMAs of 32x32x16 + 16 of 16x16x32 (equal FLOPs), 4 + 4 ds_read_b128, 16 v_exp + 16 v_add + 8 v_cvt_pk.
+// (An upper bound for that design: the P fragments would also have to change lanes between the two shapes, which is not modelled.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void kmix(const u32x4* src, float* out, int iters) {
+    __shared__ u32x4 sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = src[i];
+    __syncthreads();
+    u32x4 a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = sm[(threadIdx.x * 8 + i) & 4095]; b[i] = sm[(threadIdx.x * 8 + i + 1024) & 4095]; }
+    const u32x4* lp = sm + (threadIdx.x & 63);
+    float xs[8], ex[8], sum = 0.f; unsigned pk[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) { xs[i] = -0.37f * (float)((threadIdx.x * 7 + i * 13) % 29); ex[i] = 0.f; }
+    f32x16 accS[8];
+    f32x4 accO[16];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) accS[i][r] = 0.f;
+    for (int i = 0; i < 16; ++i) for (int r = 0; r < 4; ++r) accO[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {                      // the QK^T half
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(accS[s]) : "v"(a[s & 3]), "v"(b[s >> 1]));
+            if ((s & 1) == 0) a[4 + (s >> 1)] = lp[((s >> 1) * 64 + it * 7) & 4032];
+            asm volatile("v_exp_f32 %0, %1" : "=v"(ex[s & 7]) : "v"(xs[s & 7]));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(s + 4) & 7]));
+            if ((s & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(s >> 1) & 3]) : "v"(ex[s & 7]), "v"(ex[(s + 1) & 7]));
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                     // the P.V half: twice the instructions for the same FLOPs
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accO[s]) : "v"(a[s & 7]), "v"(b[(s >> 1) & 7]));
+            if ((s & 3) == 0) b[4 + (s >> 2)] = lp[((s >> 2) * 64 + it * 5) & 4032];
+            if ((s & 1) == 0) {
+                const int q = s >> 1;
+                asm volatile("v_exp_f32 %0, %1" : "=v"(ex[q & 7]) : "v"(xs[q & 7]));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(q + 4) & 7]));
+                if ((q & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(q >> 1) & 3]) : "v"(ex[q & 7]), "v"(ex[(q + 1) & 7]));
+            }
+        }
+        for (int f = 0; f < 4; ++f) { a[f] = a[4 + f]; }
+    }
+    float s = sum + (float)pk[0] + (float)pk[1] + (float)pk[2] + (float)pk[3];
+    for (int i = 0; i < 8; ++i) s += accS[i][0];
+    for (int i = 0; i < 16; ++i) s += accO[i][0];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+void run_mix(const char* name, const u32x4* src, float* out) {
+    const int iters = 40000;                                  // 16 x 32x32x16-equivalents per iteration, as run<32, .>
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kmix, dim3(256), dim3(256), 0, 0, src, out, iters / 10);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kmix, dim3(256), dim3(256), 0, 0, src, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 256.0 * 4 * iters * (8 * 32.0 * 32 * 16 * 2 + 16 * 16.0 * 16 * 32 * 2);
+        printf("%-58s %8.3f ms  %7.0f TFLOP/s\n", name, ms, fl / ms / 1e9);
+    }
+}
+
 template <int SHAPE, int LDS> void run(const char* name, const u32x4* src, float* out) {
     const int iters = SHAPE == 32 ? 40000 : 10000;           // 640 000 MFMAs of either shape's flop count ratio 2:1 -> equal FLOPs
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -97,6 +157,7 @@ int main() {
         snprintf(nm, sizeof nm, "16x16x32, %s operands, + ds_read_b128 per 4 MFMA", d); run<16, 1>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + softmax VALU stream", d); run<32, 2>(nm, src, out);
         snprintf(nm, sizeof nm, "16x16x32, %s, + LDS reads + softmax VALU stream", d); run<16, 2>(nm, src, out);
+        snprintf(nm, sizeof nm, "MIXED 32x32x16 (QK^T) + 16x16x32 (P.V), %s, + LDS + softmax", d); run_mix(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with HALF the v_exp", d); run<32, 3>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with NO v_exp", d); run<32, 4>(nm, src, out);
     }

@@ -51,7 +51,14 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
     klen, kl_dev = None, None
     if k_lens is not None:
         if torch.is_tensor(k_lens) and k_lens.is_cuda:
-            kl_dev = k_lens.to(torch.int32).contiguous()             # stays on the device: no host read of the lengths
+            # Lengths that live on the device are never read by the host (no sync), so they cannot be validated here the way a
+            # host list is (ValueError below): the kernel CLAMPS -- a length above Lk attends Lk keys, a length <= 0 gives a zero
+            # row block -- and lengths are taken as int32 (Lk < 2^31 always).  What can be checked without a sync is checked:
+            if k_lens.device != q.device:
+                raise ValueError(f"k_lens lives on {k_lens.device}, q on {q.device}")
+            if k_lens.dtype not in (torch.int32, torch.int64) or k_lens.dim() != 1:
+                raise ValueError(f"k_lens must be a 1-D int32 / int64 tensor, got {k_lens.dtype} with shape {tuple(k_lens.shape)}")
+            kl_dev = k_lens.clamp(min=-1, max=Lk).to(torch.int32).contiguous()      # clamp BEFORE the narrowing cast: no int64 wrap-around
         else:
             kl = [int(x) for x in (k_lens.tolist() if torch.is_tensor(k_lens) else k_lens)]
             if len(kl) != B or min(kl) < 0 or max(kl) > Lk:

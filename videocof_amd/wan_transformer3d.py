@@ -766,6 +766,8 @@ class WanTransformer3DModel(nn.Module):
             self._graph_epoch += 1
         self._bufs_last = None
         self._ctx_cache = None
+        # (the composites re-read the GEMM workspace address on every call: `_block_cws`)
+        ops.release_gemm_workspaces(include_capture=not keep_pinned)
 
     def _run_block(self, blk: _Block, em, xs, bufs, ctx_kv, rp, B, Ll, L, seq_len):
         """One WanAttentionBlock (:464-515) in place on the fp32 residual stream xs [B*Ll, C].
@@ -792,10 +794,12 @@ class WanTransformer3DModel(nn.Module):
             nonlocal qe, ke
             if not (self.fp8_attn_calibrate and "attn_exp" not in f8) or torch.cuda.is_current_stream_capturing():
                 return
-            kc = k_bf16.float()
+            # over the L valid rows of every sample only (pad rows [L, Ll) are never attended; the sequence-parallel path below
+            # measures the same rows, so both paths pick the exponents of the same operands)
+            kc = k_bf16.float().view(B, rows_per_batch, -1)[:, :L]
             if mean is not None:
-                kc = kc.view(mean.shape[0], rows_per_batch, -1) - mean[:, None, :].float()
-            aq, ak = float(q_bf16.float().abs().max()), float(kc.abs().max())
+                kc = kc - mean[:, None, :].float()
+            aq, ak = float(q_bf16.float().view(B, rows_per_batch, -1)[:, :L].abs().max()), float(kc.abs().max())
             pick = lambda a: int(max(-8, min(8, math.floor(math.log2(448.0 / max(a, 1e-30))) - 1)))
             qe, ke = pick(aq), pick(ak)
             f8["attn_exp"] = (qe, ke)
@@ -896,7 +900,13 @@ class WanTransformer3DModel(nn.Module):
                 mean = None
                 if self.fp8_attn_smooth_k:
                     mean = ops.col_mean(k2d, Lt, L, 1, out=bufs.kmean.view(-1)[:B * Cl].view(1, B * Cl), workspace=bufs.kmean_ws)
-                if self.fp8_attn_calibrate and "attn_exp" not in f8 and not torch.cuda.is_current_stream_capturing():
+                # Whether to enter the collective below must be decided by state that is THE SAME ON EVERY RANK, or the ranks dead-lock:
+                # `fp8_attn_calibrate` (set by enable_fp8_linear, which every rank calls alike) and "attn_exp_agreed" (set only here,
+                # by the collective itself) -- not by a rank-local preset of "attn_exp" or by whether this rank happens to be capturing.
+                if self.fp8_attn_calibrate and not f8.get("attn_exp_agreed"):
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("fp8 attention under sequence parallelism calibrates its exponents on the first EAGER forward "
+                                           "(one all-reduce per layer); run one before capturing a graph")
                     # per-layer exponents, agreed by the ranks: each rank holds other heads, so the operands' maxima are reduced
                     # (max) over the group -- the pair every rank then uses is the one a single device would have measured
                     for w_ in q_waits:
@@ -908,8 +918,10 @@ class WanTransformer3DModel(nn.Module):
                         amax = sp.all_reduce_max(amax)
                     aq, ak = (float(v) for v in amax.tolist())
                     pick = lambda a_: int(max(-8, min(8, math.floor(math.log2(448.0 / max(a_, 1e-30))) - 1)))
-                    qe, ke = pick(aq), pick(ak)
-                    f8["attn_exp"] = (qe, ke)
+                    if "attn_exp" not in f8:            # (a preset pair stays: exponents need not agree across ranks for correctness)
+                        qe, ke = pick(aq), pick(ak)
+                        f8["attn_exp"] = (qe, ke)
+                    f8["attn_exp_agreed"] = True
                 k8w = bufs.k8.view(-1)[:Lt * B * Cl]
                 ops.qk_quantize_fp8(None, k2d, Lt, mean, 1.0, 2.0 ** ke, None, k8w)
                 k8_all = k8w.view(Lt, B, Cl).permute(1, 0, 2)
@@ -1026,8 +1038,12 @@ class WanTransformer3DModel(nn.Module):
         # the Python launch sequence run the SAME kernels and stay bit-identical); sized by the widest Linear of the block
         M = B * Ll
         gws = None
-        for (n_, k_) in ((2 * self.dim, self.dim), (self.ffn_dim, self.dim), (self.dim, self.ffn_dim), (self.dim, self.dim)):
-            t = ops.gemm_workspace(self._device, M, n_, k_)
+        # every GEMM shape of wan_dit_block_forward: the four per-token Linears at M = B * Ll and the V^T projection, which runs per
+        # sample at M = L valid tokens (a smaller M can ask for MORE workspace: the split-K form of small shapes) -- the composite must
+        # never fall back to another kernel than the per-op path takes (ops.gemm sizes its own request), or the two stop being bit-identical
+        for (m_, n_, k_) in ((M, 2 * self.dim, self.dim), (M, self.ffn_dim, self.dim), (M, self.dim, self.ffn_dim), (M, self.dim, self.dim),
+                             (L, self.dim, self.dim)):
+            t = ops.gemm_workspace(self._device, m_, n_, k_)
             if t is not None and (gws is None or t.numel() > gws.numel()):
                 gws = t
         holder.cws.gemm_ws = gws.data_ptr() if gws is not None else None
