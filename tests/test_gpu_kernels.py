@@ -203,6 +203,46 @@ def test_attention_seam_vs_oracle(B, Lq, Lk, H, qs):
     assert float((out.float().cpu() - ref).abs().max()) < 4e-2
 
 
+def test_cross_attention_persistent_form_walks_many_blocks():
+    """Short key streams (cross-attention: 512 text rows = 8 KV tiles) run on the PERSISTENT form of the 4-wave kernel as soon as a
+    launch has more query blocks than the chip has CUs: one resident workgroup per CU walks blocks w, w + grid, ... with the next
+    block's K / V requests and Q fragments issued before the current block's output stores (csrc/attn_fwd.hip, PERSIST).  Checked:
+    against the oracle (ragged last block: Lq % 256 != 0; B = 2; heads pinned to XCDs), bit for bit against the one-workgroup-per-block
+    launch of the same kernel family (tuning key attn_persist = 0), with a key count that ends inside the peeled last tile, plain
+    (not pre-scaled) q -- the packed-shift form -- and ragged per-sample key counts from device memory."""
+    g = torch.Generator().manual_seed(11)
+    B, Lq, Lk, H = 2, 256 * 20 + 37, 512, 8           # 21 query blocks x 16 (batch, head) pairs = 336 workgroups' worth of blocks
+    q = bf(torch.randn(B, Lq, H, 128, generator=g) * 2.0)
+    k = bf(torch.randn(B, Lk, H, 128, generator=g))
+    v = bf(torch.randn(B, Lk, H, 128, generator=g) + torch.arange(128) * 0.01)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    assert ops.get_tuning("attn_persist") == 1
+    out = attention(qd, kd, vd)
+    ref = _attn_ref(q, k, v)
+    assert rel_l2(out, ref) < 6e-3 and float((out.float().cpu() - ref).abs().max()) < 4e-2
+    again = attention(qd, kd, vd)
+    assert torch.equal(out, again)                      # run to run (a block that started before its requests landed would differ)
+    out300 = attention(qd, kd, vd, k_lens=torch.tensor([300, 300]))
+    ragged = attention(qd, kd, vd, k_lens=torch.tensor([300, 77], device=DEV))
+    # pre-scaled q through the raw op (the form the DiT uses): [B, L, C] operands, V^T
+    qs = (qd.float() * (128 ** -0.5) * 1.4426950408889634).bfloat16().reshape(B, Lq, H * 128)
+    vt = torch.zeros(B, H * 128, Lk, device=DEV, dtype=torch.bfloat16)
+    for b in range(B):
+        ops.transpose_pad(vd[b].reshape(Lk, H * 128), Lk, out=vt[b])
+    pre = ops.attention_fwd(qs, kd.reshape(B, Lk, H * 128), vt, H, q_prescaled=True)
+    ops.set_tuning("attn_persist", 0)
+    try:
+        assert torch.equal(attention(qd, kd, vd), out), "persistent form != one workgroup per block"
+        assert torch.equal(attention(qd, kd, vd, k_lens=torch.tensor([300, 300])), out300)
+        assert torch.equal(attention(qd, kd, vd, k_lens=torch.tensor([300, 77], device=DEV)), ragged)
+        assert torch.equal(ops.attention_fwd(qs, kd.reshape(B, Lk, H * 128), vt, H, q_prescaled=True), pre)
+    finally:
+        ops.set_tuning("attn_persist", 1)
+    assert rel_l2(out300, _attn_ref(q, k, v, 300)) < 6e-3
+    assert rel_l2(ragged[1:], _attn_ref(q[1:], k[1:], v[1:], 77)) < 6e-3
+    assert rel_l2(pre.view(B, Lq, H, 128), ref) < 8e-3
+
+
 def test_attention_k_lens_masks_keys_and_q_lens_zero_rows():
     g = torch.Generator().manual_seed(3)
     q, k, v = (bf(torch.randn(2, 200, 2, 128, generator=g)) for _ in range(3))

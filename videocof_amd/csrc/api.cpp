@@ -72,6 +72,7 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"sp_inline", "WAN_SP_INLINE", 0},                  // library communicator: 1 = every collective on the caller's stream itself (no side stream); 0 = only while that stream is being captured
     {"gemm_splitk", "WAN_GEMM_SPLITK", 1},              // split-K form of the 128^2 GEMM for small shapes that bring a workspace: 1 = by shape, 0 = never, 2..8 = force that many pieces (developer A/B)
     {"conv_mfma", "WAN_CONV_MFMA", 0},                  // matrix instruction of the VAE's LDS-patch convolution: 0 = by the per-frame plane (16x16x32 when four frames of it fill the chip; never by frame count -- chunked decodes stay bit-identical), 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16
+    {"attn_persist", "WAN_ATTN_PERSIST", 1},            // short-KV (cross-attention) launches on the persistent form of the 4-wave kernel: one resident workgroup per CU walks the query blocks (0 = one workgroup per block, developer A/B)
 };
 struct Tuning {
     std::atomic<int> v[WAN_TUNE_COUNT];

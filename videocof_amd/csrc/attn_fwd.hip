@@ -37,8 +37,8 @@ namespace {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kD = 128;          // head dim
-constexpr int kQPerWave = 32;
-constexpr int kWavesPerWG = 8;
+constexpr int kQPerWave = 64;    // two 32-query blocks per wave
+constexpr int kWavesPerWG = 4;   // one wave per SIMD
 constexpr int kQPerWG = kQPerWave * kWavesPerWG;   // 256
 constexpr int kKV = 64;          // keys per tile
 constexpr int kThreads = kWavesPerWG * 64;
@@ -62,6 +62,7 @@ struct AttnArgs {
     // (head, z) pair bh = 8 * ((w >> 3) / nqb) + (w & 7) pins every head to one XCD, whose 32 CUs walk that head's query
     // blocks together: one head's K / V^T (34 MB at L = 67 080) streams through ONE 4 MB L2 instead of all eight.
     int nqb, nbh, xcd_map;
+    int nwg;              // nqb * nbh: the blocks a PERSIST launch walks (its grid is one workgroup per CU)
     // QK8 form (wan_attention_fwd_qk8): q, k as OCP e4m3 bytes [rows][H*128], pre-multiplied by powers of two; the MFMA
     // applies the inverse (q8_scale / k8_scale: the E8M0 byte 127 - exponent, replicated into all four bytes)
     const unsigned char* q8; int64_t ldq8, q8_bs;
@@ -180,10 +181,19 @@ constexpr float kW4Trigger = 0x1p40f;
 //      K tile image: [64 keys][128 B], chunk' = chunk ^ ((row >> 1) & 7) (the V^T image's swizzle), 2 DMA pieces per wave; a lane's
 //      A fragment (kt, dh) = the 32 bytes d = 64 dh + 32 hi .. + 31 of key pi(lane & 31) + 32 kt, read as two ds_read_b128 (which k of
 //      the MFMA a byte lands on does not matter here: q and k use the same order and the operand scales are uniform).
-template <int VARIANT, bool SPLIT, int REF, bool FIX = false, bool QK8 = false>
+// PERSIST (round 6; the cross-attention launch, VARIANT 1): ONE resident workgroup per CU walks query blocks w = blockIdx, blockIdx +
+// grid, ... instead of one workgroup per block.  A cross-attention block is only 8 KV tiles (512 text rows): per block the one-shot
+// form spends as long in what surrounds the tiles -- dispatch, the Q fragments' trip from HBM, K(0) / V(0) landing, 32 output stores
+// per lane draining -- as in the tiles themselves (0.99 ms per launch = 0.28 of peak).  Here the NEXT block's K(0) / V(0) / K(1)
+// requests and its Q fragment loads are issued before the current block's output stores (Q's registers are dead by then; vector memory
+// operations complete in issue order, so `s_waitcnt vmcnt(16)` at the top of the next block waits for exactly those requests and
+// leaves the 16 stores in flight), and the stores go through a per-block buffer descriptor whose range check drops rows >= Lq -- every
+// lane always issues all 16 (16 bytes each, after the two lanes of a row have traded halves), which is what makes the count exact.
+template <int VARIANT, bool SPLIT, int REF, bool FIX = false, bool QK8 = false, bool PERSIST = false>
 __global__ __launch_bounds__(kW4Threads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd_w4_kernel(AttnArgs a) {
     constexpr bool MAXFREE = REF == 0, SPLAT = REF == 1, PKSUB = REF == 2;
+    static_assert(!PERSIST || (!SPLIT && !FIX && !QK8 && !MAXFREE), "the persistent form is the plain lazy-reference kernel");
     static_assert(!QK8 || (SPLAT && VARIANT == 0), "the fp8 QK^T form is the self-attention lazy-reference kernel");
     static_assert(!(SPLIT && MAXFREE), "the split tail round runs the lazy-reference form");
     static_assert(!FIX || (!SPLIT && !MAXFREE), "the fix-up launch is the unsplit lazy-reference form");
@@ -205,58 +215,80 @@ void attn_fwd_w4_kernel(AttnArgs a) {
             return;
         }
     }
-    int qblk, bh;
-    if (a.xcd_map) {
-        const int s_ = wg_linear >> 3, g_ = s_ / a.nqb;
-        qblk = s_ - g_ * a.nqb;
-        bh = g_ * 8 + (wg_linear & 7);
-    } else {
-        bh = wg_linear / a.nqb;
-        qblk = wg_linear - bh * a.nqb;
-    }
-    const int bz = bh / a.H, head = bh - bz * a.H;
-    const int batch = SPLIT ? bz / a.nsplit : bz;
-    const int split = SPLIT ? bz - batch * a.nsplit : 0;
-    const int t0 = split * a.tiles_per_split;                     // first KV tile of this split
-    if constexpr (SPLIT) qblk += a.qblk0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    int Lk;
-    if constexpr (SPLIT) Lk = min(a.Lk - t0 * kKV, a.tiles_per_split * kKV);
-    else Lk = a.klens != nullptr ? max(1, min(a.klens[batch], a.Lk)) : a.Lk;        // scalar: one s_load per workgroup
-    const bf16_t* Q = a.q + batch * a.q_bs + head * kD;
-    const bf16_t* K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
-    const unsigned char* K8 = QK8 ? a.k8 + batch * a.k8_bs + head * kD + (int64_t)t0 * kKV * a.ldk8 : nullptr;
-    const bf16_t* VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt + t0 * kKV;
-    bf16_t* O = a.o + batch * a.o_bs + head * kD;
+    // ---- the query block this workgroup works on (PERSIST: re-evaluated for every block it walks).  Everything below that depends on
+    // the block -- operand origins, key count, the Q fragments -- is state that `setup_block` / `load_q` rewrite.
+    int qblk, batch, head, split, t0, Lk, nkv;
+    const bf16_t *Q, *K, *VT;
+    const unsigned char* K8;
+    bf16_t* O;
+    auto setup_block = [&](int w) __attribute__((always_inline)) {
+        int bh;
+        if (a.xcd_map) {
+            const int s_ = w >> 3, g_ = s_ / a.nqb;
+            qblk = s_ - g_ * a.nqb;
+            bh = g_ * 8 + (w & 7);
+        } else {
+            bh = w / a.nqb;
+            qblk = w - bh * a.nqb;
+        }
+        const int bz = bh / a.H;
+        head = bh - bz * a.H;
+        batch = SPLIT ? bz / a.nsplit : bz;
+        split = SPLIT ? bz - batch * a.nsplit : 0;
+        t0 = split * a.tiles_per_split;                     // first KV tile of this split
+        if constexpr (SPLIT) qblk += a.qblk0;
+        if constexpr (SPLIT) Lk = min(a.Lk - t0 * kKV, a.tiles_per_split * kKV);
+        else Lk = a.klens != nullptr ? max(1, min(a.klens[batch], a.Lk)) : a.Lk;        // scalar: one s_load per workgroup
+        nkv = (Lk + kKV - 1) / kKV;
+        Q = a.q + batch * a.q_bs + head * kD;
+        K = a.k + batch * a.k_bs + head * kD + (int64_t)t0 * kKV * a.ldk;
+        K8 = QK8 ? a.k8 + batch * a.k8_bs + head * kD + (int64_t)t0 * kKV * a.ldk8 : nullptr;
+        VT = a.vt + batch * a.vt_bs + (int64_t)head * kD * a.ldvt + t0 * kKV;
+        O = a.o + batch * a.o_bs + head * kD;
+    };
+    setup_block(wg_linear);
 
     // ---- Q fragments of the wave's two query blocks (B operands of S^T = K.Q^T), kept in AGPRs by the "a" constraints
     int qrow[2];
     u32x4 qf[2][8];
     i32x8 qf8[2][2];            // QK8: B operands, 32 e4m3 per lane and d half (d = 64 dh + 32 hi .. + 31)
+    auto load_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        qrow[qb] = qblk * kQPerWG + wid * 64 + qb * 32 + l31;
-        if constexpr (QK8) {
-            const unsigned char* qp = a.q8 + batch * a.q8_bs + head * kD + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq8 + hi * 32;
+        for (int qb = 0; qb < 2; ++qb) {
+            qrow[qb] = qblk * kQPerWG + wid * 64 + qb * 32 + l31;
+            if constexpr (QK8) {
+                const unsigned char* qp = a.q8 + batch * a.q8_bs + head * kD + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq8 + hi * 32;
 #pragma unroll
-            for (int dh = 0; dh < 2; ++dh) {
-                const u32x4 lo = *reinterpret_cast<const u32x4*>(qp + dh * 64), up = *reinterpret_cast<const u32x4*>(qp + dh * 64 + 16);
-                qf8[qb][dh] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+                for (int dh = 0; dh < 2; ++dh) {
+                    const u32x4 lo = *reinterpret_cast<const u32x4*>(qp + dh * 64), up = *reinterpret_cast<const u32x4*>(qp + dh * 64 + 16);
+                    qf8[qb][dh] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)up[0], (int)up[1], (int)up[2], (int)up[3]};
+                }
+            } else {
+                const bf16_t* qp = Q + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq + hi * 8;
+                if constexpr (PERSIST) {
+                    // asm loads, invisible to hipcc's waitcnt bookkeeping ON PURPOSE: tracked, the first use of every fragment gets a
+                    // wait sized for the worst predecessor (the first block, where only the K / V requests follow the loads) and the
+                    // S(0) product of every later block then waits for most of the previous block's output stores.  The loads are
+                    // older than those stores; the `s_waitcnt vmcnt(16)` (vmcnt(0) for the first block) at the top of the block covers them.
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(qf[qb][ks]) : "v"(qp), "i"(ks * 32) : "memory");
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+                }
             }
-        } else {
-            const bf16_t* qp = Q + (int64_t)min(qrow[qb], a.Lq - 1) * a.ldq + hi * 8;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
         }
-    }
+    };
+    load_q();
     char* const kring = smem;
     // ---- staging: this wave copies pieces 4*wid .. 4*wid+3 (1 KiB each) of every K and V^T tile
-    const int nkv = (Lk + kKV - 1) / kKV;
     // K / V^T tiles are fetched with `buffer_load_dwordx4 ... lds` (LDS-DMA through a buffer descriptor): the tile origin
     // is SCALAR state (descriptor base advanced per tile by SALU), each lane keeps one constant 32-bit byte offset per
     // piece, and the descriptor's range check returns zeros for K rows >= Lk (they are masked in the peeled last tile)
@@ -277,12 +309,12 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     }
     const int64_t k_row_bytes = QK8 ? a.ldk8 : a.ldk * 2;
     const int64_t k_tile_bytes = (int64_t)kKV * k_row_bytes;
-    const char* const k_origin = QK8 ? (const char*)K8 : (const char*)K;
     // (a.tile_mask: 0x7fffffff in product; the developer experiment attn_exp & 1 sets 15, so that the staging re-reads tiles 0..15
     // and every K / V^T tile is L2-resident -- TIMING / COUNTERS ONLY, the results are garbage: what the fabric traffic costs in clock)
     auto k_rsrc = [&](int t) {          // tile min(t, nkv-1): a request past the end re-stages the last tile into a dead slot
         const int tc = min(t, nkv - 1) & a.tile_mask;
         const int64_t left = (int64_t)(Lk - tc * kKV) * k_row_bytes;             // bytes from the tile origin to the end of row Lk-1
+        const char* const k_origin = QK8 ? (const char*)K8 : (const char*)K;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(k_origin + tc * k_tile_bytes), 0,
                                                  (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
@@ -321,6 +353,23 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) v_adr[t] = lds_base + 2 * kKTileBytes + v_rowoff + (((2 * t + hi) ^ v_sw) << 4);
 
+    auto fence = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    };
+    // ---- prologue requests: K(0), V(0), K(1) of the block `setup_block` last described
+    auto stage_prologue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { stage_k_piece(k_rsrc(0), 0, j); stage_v_piece(v_rsrc(0), 0, j); }
+        if (nkv > 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stage_k_piece(k_rsrc(1), 1, j);
+        }
+    };
+    stage_prologue();
+    int w_cur = wg_linear;              // PERSIST: the block being worked on
+    bool first_block = true;            // PERSIST: no output stores of a previous block are in flight
+  for (;;) {                            // PERSIST: one iteration per query block of this workgroup; otherwise a single pass
     f32x16 o[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -330,19 +379,17 @@ void attn_fwd_w4_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
     float l_run[2] = {0.f, 0.f};
 
-    auto fence = [&]() {
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-    };
-
     // ---- prologue: K(0), V(0), K(1) in flight; S(0)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { stage_k_piece(k_rsrc(0), 0, j); stage_v_piece(v_rsrc(0), 0, j); }
-    if (nkv > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) stage_k_piece(k_rsrc(1), 1, j);
+    if constexpr (PERSIST) {
+        // the requests of THIS block were issued before the previous block's 16 output stores: wait for them, not for the stores
+        // (a bare s_barrier: __syncthreads() is a workgroup release fence as well, i.e. `s_waitcnt vmcnt(0)` -- it would wait for the stores)
+        if (first_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        fence();
     }
-    fence();
     f32x16 s0[2][2], s1[2][2];
 // "=&v": an 8-pass MFMA reads A/B over several passes, so D must not share registers with them (hipcc marks its own
 // MFMAs early-clobber for the same reason)
@@ -714,6 +761,46 @@ void attn_fwd_w4_kernel(AttnArgs a) {
             const int bad = __syncthreads_or(!ok);
             if (tid == 0) a.flags[wg_linear] = bad;
         }
+        if constexpr (PERSIST) {
+            // this block's output window: rows [256 qblk, min(Lq, 256 qblk + 256)) of this head, as a buffer whose range check drops
+            // the rows past Lq -- every lane issues all 16 stores whatever its row (the count the next block's vmcnt(16) relies on)
+            const int rows_here = min(a.Lq - qblk * kQPerWG, kQPerWG);
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(O + (int64_t)qblk * kQPerWG * a.ldo), 0, (int)((((int64_t)rows_here - 1) * a.ldo + kD) * 2), 0x00020000);
+            int ovoff[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) ovoff[qb] = (int)((((int64_t)(wid * 64 + qb * 32 + l31)) * a.ldo + 8 * hi) * 2);
+            const int w_next = w_cur + (int)gridDim.x;
+            const bool more = w_next < a.nwg;
+            __syncthreads();                              // every wave has read its last fragments: the ring is free
+            if (more) {                                   // the next block's requests go out BEFORE this block's stores
+                setup_block(w_next);
+                stage_prologue();
+                load_q();
+            }
+            asm volatile("" ::: "memory");
+            // 16-byte stores: a lane (row q, half hi) holds d = 32 dt + 8 g + 4 hi .. + 3; the two lanes of a row trade one 8-byte
+            // piece per g pair (v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second), after which lane
+            // hi owns the 8 consecutive d = 32 dt + 16 m + 8 hi .. + 7 -- 16 stores of 16 bytes per lane instead of 32 of 8
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        unsigned w0 = pack_bf16x2(o[qb][dt][8 * m + 0] * inv[qb], o[qb][dt][8 * m + 1] * inv[qb]);
+                        unsigned w1 = pack_bf16x2(o[qb][dt][8 * m + 2] * inv[qb], o[qb][dt][8 * m + 3] * inv[qb]);
+                        unsigned w2 = pack_bf16x2(o[qb][dt][8 * m + 4] * inv[qb], o[qb][dt][8 * m + 5] * inv[qb]);
+                        unsigned w3 = pack_bf16x2(o[qb][dt][8 * m + 6] * inv[qb], o[qb][dt][8 * m + 7] * inv[qb]);
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                        const u32x4 w = {w0, w1, w2, w3};
+                        __builtin_amdgcn_raw_buffer_store_b128(w, orsrc, ovoff[qb] + (32 * dt + 16 * m) * 2, 0, 0);
+                    }
+            if (!more) break;
+            w_cur = w_next;
+            first_block = false;
+            continue;
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if (qrow[qb] >= a.Lq) continue;
@@ -728,6 +815,8 @@ void attn_fwd_w4_kernel(AttnArgs a) {
                 }
         }
     }
+    break;
+  }
 }
 
 // ====================================================================================================
@@ -1400,6 +1489,7 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     a.xcd_map = plan.xcd ? 1 : 0;
     const int64_t nwg = (int64_t)a.nqb * a.nbh;
     WAN_REQUIRE(nwg < (int64_t)1 << 31, WAN_ERR_UNSUPPORTED, "wan_attention_fwd: grid too large");
+    a.nwg = (int)nwg;
     dim3 grid((unsigned)nwg);
     const bool ref2 = plan.ref2;
     const dim3 block4(kW4Threads);
@@ -1414,11 +1504,17 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
         hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1, false, true>), grid, block4, kLdsBytesW4, st, a);
     } else if (!fast) {               // lazy-reference 4-wave kernel, one launch: any q form, scratch or not, no input-dependent path
         variant = WAN_ATTN_VARIANT_W4_LAZY;
+        // short KV streams (cross-attention: 8 tiles per query block): ONE resident workgroup per CU walks the blocks (PERSIST, see the
+        // kernel); the grid stays a multiple of 8 so that w & 7 -- the XCD a head is pinned to -- is the same for every block of a workgroup
+        const bool persist = !self && wan_tune(WAN_TUNE_ATTN_PERSIST) != 0 && nwg > (wan_cu_count() & ~7) && (wan_cu_count() & ~7) >= 8;
+        const dim3 pgrid(persist ? (unsigned)(wan_cu_count() & ~7) : (unsigned)nwg);
         if (ref2) {
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 2>), grid, block4, kLdsBytesW4, st, a);
+            else if (persist) hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 2, false, false, true>), pgrid, block4, kLdsBytesW4, st, a);
             else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 2>), grid, block4, kLdsBytesW4, st, a);
         } else {
             if (self) hipLaunchKernelGGL((attn_fwd_w4_kernel<0, false, 1>), grid, block4, kLdsBytesW4, st, a);
+            else if (persist) hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1, false, false, true>), pgrid, block4, kLdsBytesW4, st, a);
             else hipLaunchKernelGGL((attn_fwd_w4_kernel<1, false, 1>), grid, block4, kLdsBytesW4, st, a);
         }
     } else {                         // max-free attempt (2 % faster), then the lazy-reference kernel on the flagged workgroups only
