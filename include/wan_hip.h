@@ -42,9 +42,9 @@ int wan_abi_version(void);
 const char* wan_last_error(void);
 
 /* Developer switches (A/B harnesses, bring-up).  The matching environment variables (WAN_ATTN_TAIL, WAN_ATTN_FAST,
- * WAN_ATTN_XCD_MAP, WAN_ATTN_REF, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_EXP) are
+ * WAN_ATTN_XCD_MAP, WAN_ATTN_REF, WAN_GEMM_W4, WAN_GEMM_GM, WAN_GEMM_PHASES, WAN_GEMM_VARIANT, WAN_CONV_XCD, WAN_DEBUG_CHECKS, WAN_ATTN_PERSIST) are
  * read ONCE, at the first call into the library; the launch paths never call getenv().  Keys: "attn_tail",
- * "attn_fast", "attn_xcd_map", "attn_ref", "conv_head", "gemm_exp", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks", "attn_exp",
+ * "attn_fast", "attn_xcd_map", "attn_ref", "conv_head", "gemm_exp", "gemm_w4", "gemm_gm", "gemm_phases", "gemm_variant", "conv_xcd", "debug_checks",
  * "gemm_pk", "gemm_pk_form", "gemm_pk_workers", "gemm_pk_min_units", "gemm_pk_order", "gemm_splitk", "row_group", "sp_inline", "conv_patch", "attn_persist" (1: cross-attention on the persistent form of the 4-wave kernel), "conv_mfma" (0 = by the per-frame plane, 32 / 16 = force v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16).
  * "debug_checks" = 1 turns on SYNCHRONISING contract checks (V^T pad columns of wan_attention_fwd are finite).
  * wan_set_tuning is an atomic store: safe against concurrent launches, which see the old or the new value.

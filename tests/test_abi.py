@@ -100,7 +100,7 @@ def test_tuning_switches_are_read_once_and_settable():
     (the launch paths never call getenv)."""
     lib = _lib.load()
     for key, default in (("attn_tail", 1), ("attn_fast", 1), ("attn_xcd_map", 1), ("gemm_gm", 0), ("gemm_phases", 0),
-                         ("gemm_variant", 0), ("conv_xcd", 1), ("debug_checks", 0), ("attn_exp", 0), ("attn_ref", 1), ("gemm_w4", 1), ("conv_fast", 1), ("conv_patch", 1), ("conv_head", 1), ("gemm_exp", 0)):
+                         ("gemm_variant", 0), ("conv_xcd", 1), ("debug_checks", 0), ("attn_persist", 1), ("attn_ref", 1), ("gemm_w4", 1), ("conv_fast", 1), ("conv_patch", 1), ("conv_head", 1), ("gemm_exp", 0)):
         assert lib.wan_get_tuning(key.encode()) == default, key
     assert lib.wan_set_tuning(b"attn_tail", 0) == _lib.WAN_OK and lib.wan_get_tuning(b"attn_tail") == 0
     os.environ["WAN_ATTN_TAIL"] = "7"                    # too late: not consulted again

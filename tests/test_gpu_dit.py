@@ -455,6 +455,11 @@ def test_pipeline_bf16_mode_runs_and_is_close(golden, model):
                weight_dtype=torch.bfloat16)
     assert out.latents.dtype == torch.bfloat16
     assert rel_l2(out.latents.float(), g["steps"][3]) < 4e-2
+    # `timesteps=`: with the UniPC scheduler the reference never reads it (pipeline_wan.py:613-615) -- accepted and ignored, same bits
+    again = pipe(latents=lat, prompt_embeds=[torch.from_numpy(g["ctx"]).to(DEV)], source_frames=9, reasoning_frames=4,
+                 num_inference_steps=4, guidance_scale=1.0, shift=3, repeat_rope=True, cot=True, output_type="latent",
+                 weight_dtype=torch.bfloat16, timesteps=[900, 500, 100, 10])
+    assert torch.equal(again.latents, out.latents)
 
 
 def test_wider_model_3_heads_vs_oracle():

@@ -67,6 +67,46 @@ def test_attention_w4_main_loop_is_clean(attn_asm, mangled, what):
     assert packed == (64 if "packed" in what else 0)
 
 
+@pytest.mark.parametrize("mangled", ["attn_fwd_w4_kernelILi1ELb0ELi1ELb0ELb0ELb1E", "attn_fwd_w4_kernelILi1ELb0ELi2ELb0ELb0ELb1E"])
+def test_cross_attention_persistent_form_counts_its_stores(attn_asm, mangled):
+    """The persistent cross-attention kernel (PERSIST): the next block's K / V requests and Q fragment loads are issued BEFORE the current
+    block's output stores, and `s_waitcnt vmcnt(16)` at the top of the next block waits for exactly those -- which is only right if the
+    kernel issues EXACTLY 16 vector-memory instructions after them: 16 buffer_store_dwordx4 (range-checked by their descriptor, never
+    branched around), no other store form, and nothing compiler-tracked in between.  The Q fragments arrive through untracked asm loads
+    straight into AGPRs: no instruction but those loads and the MFMAs may name those registers (a copy would read them too early)."""
+    body = _kernel(attn_asm, mangled)
+    meta = "\n".join(attn_asm)
+    priv = re.search(re.escape(mangled) + r"\w*\.private_seg_size, (\d+)", meta)
+    assert priv and int(priv.group(1)) == 0
+    code = [l for l in body if re.match(r"\s+[a-z]", l)]
+    assert sum("buffer_store_dwordx4" in l for l in code) == 16
+    assert not any(re.match(r"\s+(buffer_store_dwordx2|global_store|flat_store)", l) for l in code)
+    assert sum("s_waitcnt vmcnt(16)" in l for l in code) == 1
+    loads = [l for l in code if re.match(r"\s+global_load_dwordx4 a\[", l)]
+    assert len(loads) == 32                               # 16 for the first block + 16 at the end of every block for the next one
+    regs = set()
+    for l in loads:
+        m = re.search(r"a\[(\d+):(\d+)\]", l)
+        regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    assert len(regs) == 64
+
+    def named(l):
+        out = set()
+        for m in re.finditer(r"a\[(\d+):(\d+)\]", l):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\ba(\d+)\b", l):
+            out.add(int(m.group(1)))
+        return out
+    others = [l.strip() for l in code if (named(l) & regs) and "global_load_dwordx4" not in l and "v_mfma" not in l]
+    assert not others, others[:5]
+    # between the last of the in-loop Q loads and the end of the stores: stores, VALU, SALU only -- no other vector-memory instruction
+    i0 = max(i for i, l in enumerate(code) if re.match(r"\s+global_load_dwordx4 a\[", l))
+    i1 = max(i for i, l in enumerate(code) if "buffer_store_dwordx4" in l)
+    assert i1 > i0
+    between = [l.strip() for l in code[i0 + 1:i1] if re.match(r"\s+(buffer_load|global_load|global_store|flat_|buffer_atomic|global_atomic)", l)]
+    assert not between, between[:5]
+
+
 @pytest.mark.parametrize("mangled,what", [("attn_fwd_w4_kernelILi0ELb0ELi1ELb0ELb1E", "fp8 QK^T"),
                                            ("attn_fwd_w4_kernelILi0ELb1ELi1ELb0ELb1E", "fp8 QK^T, split-KV tail")])
 def test_attention_qk8_main_loop_is_clean(attn_asm, mangled, what):

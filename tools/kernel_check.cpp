@@ -887,7 +887,7 @@ int main(int argc, char** argv) {
         fill(q);
         const int64_t wsb = wan_attention_workspace_bytes(1, L, Lk, H, 128);
         Dev<char> ws((size_t)std::max<int64_t>(wsb, 16)); ws.zero();
-        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_exp", "attn_ref"};
+        const char* keys[] = {"attn_tail", "attn_fast", "attn_xcd_map", "attn_persist", "attn_ref"};
         const int nkeys = 5;
         int defaults[5]; for (int i = 0; i < nkeys; ++i) defaults[i] = wan_get_tuning(keys[i]);
         for (int round = 0; round < 2; ++round)

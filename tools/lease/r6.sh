@@ -43,6 +43,43 @@ PY
     timeout 900 python tools/bench_ingest.py --layers 40 2>$out/ingest.err | json > $out/ingest_14b.json; cat $out/ingest_14b.json
     timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
     ;;
+  c)  # persistent cross-attention: numerics, A/B; the round's kernel changes against the pre-change library on ONE box; GPU suite
+    timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "cross_attention_persistent or attention" > $out/pytest_attn.log 2>&1; tail -3 $out/pytest_attn.log
+    timeout 600 python tools/bench_cross_attn.py > $out/cross_attn_persistent_ab.log 2>&1; cat $out/cross_attn_persistent_ab.log
+    OLD=$PWD/tools/exp_lib/libwan_hip_before_persistent_cross.so
+    for i in 1 2; do
+      timeout 400 $B --steps 4 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | json > $out/bench_new_$i.json
+      WAN_HIP_LIB=$OLD timeout 400 $B --steps 4 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | json > $out/bench_old_$i.json
+    done
+    python - $out <<'PY'
+import json, sys
+out = sys.argv[1]
+with open(out + "/step_ab_same_box.log", "w") as fo:
+    for tag in ("new_1", "old_1", "new_2", "old_2"):
+        try:
+            d = json.load(open(f"{out}/bench_{tag}.json"))
+            line = f"{tag}: {d['ms_per_step']:.2f} ms/step  value {d['value']:.0f}  normalised {d['value_normalised']:.0f}  attention {d['roofline']['avg_ms']:.3f} ms/launch  box {d['box']['mfma_mix_tflops']:.1f} TF (before {d['box']['before']['mfma_mix_tflops']:.1f} after {d['box']['after']['mfma_mix_tflops']:.1f})"
+        except Exception as e:
+            line = f"{tag}: no line ({e})"
+        print(line); fo.write(line + "\n")
+PY
+    PASSES="trace" bash tools/profile_bench.sh 14b_new > $out/prof_new.log 2>&1
+    WAN_HIP_LIB=$OLD PASSES="trace" bash tools/profile_bench.sh 14b_old > $out/prof_old.log 2>&1
+    python - <<'PY'
+import csv
+def load(p):
+    return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6) for r in csv.DictReader(open(p))}
+try:
+    n, o = load("gpurun_out/prof_14b_new/kernel_stats.csv"), load("gpurun_out/prof_14b_old/kernel_stats.csv")
+    tn, to = sum(v[2] for v in n.values()), sum(v[2] for v in o.values())
+    print(f"GPU time per 1-step run: new {tn:.1f} ms, old {to:.1f} ms")
+    for k in sorted(set(n) | set(o), key=lambda k: -(n.get(k, (0, 0, 0))[2] + o.get(k, (0, 0, 0))[2]))[:14]:
+        print(f"  {k[:110]:110s} new {n.get(k, (0, 0, 0))[1]:9.3f} ms x{n.get(k, (0, 0, 0))[0]:<4d} old {o.get(k, (0, 0, 0))[1]:9.3f} ms x{o.get(k, (0, 0, 0))[0]}")
+except Exception as e:
+    print("kernel stats comparison failed:", e)
+PY
+    timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'

@@ -12,7 +12,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwan_hip.so")
+# WAN_HIP_LIB: a developer A/B hook -- load ANOTHER build of the library (e.g. the tree of an earlier commit, tools/exp_lib/) through the
+# same binding, so that two builds can be timed back to back on one box.  Unset in every product / test / benchmark path.
+LIB_PATH = os.environ.get("WAN_HIP_LIB") or os.path.join(_HERE, "libwan_hip.so")
 ABI_VERSION = 10
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634

@@ -53,7 +53,6 @@ const TuningKey kTuningKeys[WAN_TUNE_COUNT] = {
     {"gemm_gm", "WAN_GEMM_GM", 0},              // M tiles per rasterisation group of the 256^2 GEMM (0 = by shape)
     {"gemm_phases", "WAN_GEMM_PHASES", 0},      // K-loop phasing of the 256^2 GEMM (0 = default)
     {"debug_checks", "WAN_DEBUG_CHECKS", 0},    // synchronising contract checks (V^T padding finite, ...)
-    {"attn_exp", "WAN_ATTN_EXP", 0},            // experiment selector of the attention kernel (0 = product path)
     {"gemm_variant", "WAN_GEMM_VARIANT", 0},    // 1 = force the 128^2 GEMM, 2 = force the 256^2 GEMM, 0 = by shape
     {"conv_xcd", "WAN_CONV_XCD", 1},            // XCD slab rasterisation of wan_conv_cl
     {"gemm_w4", "WAN_GEMM_W4", 1},              // 256^2 GEMM on the 4-wave kernel: 0 never, 1 K >= 4096, 2 K >= 8192, 3 whenever K % 128 == 0

@@ -75,8 +75,6 @@ struct AttnArgs {
     // packed ragged batches (wan_attention_fwd_varlen): keys of batch b end at klens[b] (device memory, clamped to [1, Lk]); NULL =
     // every batch attends Lk keys.  The reference packs such batches behind cu_seqlens (attention_utils.py:95-146)
     const int* klens;
-    int tile_mask;        // developer experiment (attn_exp & 1): staging reads tile (t & tile_mask); 0x7fffffff in product
-    int exp_nocheck;      // developer experiment (attn_exp & 2), TIMING ONLY: the lazy form skips its per-tile window check
 };
 
 // VARIANT (template parameter of the kernels below) only names the instantiation so profiles separate the two
@@ -309,17 +307,15 @@ void attn_fwd_w4_kernel(AttnArgs a) {
     }
     const int64_t k_row_bytes = QK8 ? a.ldk8 : a.ldk * 2;
     const int64_t k_tile_bytes = (int64_t)kKV * k_row_bytes;
-    // (a.tile_mask: 0x7fffffff in product; the developer experiment attn_exp & 1 sets 15, so that the staging re-reads tiles 0..15
-    // and every K / V^T tile is L2-resident -- TIMING / COUNTERS ONLY, the results are garbage: what the fabric traffic costs in clock)
     auto k_rsrc = [&](int t) {          // tile min(t, nkv-1): a request past the end re-stages the last tile into a dead slot
-        const int tc = min(t, nkv - 1) & a.tile_mask;
+        const int tc = min(t, nkv - 1);
         const int64_t left = (int64_t)(Lk - tc * kKV) * k_row_bytes;             // bytes from the tile origin to the end of row Lk-1
         const char* const k_origin = QK8 ? (const char*)K8 : (const char*)K;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(k_origin + tc * k_tile_bytes), 0,
                                                  (int)min(left, (int64_t)0x7fffffff), 0x00020000);
     };
     auto v_rsrc = [&](int t) {          // tile min(t, nkv-1) (t <= nkv - 1 on every call); V^T pad columns exist up to roundup(Lk, 64)
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)(min(t, nkv - 1) & a.tile_mask) * kKV * 2), 0, 0x7fffffff, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + (int64_t)min(t, nkv - 1) * kKV * 2), 0, 0x7fffffff, 0x00020000);
     };
     auto stage_k_piece = [&](__amdgpu_buffer_rsrc_t r, int kslot, int j) {
         if constexpr (QK8) {
@@ -585,7 +581,10 @@ void attn_fwd_w4_kernel(AttnArgs a) {
                                 "i"(231 + 8 * (f)), "i"(kslot_next * kKTileBytes + ((f) & 1) * 32 * 128) : W8_KCLOB)
 #define QK8(qb, kt, dh, f, w) do { W4_LGKM(w); if ((dh) == 0) W8K_MFMA_C(sn[qb][kt], f, qf8[qb][0], negm[qb]); else W8K_MFMA_S(sn[qb][kt], f, qf8[qb][1]); SB(); } while (0)
 #define G8(j) do { if ((j) < 2) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 2); } while (0)
-#define MIDCHECK() do { if constexpr (!MAXFREE) { if (a.exp_nocheck == 0) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } } while (0)
+// (the always-true SCALAR test `a.nsplit >= 0` in front of the vector test is a code-generation workaround: it ends the basic block
+// ahead of the wave-wide compare, and only then does hipcc keep the loop free of accumulator <-> VGPR copies -- without it 7
+// v_accvgpr_read + 1 v_accvgpr_write appear per two tiles; tests/test_isa_static.py watches the loop's instruction histogram)
+#define MIDCHECK() do { if constexpr (!MAXFREE) { if (a.nsplit >= 0) { if (__builtin_expect(!__all(fmaxf(ps0, ps1) <= kW4Trigger), 0)) repair(sc, sn, pc, ps0, ps1); } } } while (0)
 #define PV(qb, dt, tt, f, w) do { if constexpr (MAXFREE) { if ((tt) < 2) W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pc[qb][(tt) & 1]); else W4_MFMA_O(o[qb][dt], vfr[(f) & 3], pf23[qb][(tt) & 1]); } \
                                   else { W4_LGKM(w); if ((tt) < kAhead) W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pc[qb][tt]); else W4A_MFMA_O(o[qb][dt], fr[((f) + 4) % 5], pf23[qb][(tt) & 1]); } SB(); } while (0)
 #define G(j) do { if ((j) < 4) stage_k_piece(rk, 1 - kslot_next, (j)); else stage_v_piece(rv, 1 - vslot, (j) - 4); } while (0)
@@ -1456,8 +1455,6 @@ static wan_status_t attention_fwd_impl(const void* q, int64_t ldq, int64_t q_bst
     const int nqb_all = (Lq + kQPerWG - 1) / kQPerWG;
     hipStream_t st = (hipStream_t)stream;
     const bool self = Lk > 1024;
-    a.tile_mask = (wan_tune(WAN_TUNE_ATTN_EXP) & 1) ? 15 : 0x7fffffff;
-    a.exp_nocheck = (wan_tune(WAN_TUNE_ATTN_EXP) & 2) ? 1 : 0;
     if (wan_tune(WAN_TUNE_DEBUG_CHECKS) != 0 && klens == nullptr) {       // synchronising contract check, developer builds / bring-up only
         const wan_status_t cs = check_vt_padding(a, batch, lk_pad, st);
         if (cs != WAN_OK) return cs;

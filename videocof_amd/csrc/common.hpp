@@ -24,7 +24,7 @@ void wan_set_error(const char* fmt, ...);
 int wan_cu_count();      // compute units of the current device (256 on MI355X), cached; 256 if it cannot be queried
 // developer switches (api.cpp): environment read once at first use, overridable with wan_set_tuning()
 enum { WAN_TUNE_ATTN_TAIL = 0, WAN_TUNE_ATTN_FAST, WAN_TUNE_ATTN_XCD_MAP, WAN_TUNE_GEMM_GM, WAN_TUNE_GEMM_PHASES,
-       WAN_TUNE_DEBUG_CHECKS, WAN_TUNE_ATTN_EXP, WAN_TUNE_GEMM_VARIANT, WAN_TUNE_CONV_XCD, WAN_TUNE_GEMM_W4, WAN_TUNE_CONV_FAST, WAN_TUNE_CONV_PATCH, WAN_TUNE_ATTN_REF, WAN_TUNE_CONV_HEAD, WAN_TUNE_GEMM_EXP, WAN_TUNE_GEMM_RING, WAN_TUNE_GEMM_PK, WAN_TUNE_GEMM_PK_WORKERS, WAN_TUNE_GEMM_PK_MIN_UNITS, WAN_TUNE_GEMM_PK_ORDER, WAN_TUNE_GEMM_PK_FORM, WAN_TUNE_ROW_GROUP, WAN_TUNE_SP_INLINE, WAN_TUNE_GEMM_SPLITK, WAN_TUNE_CONV_MFMA, WAN_TUNE_ATTN_PERSIST, WAN_TUNE_COUNT };
+       WAN_TUNE_DEBUG_CHECKS, WAN_TUNE_GEMM_VARIANT, WAN_TUNE_CONV_XCD, WAN_TUNE_GEMM_W4, WAN_TUNE_CONV_FAST, WAN_TUNE_CONV_PATCH, WAN_TUNE_ATTN_REF, WAN_TUNE_CONV_HEAD, WAN_TUNE_GEMM_EXP, WAN_TUNE_GEMM_RING, WAN_TUNE_GEMM_PK, WAN_TUNE_GEMM_PK_WORKERS, WAN_TUNE_GEMM_PK_MIN_UNITS, WAN_TUNE_GEMM_PK_ORDER, WAN_TUNE_GEMM_PK_FORM, WAN_TUNE_ROW_GROUP, WAN_TUNE_SP_INLINE, WAN_TUNE_GEMM_SPLITK, WAN_TUNE_CONV_MFMA, WAN_TUNE_ATTN_PERSIST, WAN_TUNE_COUNT };
 int wan_tune(int which);
 void wan_note_attn_variant(int variant);     // read back through wan_get_tuning("last_attn_variant")
 #ifdef __cplusplus

@@ -877,7 +877,12 @@ int64_t wan_gemm_pk_workspace_bytes(int M, int N) {
 static void pk_plan_args(PkArgs& g, int M, int N, int K) {
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
-    g.gm = g.tiles_n >= 40 ? 2 : 3;
+    // M tiles per rasterisation group = the shape of the 32 tiles in flight on an XCD (GM x 32 / GM): GM + 32 / GM distinct operand panels feed
+    // 64 panel reads, so 4 x 8 is the minimum.  Round-6 sweep on the 14B shapes (profiles/r06/gemm_gm_sweep.log, gemm_gm_fetch.log): the L2 ->
+    // fabric reads follow that count exactly (ffn.0: GM 2 22.8 GB, 4 15.5, 6 15.1, 16 22.1 per launch) and the TIME does not (GM 2 / 3 / 4 / 6
+    // within 0.6 % on every shape; 8 loses 2-3 %, 16 loses 8 %): the Linears are not waiting for the fabric.  4 for the wide outputs (q|k +1.1 %,
+    // ffn.0 +0.1 %, a third less fabric traffic), 3 otherwise (o / v / ffn.2 are at their best there).
+    g.gm = g.tiles_n >= 40 ? 4 : 3;
     if (const int gm = wan_tune(WAN_TUNE_GEMM_GM); gm > 0) g.gm = gm;
     g.nworkers = wan_gemm_pk_workers(M, N);
     // smallest range worth a worker: a quarter of a tile's K range (a tile is then cut into at most ~5 pieces), at least one unit
