@@ -127,17 +127,101 @@ def pmc_traffic(workload, shards, variant_code=None):
 BOX_REFERENCE_MFMA_MIX_TFLOPS = 1500.0
 
 
+class BoxSampler:
+    """Samples the GPU's own telemetry (sysfs hwmon of the amdgpu card: gfx clock, socket power, junction temperature) every 100 ms
+    from a background thread while the timed region runs -- what the chip actually held during THIS measurement, next to what the
+    calibration probe reached before and after it.  File reads only (no subprocess, nothing enqueued on the GPU); absent or unreadable
+    files simply leave the fields out."""
+
+    def __init__(self, device_index=0, period_s=0.1):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thread = period_s, {"sclk_mhz": [], "power_w": [], "temp_c": []}, threading.Event(), None
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        pick = None
+        for h in cards:
+            dev_dir = os.path.realpath(os.path.join(h, "..", ".."))
+            if want and os.path.basename(dev_dir).lower() == want.lower():
+                pick = h
+        if pick is None and len(cards) >= 1:
+            pick = cards[min(device_index, len(cards) - 1)]
+        if pick:
+            for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_input", "power1_average")), ("temp_c", ("temp2_input", "temp1_input"))):
+                for n in names:
+                    f = os.path.join(pick, n)
+                    if os.path.exists(f):
+                        self.files[key] = f
+                        break
+        self.source = pick
+
+    def _read(self):
+        for key, f in self.files.items():
+            try:
+                with open(f) as fh:
+                    v = float(fh.read().strip())
+                self.samples[key].append(v / 1e6 if key in ("sclk_mhz", "power_w") else v / 1e3)
+            except Exception:
+                pass
+
+    def start(self):
+        import threading
+        if not self.files:
+            return self
+
+        def loop():
+            while not self._stop.wait(self.period):
+                self._read()
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2)
+        out = {"source": self.source, "samples": max((len(v) for v in self.samples.values()), default=0)}
+        for key, v in self.samples.items():
+            if v:
+                out[key] = {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1)}
+        return out
+
+
 def box_object(box):
     if box is None:
         return None
     b, a = box["before"], box["after"]
     mean = 0.5 * (b["mfma_mix_tflops"] + a["mfma_mix_tflops"])
     return {"mfma_mix_tflops": round(mean, 1), "copy_tbps": round(0.5 * (b["copy_tbps"] + a["copy_tbps"]), 3),
-            "before": b, "after": a, "reference_mfma_mix_tflops": BOX_REFERENCE_MFMA_MIX_TFLOPS,
+            "before": b, "after": a, "telemetry_during_timed_region": box.get("telemetry"),
+            "reference_mfma_mix_tflops": BOX_REFERENCE_MFMA_MIX_TFLOPS,
             "rel_to_reference": round(mean / BOX_REFERENCE_MFMA_MIX_TFLOPS, 4),
             "what": "wan_box_probe on rank 0: 32x32x16 bf16 MFMAs + LDS fragment reads + softmax VALU stream on random operands, one "
                     "4-wave workgroup per CU, ~0.2 s measured after ~0.1 s of the same (chip at its power limit), and a 256 MiB copy; "
                     "before = after the warm-up steps, after = right after the timed region; the same kernels every round"}
+
+
+def committed_ingest():
+    """What precedes the first edit of a process: checkpoint ingest + the three LoRA merges of fast_infer.py:366-386 at the real size
+    (28.6 GB of bf16 safetensors shards, three rank-128 LoRA files), measured by tools/bench_ingest.py on a GPU box and committed -- it
+    writes 32 GB of synthetic files first, too long for the default bench run, so the line quotes the newest committed measurement."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ingest_14b.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            return {"load_s": d["load_s"], "merge_s": d["merge_s"], "checkpoint_GB": round(d["checkpoint_bytes"] / 1e9, 1),
+                    "lora_GB": round(d["lora_bytes"] / 1e9, 2), "check_ok": d["check"]["ok"], "measured_in_this_run": False,
+                    "source": os.path.relpath(path, ROOT), "how": "python tools/bench_ingest.py (page-cache reads; synthetic values, real layout)"}
+        except Exception:
+            continue
+    return None
 
 
 def host_threads():
@@ -576,12 +660,14 @@ def main():
     if not args.no_box_probe:
         from videocof_amd import ops as vops
         box = {"before": vops.box_probe(dev)}     # the warm-up steps above have brought the chip to temperature
+    sampler = BoxSampler(local_rank).start() if box is not None else None
     fence()
     t0 = time.perf_counter()
     out = run(args.steps)
     fence()
     wall = time.perf_counter() - t0
     if box is not None:
+        box["telemetry"] = sampler.stop()
         box["after"] = vops.box_probe(dev)
     rank_walls = None
     if world > 1:
@@ -706,6 +792,8 @@ def main():
             res["e2e"] = e2e_edit(model, wl, dev)
         except Exception as e:
             res["e2e"] = {"error": repr(e)}
+    if rank == 0 and isinstance(res.get("e2e"), dict) and "error" not in res["e2e"]:
+        res["e2e"]["ingest"] = committed_ingest()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

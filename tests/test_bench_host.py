@@ -162,3 +162,9 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     assert lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED, 0) & 15 == 1
     assert lib.wan_attention_plan(1, L, L, H, 128, 0, ws) & 15 == 1
     assert lib.wan_attention_plan(1, L, L, H, 64, 0, ws) == 0
+
+
+def test_committed_ingest_measurement_is_quoted_with_its_source():
+    d = bench.committed_ingest()
+    assert d is not None and d["source"].startswith("profiles/r") and d["measured_in_this_run"] is False
+    assert d["check_ok"] is True and 25 < d["checkpoint_GB"] < 32 and d["load_s"] > 0 and d["merge_s"] > 0
