@@ -80,6 +80,24 @@ except Exception as e:
 PY
     timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
     ;;
+  d)  # early prefetch in the persistent cross-attention kernel; telemetry-carrying bench lines; ingest straight to the device; configs[1]
+    timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "cross_attention_persistent or attention" > $out/pytest_attn.log 2>&1; tail -3 $out/pytest_attn.log
+    timeout 600 python tools/bench_cross_attn.py > $out/cross_attn_persistent_ab.log 2>&1; cat $out/cross_attn_persistent_ab.log
+    timeout 400 $B --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_1.err | json > $out/bench_14b_run1.json
+    timeout 400 $B --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_2.err | json > $out/bench_14b_run2.json
+    timeout 400 $B --workload 1.3b-cof --steps 4 --no-cpu-baseline 2>$out/bench_13.err | json > $out/bench_1p3b_cof.json
+    timeout 900 python tools/bench_ingest.py --layers 40 2>$out/ingest.err | json > $out/ingest_14b.json; cat $out/ingest_14b.json
+    timeout 900 python -m pytest tests/test_gpu_dit.py -x -q > $out/pytest_dit.log 2>&1; tail -3 $out/pytest_dit.log
+    python - $out <<'PY'
+import json, sys
+for n in ("bench_14b_run1", "bench_14b_run2", "bench_1p3b_cof"):
+    try:
+        d = json.load(open(f"{sys.argv[1]}/{n}.json"))
+        print(n, "telemetry", d["box"]["telemetry_during_timed_region"])
+    except Exception as e:
+        print(n, "no telemetry", e)
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'

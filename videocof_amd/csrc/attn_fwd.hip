@@ -648,6 +648,23 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         ++it;
         last_in_s1 = true;
     }
+    // PERSIST: what the peeled tile and the epilogue need of THIS block, before `setup_block` describes the next one.  With an even
+    // tile count the whole ring but V slot 1 (the peeled tile's) is free from here on -- K(nkv-1) was consumed by the S product of the
+    // last interval, behind its fence -- and the Q fragments are dead: the next block's K(0) / V(0) / K(1) requests and its Q loads go
+    // out NOW and travel under the peeled tile and the epilogue (~5k cycles) instead of under the epilogue's 16 stores alone.
+    const int Lk_blk = Lk, qblk_blk = qblk;
+    bf16_t* const O_blk = O;
+    const int w_next = w_cur + (int)gridDim.x;
+    const bool more = PERSIST && w_next < a.nwg;
+    bool staged = false;
+    if constexpr (PERSIST) {
+        if (more && (nkv & 1) == 0) {
+            setup_block(w_next);
+            stage_prologue();
+            load_q();
+            staged = true;
+        }
+    }
     // ---- peeled last tile (it == nkv - 1): mask keys >= Lk, no staging, no next S.  All four P fragments are recomputed
     // here with the mask (the first two that the last interval produced ahead of time, and `carry`, are dropped).
     {
@@ -670,7 +687,7 @@ void attn_fwd_w4_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= Lk) sl[kt][r] = -INFINITY;
+                    if (key >= Lk_blk) sl[kt][r] = -INFINITY;
                 }
             }
             float delta = 0.f;
@@ -763,16 +780,14 @@ void attn_fwd_w4_kernel(AttnArgs a) {
         if constexpr (PERSIST) {
             // this block's output window: rows [256 qblk, min(Lq, 256 qblk + 256)) of this head, as a buffer whose range check drops
             // the rows past Lq -- every lane issues all 16 stores whatever its row (the count the next block's vmcnt(16) relies on)
-            const int rows_here = min(a.Lq - qblk * kQPerWG, kQPerWG);
+            const int rows_here = min(a.Lq - qblk_blk * kQPerWG, kQPerWG);
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(O + (int64_t)qblk * kQPerWG * a.ldo), 0, (int)((((int64_t)rows_here - 1) * a.ldo + kD) * 2), 0x00020000);
+                (void*)(O_blk + (int64_t)qblk_blk * kQPerWG * a.ldo), 0, (int)((((int64_t)rows_here - 1) * a.ldo + kD) * 2), 0x00020000);
             int ovoff[2];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) ovoff[qb] = (int)((((int64_t)(wid * 64 + qb * 32 + l31)) * a.ldo + 8 * hi) * 2);
-            const int w_next = w_cur + (int)gridDim.x;
-            const bool more = w_next < a.nwg;
-            __syncthreads();                              // every wave has read its last fragments: the ring is free
-            if (more) {                                   // the next block's requests go out BEFORE this block's stores
+            if (more && !staged) {                        // odd tile count: V slot 0 was the peeled tile's -- the requests go out here,
+                __syncthreads();                          // once every wave has read its last fragments, still BEFORE this block's stores
                 setup_block(w_next);
                 stage_prologue();
                 load_q();
