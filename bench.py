@@ -498,6 +498,10 @@ def main():
                     help="process-group backend; gloo (host-staged exchanges) only to exercise the N>1 code path on a box "
                          "whose ranks share one GPU -- its numbers are meaningless")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
+    ap.add_argument("--force-sp", action="store_true",
+                    help="ONE rank, the whole sequence-parallel line: a 1-rank RCCL process group + model.force_ulysses -- every exchange is a "
+                         "real (identity) RCCL all-to-all issued async on the group's stream, the parity probe is gathered through the group, "
+                         "the walls through all_gather: the N > 1 code path of this file on a box with one GPU.  Never a headline line.")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-box-probe", action="store_true",
                     help="skip the ~0.4 s box fingerprint (wan_box_probe) before and after the timed region")
@@ -541,7 +545,16 @@ def main():
     from videocof_amd import dist as vdist
     from videocof_amd.weights import random_dit_state_dict
 
-    if world > 1:
+    force_sp = args.force_sp and world == 1
+    if force_sp:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or force_sp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the collective libraries print connection banners on fd 1 ("[Gloo] Rank 0 is connected to ..."): keep stdout for the
         # ONE JSON line and send whatever they print during set-up to stderr
@@ -549,7 +562,9 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            if args.backend == "nccl":
+            if force_sp:
+                dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
+            elif args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group("gloo")
@@ -561,7 +576,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.layers > 0:
         wl["num_layers"] = min(args.layers, wl["num_layers"])
-    sp = world > 1 and args.mode == "sp"
+    sp = (world > 1 or force_sp) and args.mode == "sp"
     if sp and wl["num_heads"] % world:
         raise SystemExit(f"{wl['num_heads']} heads cannot be split over {world} GPUs (Ulysses)")
 
@@ -585,6 +600,7 @@ def main():
     if sp:
         vdist.init_sequence_parallel()
         model.enable_multi_gpus_inference()
+        model.force_ulysses = force_sp
     Fs, G, Ft = wl["fs"], wl["g"], wl["ft"]
     Ftot = Fs + G + Ft
     cof = Fs > 0
@@ -639,9 +655,11 @@ def main():
             return gloop((n_steps,), latents, ctx, loop, keep=(sched.timesteps,))
         return loop(latents, ctx)
 
+    grouped = world > 1 or force_sp             # a process group exists: barriers, gathered walls, a teardown
+
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -670,7 +688,7 @@ def main():
         box["telemetry"] = sampler.stop()
         box["after"] = vops.box_probe(dev)
     rank_walls = None
-    if world > 1:
+    if grouped:
         # every rank's own wall time of the timed region: the line's time is the MAX; the list and max / min show a straggler
         tws = [torch.zeros(1, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64) for _ in range(world)]
         dist.all_gather(tws, torch.tensor([wall], device=tws[0].device, dtype=torch.float64))
@@ -776,8 +794,9 @@ def main():
         "roofline": roof,
         "box": box_object(box),
         "value_normalised": None if box is None else round(value * BOX_REFERENCE_MFMA_MIX_TFLOPS / (0.5 * (box["before"]["mfma_mix_tflops"] + box["after"]["mfma_mix_tflops"])), 1),
-        "ranks_seen": dist.get_world_size() if world > 1 else 1,
-        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (host-staged, numbers meaningless)")) if world > 1 else None,
+        "ranks_seen": dist.get_world_size() if grouped else 1,
+        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (host-staged, numbers meaningless)")
+                    + (" -- ONE rank, force_ulysses: identity exchanges, the N > 1 code path only" if force_sp else "")) if grouped else None,
         "exposed_comm_ms": exposed_comm(comm, args.steps, wl["num_layers"]),
         "rank_wall_s": None if rank_walls is None else {
             "per_rank": [round(v, 4) for v in rank_walls], "max_over_min": round(max(rank_walls) / min(rank_walls), 4),
@@ -787,7 +806,7 @@ def main():
         "attn_stress": bool(args.attn_stress),
         "fp8_attn_smooth_k": (not args.fp8_no_smooth_k) if (args.fp8 and "attn" in args.fp8_layers.split(",")) else None,
     }
-    if rank == 0 and world == 1 and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
+    if rank == 0 and world == 1 and not force_sp and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
         try:        # the metric's second half (sec / video of a whole edit); separate from the timed region above, never takes it down
             res["e2e"] = e2e_edit(model, wl, dev)
         except Exception as e:
@@ -804,7 +823,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -606,3 +606,26 @@ def test_bench_line_under_sequence_parallelism_is_self_validating():
     assert set(ec["per_step_by_exchange"]) == {"q_g0", "o_g1", "all_gather"}
     assert abs(sum(ec["per_step_by_exchange"].values()) - ec["per_step"]) < 0.01
     assert line["box"] is not None and line["box"]["mfma_mix_tflops"] > 100 and line["value_normalised"] > 0
+
+
+def test_bench_sequence_parallel_line_over_rccl_with_one_rank():
+    """`bench.py --force-sp`: the N > 1 code path of the bench on its REAL transport -- a 1-rank RCCL process group, model.force_ulysses:
+    every exchange an async RCCL all-to-all on the group's stream, the parity probe gathered through the group, walls through all_gather
+    on device tensors, barriers, teardown -- everything a multi-GPU run executes except bytes crossing between devices."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sp", "--workload", "1.3b-small", "--layers", "3",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and "RCCL" in line["backend"] and "force_ulysses" in line["backend"]
+    assert line["config"]["parallelism"] == "ulysses-sp1"
+    assert line["parity"]["ok"] is True and line["parity"]["rel_l2"] < 1e-2
+    assert set(line["exposed_comm_ms"]["per_step_by_exchange"]) == {"q_g0", "o_g1", "all_gather"}
+    assert line["rank_wall_s"]["per_rank"] and line["rank_wall_s"]["max_over_min"] == 1.0
+    assert line["roofline"]["heads_local"] == 12 and "e2e" not in line
