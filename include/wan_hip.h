@@ -380,6 +380,12 @@ wan_status_t wan_sp_unpack_heads_split(const void* wire, void* x_bf16, int64_t l
  *                ticket is good for a wait at any later time (a recycled event marks a later point of the side stream).  One
  *                host thread drives a communicator.
  *      wan_sp_all_gather: recv[r] <- send of rank r (the head output, wan_transformer3d.py:1085-1086); also asynchronous.
+ *      Stream capture: while `compute_stream` is being captured into a hipGraph the collectives are recorded ON it (no side stream,
+ *                no events; tuning key "sp_inline" forces that form).  Verified with ONE rank only (capture + bit-identical replay);
+ *                several ranks replaying RCCL collectives from graphs in lockstep are untested -- the Python host refuses to capture
+ *                a sequence-parallel forward with world_size > 1 unless WAN_SP_GRAPH_MULTI_RANK=1 (videocof_amd/graph.py).
+ *      wan_sp_destroy: destroys the RCCL comm, the side stream and the events -- EXCEPT for a communicator that was ever captured:
+ *                instantiated graphs hold its RCCL kernels, so its comm is deliberately leaked (it lives until the process exits).
  *      RCCL is bound at run time (dlopen "librccl.so.1"): WAN_ERR_UNSUPPORTED if it cannot be loaded. */
 typedef struct wan_sp_comm wan_sp_comm;
 #define WAN_SP_UNIQUE_ID_BYTES 128

@@ -98,6 +98,19 @@ for n in ("bench_14b_run1", "bench_14b_run2", "bench_1p3b_cof"):
         print(n, "no telemetry", e)
 PY
     ;;
+  final)  # the pass behind profiles/r06/ on the round's final tree: suite, smoke, headline line (default + driver form), rocprofv3 passes, yardstick
+    timeout 1800 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+    timeout 300 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+    timeout 900 $B 2>$out/bench_default.err | json > $out/bench_14b_final.json
+    timeout 900 $B --steps 20 --warmup 5 2>$out/bench_driver.err | json > $out/bench_14b_driver_like_20_steps.json
+    timeout 600 $B --workload 14b-cof-33f 2>$out/bench_33f.err | json > $out/bench_14b_cof_33f_final.json
+    timeout 600 $B --force-sp --steps 2 --no-cpu-baseline 2>$out/bench_forcesp.err | json > $out/bench_14b_force_sp_rccl_one_rank.json
+    bash tools/profile_bench.sh r06_final > $out/prof.log 2>&1
+    bash tools/profile_bench_sq.sh r06_final > $out/prof_sq.log 2>&1
+    BENCH_ARGS="" PASSES="trace" bash tools/profile_bench.sh r06_fp8 --fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv > $out/prof_fp8.log 2>&1
+    timeout 600 $B --fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv --no-cpu-baseline --no-e2e 2>$out/bench_fp8.err | json > $out/bench_14b_fp8_everything.json
+    timeout 900 python tools/bench_gemm_yardstick.py > $out/gemm_yardstick_final_tree.log 2>&1; tail -25 $out/gemm_yardstick_final_tree.log
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
@@ -119,4 +132,4 @@ e = d.get("e2e")
 if e: print("  e2e", {k: e.get(k) for k in ("sec_per_video", "stages_s", "error")})
 PY
 done
-for f in $out/*.err; do echo "== $f"; tail -5 "$f"; done
+for f in $out/*.err; do [ -f "$f" ] && { echo "== $f"; tail -5 "$f"; }; done; true
