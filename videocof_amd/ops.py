@@ -322,8 +322,8 @@ def release_gemm_workspaces(include_capture: bool = False) -> int:
     """Drop the cached persistent-GEMM workspaces (~128 MiB per (device, stream) that ever issued a Linear): the eager entries
     always -- each is re-allocated by the next GEMM of its stream, and a buffer goes back to the caching allocator on the stream
     whose launches used it, so nothing in flight loses it -- and, with ``include_capture``, the per-device capture workspaces and
-    the retired ones as well (ONLY once every graph that recorded launches on them is gone: ``WanTransformer3DModel.
-    release_workspaces()`` without ``keep_pinned`` invalidates its graphs and passes True).  Returns the bytes released."""
+    the retired ones as well -- ONLY once every hipGraph of the process that recorded launches on them is gone (a graph holds raw
+    addresses, not references; ``WanTransformer3DModel.release_workspaces()`` therefore never passes True).  Returns the bytes released."""
     freed = 0
     for key in [k for k in _GEMM_WS if include_capture or k[1] != "capture"]:
         freed += _GEMM_WS.pop(key).numel()

@@ -779,8 +779,10 @@ class WanTransformer3DModel(nn.Module):
             self._graph_epoch += 1
         self._bufs_last = None
         self._ctx_cache = None
-        # (the composites re-read the GEMM workspace address on every call: `_block_cws`)
-        ops.release_gemm_workspaces(include_capture=not keep_pinned)
+        # the per-stream GEMM workspaces of eager launches (re-allocated on demand; the composites re-read the address on every call,
+        # `_block_cws`).  The per-device CAPTURE workspace stays: graphs bake its address in, and graphs of OTHER models of this process
+        # may still replay from it -- `ops.release_gemm_workspaces(include_capture=True)` is for a caller who knows every graph is gone.
+        ops.release_gemm_workspaces(include_capture=False)
 
     def _run_block(self, blk: _Block, em, xs, bufs, ctx_kv, rp, B, Ll, L, seq_len):
         """One WanAttentionBlock (:464-515) in place on the fp32 residual stream xs [B*Ll, C].
