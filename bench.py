@@ -203,7 +203,7 @@ def box_object(box):
             "reference_mfma_mix_tflops": BOX_REFERENCE_MFMA_MIX_TFLOPS,
             "rel_to_reference": round(mean / BOX_REFERENCE_MFMA_MIX_TFLOPS, 4),
             "what": "wan_box_probe on rank 0: 32x32x16 bf16 MFMAs + LDS fragment reads + softmax VALU stream on random operands, one "
-                    "4-wave workgroup per CU, ~0.2 s measured after ~0.1 s of the same (chip at its power limit), and a 256 MiB copy; "
+                    "4-wave workgroup per CU, ~0.6 s measured after ~0.3 s of the same (chip at its power limit), and a 256 MiB copy; "
                     "before = after the warm-up steps, after = right after the timed region; the same kernels every round"}
 
 
@@ -677,7 +677,7 @@ def main():
     box = None
     if not args.no_box_probe:
         from videocof_amd import ops as vops
-        box = {"before": vops.box_probe(dev)}     # the warm-up steps above have brought the chip to temperature
+        box = {"before": vops.box_probe(dev, target_ms=900)}     # (0.6 s measured after 0.3 s of the same) the warm-up steps above have brought the chip to temperature
     sampler = BoxSampler(local_rank).start() if box is not None else None
     fence()
     t0 = time.perf_counter()
@@ -686,7 +686,7 @@ def main():
     wall = time.perf_counter() - t0
     if box is not None:
         box["telemetry"] = sampler.stop()
-        box["after"] = vops.box_probe(dev)
+        box["after"] = vops.box_probe(dev, target_ms=900)
     rank_walls = None
     if grouped:
         # every rank's own wall time of the timed region: the line's time is the MAX; the list and max / min show a straggler

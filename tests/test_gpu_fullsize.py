@@ -149,6 +149,33 @@ def test_config3_shape_batch2_two_prompts():
     assert rel_l2(out[0], ref[1]) > 5e-2            # the two prompts really give different outputs
 
 
+def test_config3_cof_layout_batch2_at_720p():
+    """configs[3] as the reference CLI would really run it for an EDIT (inference.py: guidance 5 -> B = 2 [uncond, cond]; the VideoCoF
+    layout at 81f@720p: 21 source + 1 grounding + 21 target latent frames -> grid (43,45,80), L = 154 800 per sample, CoF positions
+    `frame_split_indices=[21, 21]`, `ground_frame_indices=[(21, 22)] * 2`, pipeline_wan.py:713-718) with one layer at 14B width: the
+    whole forward against the oracle's.  The largest single-device call shape of the BASELINE configs that carries a batch."""
+    m = _model_14b_width(1, seed=7)
+    cfg = O.DiTConfig(num_layers=1, **W14)
+    g = torch.Generator(device=DEV).manual_seed(17)
+    lat = torch.randn(2, 16, 43, 90, 160, device=DEV, generator=g)
+    ctx = [torch.randn(1, 4096, device=DEV, generator=g).bfloat16().float(),
+           torch.randn(33, 4096, device=DEV, generator=g).bfloat16().float()]
+    t = torch.tensor([749, 749], device=DEV)
+    L = 43 * 45 * 80
+    kw = dict(frame_split_indices=[21, 21], ground_frame_indices=[(21, 22), (21, 22)])
+    out = m(lat.bfloat16().float(), t, ctx, L, **kw)
+    m.release_workspaces()
+    assert out.shape == lat.shape
+    sd = oracle_sd(m)
+    for b in range(2):                                  # one sample at a time: the oracle's fp32 activations of both would not fit next to the model's
+        ref = O.dit_forward(sd, cfg, lat[b:b + 1].bfloat16().float(), t[b:b + 1], ctx[b:b + 1], L, [21], [(21, 22)])[0]
+        r, c = rel_l2(out[b], ref), cosine(out[b], ref)
+        print(f"configs[3] CoF layout at 720p, sample {b}: rel-L2 {r:.2e} cosine {c:.6f}")
+        assert r < 1e-2 and c > 0.9999, (b, r, c)
+        del ref
+        torch.cuda.empty_cache()
+
+
 def test_fixture_g5_block_residual_stream(golden):
     """The reference-captured WanAttentionBlock fixture (ragged L = 420, CoF indices) through block_forward."""
     tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
