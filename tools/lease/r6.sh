@@ -3,7 +3,7 @@
 # Everything a stage produces goes under gpurun_out/r06_<stage>/ (merged back); what is to be judged is copied to profiles/r06/ by hand.
 set -u
 stage=${1:?stage}
-out=gpurun_out/r06_$stage
+out=gpurun_out/r06_${stage}${3:-}
 mkdir -p "$out"
 B="python bench.py"
 json() { grep '^{' | tail -1; }
@@ -110,6 +110,12 @@ PY
     BENCH_ARGS="" PASSES="trace" bash tools/profile_bench.sh r06_fp8 --fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv > $out/prof_fp8.log 2>&1
     timeout 600 $B --fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv --no-cpu-baseline --no-e2e 2>$out/bench_fp8.err | json > $out/bench_14b_fp8_everything.json
     timeout 900 python tools/bench_gemm_yardstick.py > $out/gemm_yardstick_final_tree.log 2>&1; tail -25 $out/gemm_yardstick_final_tree.log
+    ;;
+  fp)  # one more box for the fingerprint table (0.6 s probe window): the headline line twice, 4 steps and the driver's 20
+    timeout 600 $B --steps 4 --no-cpu-baseline --no-e2e 2>/dev/null | json > $out/bench_14b_run1.json
+    timeout 600 $B --steps 20 --warmup 5 --no-cpu-baseline --no-e2e 2>/dev/null | json > $out/bench_14b_run2_20steps.json
+    timeout 600 $B --steps 4 --no-cpu-baseline --no-e2e 2>/dev/null | json > $out/bench_14b_run3.json
+    [ "${2:-}" = tests ] && { timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_dit.py -q -x > $out/pytest_fullsize_dit.log 2>&1; tail -3 $out/pytest_fullsize_dit.log; }
     ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
