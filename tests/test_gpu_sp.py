@@ -53,8 +53,12 @@ def _worker(rank, world, port, q_out, heads):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,heads", [(2, 4), (4, 4), (8, 8)])
+@pytest.mark.parametrize("world,heads", [(2, 4), (4, 4), (8, 8), (2, 3), (4, 6), (8, 12)])
 def test_sp_forward_equals_single_device(world, heads):
+    """(2, 3), (4, 6), (8, 12): num_heads % world != 0 -- the 12-head 1.3B model on 8 GPUs, where the reference would reach for
+    ring_degree (dist/fuser.py:46-49).  Here the heads are padded to a multiple of the degree and dealt round-robin by re-arranged, zero
+    -padded weight copies (WanTransformer3DModel._pad_heads_for_ulysses): the same kernels and equal-split exchanges, a dummy head on
+    the ranks that are one short."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

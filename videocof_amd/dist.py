@@ -26,6 +26,10 @@ the q/k exchange.
 
 Everything here is plain ``torch.distributed`` tensor plumbing and runs
 identically on gloo/CPU (tests) and RCCL/GPU.
+
+num_heads % P != 0 (12 heads on 8 GPUs; the reference's answer is ``ring_degree``, dist/fuser.py:46-49,
+not built here): the model pads its heads to a multiple of P with zero-weight dummy heads dealt
+round-robin (``WanTransformer3DModel._pad_heads_for_ulysses``), so this layer only ever sees equal splits.
 """
 from __future__ import annotations
 

@@ -72,7 +72,7 @@ class _Block:
     """Packed weights of one WanAttentionBlock (device tensors; bf16 matrices, fp32 vectors)."""
     __slots__ = ("w_qk", "b_qk", "w_v", "b_v", "w_o", "b_o", "nq", "nk",
                  "w_cq", "b_cq", "w_ck", "b_ck", "w_cv", "b_cv", "w_co", "b_co", "ncq", "nck",
-                 "n3w", "n3b", "w1", "b1", "w2", "b2", "modulation", "f8", "_cw")
+                 "n3w", "n3b", "w1", "b1", "w2", "b2", "modulation", "f8", "_cw", "spw")
 
 
 class WanTransformer3DModel(nn.Module):
@@ -128,6 +128,7 @@ class WanTransformer3DModel(nn.Module):
         # group -- the q exchange of group 1 runs under the attention of group 0, the o exchange of group 0 under the attention of
         # group 1.  1 = one exchange / one attention launch per layer.  Needs >= 2 local heads.
         self.sp_head_groups = 2
+        self._sp_pad = None                 # heads padded to a multiple of the Ulysses degree (see _pad_heads_for_ulysses)
         self._usp = False                   # this forward runs the Ulysses branch (set by forward)
         self._comm_events = None            # bench.py: list collecting (start, end) HIP events around the EXPOSED exchanges
         self.cache_context = False          # hoist step-invariant text K/V (parity neutral)
@@ -312,6 +313,7 @@ class WanTransformer3DModel(nn.Module):
             b.modulation = vec(p + "modulation").reshape(6, C)
             b.f8 = None
             b._cw = None
+            b.spw = None
             self.blocks.append(b)
         w["mod_all"] = torch.stack([b.modulation for b in self.blocks])        # [layers, 6, C]
         self._cdw = None
@@ -325,6 +327,8 @@ class WanTransformer3DModel(nn.Module):
         self._reset_attention_scratch()                # the sticky "max-free attempt off" word described the OLD weights' scores
         if self._fp8:
             self.enable_fp8_linear(self._fp8, attn_smooth_k=self.fp8_attn_smooth_k)          # re-quantise from the new bf16 weights
+        if getattr(self, "_sp_pad", None) is not None:
+            self._pad_heads_for_ulysses(self.sp_world_size)                                  # the padded copies follow the new weights
         return IncompatibleKeys(missing, extra)
 
     def state_dict(self, *args, **kwargs):  # type: ignore[override]
@@ -488,9 +492,48 @@ class WanTransformer3DModel(nn.Module):
         sp = get_sp_group()
         if sp is None:
             raise RuntimeError("sequence-parallel group is not initialised (videocof_amd.dist.set_multi_gpus_devices)")
-        if self.num_heads % sp.world_size:
-            raise ValueError(f"num_heads={self.num_heads} is not divisible by ulysses degree {sp.world_size}")
         self._sp, self.sp_world_size, self.sp_world_rank = sp, sp.world_size, sp.rank
+        self._sp_pad = None
+        if self.num_heads % sp.world_size:
+            self._pad_heads_for_ulysses(sp.world_size)
+
+    def _pad_heads_for_ulysses(self, P: int):
+        """num_heads % P != 0 (the 12-head 1.3B model on 8 GPUs): the reference would reach for ``ring_degree`` (dist/fuser.py:46-49;
+        ring attention is not built here).  Ulysses itself needs whole heads per rank, so the heads are PADDED to the next multiple of P
+        and dealt round-robin: head h -> rank h % P, local slot h // P; a rank whose last slot has no head computes a dummy one (q = k =
+        v = 0: a uniform softmax over zeros).  All of it is a re-arrangement of WEIGHTS done once, here: the self-attention q / k / v
+        projections get their output rows permuted into wire order with zero rows for the dummy heads (so every kernel and every
+        exchange of the equal-split path runs unchanged on C_pad channels), the RMSNorm gains follow, with gain and epsilon
+        corrected for the mean now being taken over C_pad channels (x / sqrt(sum / C + eps) = x * sqrt(C / C_pad) / sqrt(sum / C_pad +
+        eps * C / C_pad)), and the o projection gets the matching column permutation with zero columns.  Cost: the dummy heads' attention
+        and the padding on the wires (12 heads on 8 ranks: 16 slots, what 6 ranks would take); the token-local two thirds of a layer
+        split P ways regardless."""
+        if self._fp8:
+            raise NotImplementedError("fp8 projections with padded heads under sequence parallelism")
+        H, C, d, dev = self.num_heads, self.dim, self.d, self._device
+        Hl = (H + P - 1) // P
+        Hp, Cp = Hl * P, Hl * P * d
+        cp = torch.arange(Cp, device=dev)
+        r, sl, j = cp // (Hl * d), (cp % (Hl * d)) // d, cp % d
+        hreal = sl * P + r
+        valid = hreal < H
+        src = torch.where(valid, hreal * d + j, torch.zeros_like(cp))
+        gain = math.sqrt(C / Cp)
+
+        def rows(w):                         # [C, ...] -> [Cp, ...] in wire order, zero rows for the dummy heads
+            out = w.index_select(0, src)
+            out[~valid] = 0
+            return out.contiguous()
+        for blk in self.blocks:
+            spw = SimpleNamespace()
+            spw.w_q, spw.b_q = rows(blk.w_qk[:C]), rows(blk.b_qk[:C])
+            spw.w_k, spw.b_k = rows(blk.w_qk[C:]), rows(blk.b_qk[C:])
+            spw.w_v, spw.b_v = rows(blk.w_v), rows(blk.b_v)
+            spw.nq, spw.nk = rows(blk.nq) * gain, rows(blk.nk) * gain
+            spw.w_o = rows(blk.w_o.t().contiguous()).t().contiguous()          # [C, Cp]: columns in wire order
+            blk.spw = spw
+        self._sp_pad = SimpleNamespace(H=Hp, C=Cp, eps=self.eps * C / Cp, pad_heads=Hp - H)
+        self._bufs, self._bufs_last = {}, None
 
     def enable_fp8_linear(self, layers=("qkv", "ffn"), attn_smooth_k: bool = True):
         """FP8 (OCP e4m3) projections, SURVEY.md 8f-4 -- an explicit LOSSY option, off by default and never used by a
@@ -521,6 +564,8 @@ class WanTransformer3DModel(nn.Module):
         sharded model uses the exponents a single device would have measured.
         The bf16 weights stay loaded (the last block under ``skip_source_frames`` and the sequence-parallel path use them).
         Measured error: tests/test_gpu_fp8.py, DESIGN.md section 13."""
+        if getattr(self, "_sp_pad", None) is not None:
+            raise NotImplementedError("fp8 projections with padded heads under sequence parallelism (num_heads % ulysses degree != 0)")
         layers = tuple(layers)
         if not set(layers) <= {"qkv", "ffn", "o", "cross", "attn", "attn_pv"} or not layers:
             raise ValueError(f"enable_fp8_linear: layers must be drawn from ('qkv', 'ffn', 'o', 'cross', 'attn', 'attn_pv'), got {layers}")
@@ -717,7 +762,8 @@ class WanTransformer3DModel(nn.Module):
     def _workspaces(self, B, Ll, L, seq_len):
         """Per-forward activation buffers (module docstring).  Kept across calls of one shape: the caching allocator
         would hand the same blocks back anyway, and fixed addresses are what a captured hipGraph replays."""
-        key = (B, Ll, L, seq_len, self.sp_world_size, self._usp, str(self._device), tuple(self._fp8))
+        Ca = self._sp_pad.C if (self._usp and self._sp_pad is not None) else self.dim       # channels on the attention side of Ulysses
+        key = (B, Ll, L, seq_len, self.sp_world_size, self._usp, str(self._device), tuple(self._fp8), Ca)
         b = self._bufs.get(key)
         if b is not None:
             self._bufs_last = key
@@ -740,8 +786,11 @@ class WanTransformer3DModel(nn.Module):
             # head-sharded V^T the attention kernel reads (pad columns [P*Ll, ld) zeroed once, never written again)
             b.vt = None
             for name in ("kw_s", "kw_r", "qw_s", "qw_r", "vw_s", "vw_r", "ow_s", "ow_r"):
-                setattr(b, name, torch.empty(M * C, device=dev, dtype=torch.bfloat16))
-            b.vt_full = torch.zeros(B, C // P, ops.round_up(seq_len, 64), device=dev, dtype=torch.bfloat16)
+                setattr(b, name, torch.empty(M * Ca, device=dev, dtype=torch.bfloat16))
+            b.vt_full = torch.zeros(B, Ca // P, ops.round_up(seq_len, 64), device=dev, dtype=torch.bfloat16)
+            if Ca != C:                          # padded heads: the q | k projections and the gathered attention output are Ca wide
+                b.qk_a = torch.empty(M, 2 * Ca, device=dev, dtype=torch.bfloat16)
+                b.att_a = torch.empty(M, Ca, device=dev, dtype=torch.bfloat16)
         b.qk3 = b.qk.view(B, Ll, 2 * C)
         if self._fp8:
             b.hq = torch.empty(M, C, device=dev, dtype=ops.FP8)
@@ -864,31 +913,43 @@ class WanTransformer3DModel(nn.Module):
             # the q projection, only the q exchange is exposed.  The arrived q / k buffers ARE the attention operands
             # ([P*Ll][B][C/P], uniform strides), the attention output IS the send buffer of the inverse exchange; the only
             # re-layout passes per layer are wan_sp_unpack_vt and wan_sp_unpack_heads (2 x M*C bf16 each way).
-            sp, Cl, Lt = self._sp, C // P, P * Ll
+            # Padded heads (num_heads % P != 0, _pad_heads_for_ulysses): the attention side runs on Ca = C_pad channels / Ha = H_pad heads
+            # with the wire-ordered, zero-padded weight copies; otherwise Ca = C and everything below is the model's own tensors.
+            pad = self._sp_pad
+            Ca, Ha = (pad.C, pad.H) if pad is not None else (C, H)
+            eps_a = pad.eps if pad is not None else self.eps
+            spw = blk.spw if pad is not None else None
+            nq_a, nk_a = (spw.nq, spw.nk) if pad is not None else (blk.nq, blk.nk)
+            qk_a = bufs.qk_a if pad is not None else qk
+            sp, Cl, Lt = self._sp, Ca // P, P * Ll
             if "qk" in f8:          # e4m3 operands: the q | k weight copy and its per-output-channel scales split by rows like the bf16 one
                 w8, ws8 = f8["qk"]
                 proj = lambda rows, bias, out: ops.gemm_fp8(bufs.hq, bufs.rs, w8[rows], ws8[rows], bias, ops.EPI_BF16, out=out)
                 proj_vt = lambda b, out: ops.gemm_fp8(bufs.hq[b * Ll:(b + 1) * Ll], bufs.rs[b * Ll:(b + 1) * Ll], *f8["v"], blk.b_v,
                                                       ops.EPI_BF16_T, out=out)
+            elif pad is not None:
+                proj = lambda rows, bias, out: ops.gemm(h, spw.w_k if rows.start else spw.w_q, spw.b_k if rows.start else spw.b_q,
+                                                        ops.EPI_BF16, out=out)
+                proj_vt = lambda b, out: ops.gemm(h[b * Ll:(b + 1) * Ll], spw.w_v, spw.b_v, ops.EPI_BF16_T, out=out)
             else:
                 proj = lambda rows, bias, out: ops.gemm(h, blk.w_qk[rows], bias, ops.EPI_BF16, out=out)
                 proj_vt = lambda b, out: ops.gemm(h[b * Ll:(b + 1) * Ll], blk.w_v, blk.b_v, ops.EPI_BF16_T, out=out)
-            proj(slice(C, 2 * C), blk.b_qk[C:], qk[:, C:])
-            ops.rmsnorm_rope_sp(qk[:, C:], blk.nk, None, None, self.d, self.eps, self._rope_dev, rp, bufs.kw_s, None, P, B)
+            proj(slice(Ca, 2 * Ca), blk.b_qk[C:], qk_a[:, Ca:])
+            ops.rmsnorm_rope_sp(qk_a[:, Ca:], nk_a, None, None, self.d, eps_a, self._rope_dev, rp, bufs.kw_s, None, P, B)
             wait_k = sp.exchange(bufs.kw_r, bufs.kw_s, async_op=True)
-            vsend = bufs.vw_s.view(C, B, Ll)
+            vsend = bufs.vw_s.view(Ca, B, Ll)
             for b in range(B):
                 proj_vt(b, vsend[:, b])
             wait_v = sp.exchange(bufs.vw_r, bufs.vw_s, async_op=True)
-            proj(slice(0, C), blk.b_qk[:C], qk[:, :C])
+            proj(slice(0, Ca), blk.b_qk[:C], qk_a[:, :Ca])
             # Head groups (q and o only; k and V^T are already under the projections).  The RMSNorm of q spans ALL heads of a token
             # (wan_transformer3d.py:264-267: WanRMSNorm(dim)), so no head group of q exists before the whole projection does -- the
             # pipeline is between the exchanges and the attention launches, not inside the projection: with groups g0 | g1 the
             # exposed transfers per layer are q(g0) and o(g1), ONE exchange's worth instead of two.
-            Hl = H // P
+            Hl = Ha // P
             h0 = Hl // 2 if (self.sp_head_groups >= 2 and Hl >= 2) else 0
             split, n0 = h0 * self.d, Lt * B * h0 * self.d        # group 0: channels [0, split) of every slab, n0 elements of wire
-            ops.rmsnorm_rope_sp(qk[:, :C], blk.nq, None, None, self.d, self.eps, self._rope_dev, rp, bufs.qw_s, None, P, B,
+            ops.rmsnorm_rope_sp(qk_a[:, :Ca], nq_a, None, None, self.d, eps_a, self._rope_dev, rp, bufs.qw_s, None, P, B,
                                 x0_scale=self._qs, split=split)
             if h0:
                 wait_q = sp.exchange(bufs.qw_r[:n0], bufs.qw_s[:n0], async_op=True)
@@ -974,9 +1035,16 @@ class WanTransformer3DModel(nn.Module):
             for w_ in wait_o:
                 w_()
             self._comm_done(cev)
-            ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B, split=split)
-            o_in = att
-        if "o" in f8:
+            if pad is not None:                 # [B*Ll, Ca] in wire order; the o projection's padded weight has the matching columns
+                ops.sp_unpack_heads(bufs.ow_r, bufs.att_a, P, Ll, B, split=split)
+                ops.gemm(bufs.att_a, spw.w_o, blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
+                o_in = None
+            else:
+                ops.sp_unpack_heads(bufs.ow_r, att, P, Ll, B, split=split)
+                o_in = att
+        if o_in is None:
+            pass
+        elif "o" in f8:
             ops.quantize_rows_fp8(o_in, out=bufs.attq, out_scale=bufs.atts)
             ops.gemm_fp8(bufs.attq, bufs.atts, *f8["o"], blk.b_o, ops.EPI_RESID_F32, out=xs, gate=em[2], rows_per_batch=Ll)
         else:
