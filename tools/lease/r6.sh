@@ -117,6 +117,11 @@ PY
     timeout 600 $B --steps 4 --no-cpu-baseline --no-e2e 2>/dev/null | json > $out/bench_14b_run3.json
     [ "${2:-}" = tests ] && { timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_dit.py -q -x > $out/pytest_fullsize_dit.log 2>&1; tail -3 $out/pytest_fullsize_dit.log; }
     ;;
+  e)  # padded heads under Ulysses (num_heads % P != 0); the 1.3B model sequence-parallel over 8 ranks on a shared GPU (gloo); whole suite
+    timeout 1200 python -m pytest tests/test_gpu_sp.py -x -q > $out/pytest_sp.log 2>&1; tail -4 $out/pytest_sp.log
+    timeout 1200 $B --gpus 8 --backend gloo --share-gpu --workload 1.3b-cof --layers 4 --steps 1 --warmup 1 --no-box-probe 2>$out/bench_sp8_13.err | json > $out/bench_sp8_gloo_shared_gpu_1p3b_padded_heads.json
+    timeout 1800 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
