@@ -122,6 +122,16 @@ PY
     timeout 1200 $B --gpus 8 --backend gloo --share-gpu --workload 1.3b-cof --layers 4 --steps 1 --warmup 1 --no-box-probe 2>$out/bench_sp8_13.err | json > $out/bench_sp8_gloo_shared_gpu_1p3b_padded_heads.json
     timeout 1800 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
     ;;
+  g)  # every other bench mode once on the final tree (no exception, sane line): graphs, replicas, stress weights, the stand-alone tools
+    timeout 300 $B --workload 1.3b-small --graph-loop --no-cpu-baseline 2>$out/b1.err | json > $out/bench_1p3b_small_graph_loop.json
+    timeout 300 $B --workload 1.3b-small --graph --no-cpu-baseline 2>$out/b2.err | json > $out/bench_1p3b_small_graph.json
+    timeout 300 $B --workload 1.3b-small --no-cpu-baseline 2>$out/b3.err | json > $out/bench_1p3b_small_eager.json
+    timeout 600 $B --gpus 2 --mode dp --backend gloo --share-gpu --workload 1.3b-small --no-cpu-baseline 2>$out/b4.err | json > $out/bench_dp2_gloo_shared_gpu_1p3b_small.json
+    timeout 600 $B --attn-stress --steps 2 --no-cpu-baseline --no-e2e 2>$out/b5.err | json > $out/bench_14b_attn_stress.json
+    timeout 600 $B --workload 14b-720p --steps 2 --no-cpu-baseline 2>$out/b6.err | json > $out/bench_14b_720p.json
+    timeout 600 python tools/bench_vae.py > $out/bench_vae.log 2>&1; tail -4 $out/bench_vae.log
+    timeout 300 python tools/bench_t5.py > $out/bench_t5.log 2>&1; tail -3 $out/bench_t5.log
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
