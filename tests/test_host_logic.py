@@ -340,3 +340,50 @@ def test_fresh_values_follow_the_reference_init_rules():
     assert float(w.abs().max()) <= bound and float(w.std()) == pytest.approx(bound / math.sqrt(3), rel=0.05)
     assert float(m._fresh_value("text_embedding.0.weight", (256, 64), g).std()) == pytest.approx(0.02, rel=0.1)
     assert float(m._fresh_value("blocks.0.modulation", (1, 6, 256), g).std()) == pytest.approx(1 / 16, rel=0.15)
+
+
+def test_ulysses_head_padding_is_an_exact_rearrangement():
+    """num_heads % P != 0 under Ulysses (WanTransformer3DModel._pad_heads_for_ulysses): heads padded to a multiple of the degree and
+    dealt round-robin purely by re-arranged, zero-padded weights.  The algebra on the CPU in fp64: q / k / v projections with permuted +
+    zero rows, RMSNorm over the PADDED width with gain * sqrt(C / C_pad) and eps * C / C_pad, per-head attention (dummy heads: q = k = v
+    = 0), o projection with permuted + zero columns == the unpadded layer."""
+    from videocof_amd.wan_transformer3d import ulysses_head_padding
+    H, P, d, L = 3, 2, 8, 11
+    C = H * d
+    Hp, Cp, src, valid = ulysses_head_padding(H, P, d)
+    assert (Hp, Cp) == (4, 32) and int(valid.sum()) == C
+    assert sorted(src[valid].tolist()) == list(range(C))                       # every real channel exactly once
+    heads_of_rank = [[int(src[r * (Hp // P) * d + s * d] // d) if bool(valid[r * (Hp // P) * d + s * d]) else None for s in range(Hp // P)]
+                     for r in range(P)]
+    assert heads_of_rank == [[0, 2], [1, None]]                                # round-robin; the short rank is the last one
+    H12, C12, s12, v12 = ulysses_head_padding(12, 8, 128)
+    assert (H12, C12) == (16, 2048) and int(v12.sum()) == 1536
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(L, C, generator=g, dtype=torch.float64)
+    wq, wk, wv, wo = (torch.randn(C, C, generator=g, dtype=torch.float64) for _ in range(4))
+    bq, bk, bv = (torch.randn(C, generator=g, dtype=torch.float64) for _ in range(3))
+    nq, nk = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5 for _ in range(2))
+    eps = 1e-6
+
+    def rms(t, w, e):
+        return t / torch.sqrt((t * t).mean(dim=-1, keepdim=True) + e) * w
+
+    def attend(q, k, v, heads):
+        out = []
+        for h in range(heads):
+            sl = slice(h * d, (h + 1) * d)
+            p = torch.softmax(q[:, sl] @ k[:, sl].t() / d ** 0.5, dim=-1)
+            out.append(p @ v[:, sl])
+        return torch.cat(out, dim=1)
+    ref = attend(rms(x @ wq.t() + bq, nq, eps), rms(x @ wk.t() + bk, nk, eps), x @ wv.t() + bv, H) @ wo.t()
+
+    def rows(w):
+        o = w.index_select(0, src).clone()
+        o[~valid] = 0
+        return o
+    gain, eps_p = (C / Cp) ** 0.5, eps * C / Cp
+    qp = rms(x @ rows(wq).t() + rows(bq), rows(nq) * gain, eps_p)
+    kp = rms(x @ rows(wk).t() + rows(bk), rows(nk) * gain, eps_p)
+    vp = x @ rows(wv).t() + rows(bv)
+    got = attend(qp, kp, vp, Hp) @ rows(wo.t().contiguous())          # (the model stores this as an nn.Linear weight: [C, C_pad])
+    assert float((got - ref).abs().max()) < 1e-10

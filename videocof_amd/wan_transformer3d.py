@@ -68,6 +68,21 @@ class StateDictShapeError(ValueError, RuntimeError):
     RuntimeError because that is what ``nn.Module.load_state_dict`` raises for "size mismatch for <key>"."""
 
 
+def ulysses_head_padding(num_heads: int, degree: int, head_dim: int):
+    """The channel map of Ulysses with num_heads % degree != 0: (H_pad, C_pad, src, valid) with H_pad the next multiple of the
+    degree, and for every padded channel cp in WIRE order -- rank r = cp // (Hl * d) holds local slots s = 0 .. Hl - 1, slot s of rank r
+    is head s * degree + r (round-robin: the ranks that are one head short are the LAST ones, and every rank's real heads come first)
+    -- the real channel it copies (``src``) or ``valid`` = False for a dummy head's channel."""
+    Hl = (num_heads + degree - 1) // degree
+    Hp, Cp = Hl * degree, Hl * degree * head_dim
+    cp = torch.arange(Cp)
+    r, sl, j = cp // (Hl * head_dim), (cp % (Hl * head_dim)) // head_dim, cp % head_dim
+    hreal = sl * degree + r
+    valid = hreal < num_heads
+    src = torch.where(valid, hreal * head_dim + j, torch.zeros_like(cp))
+    return Hp, Cp, src, valid
+
+
 class _Block:
     """Packed weights of one WanAttentionBlock (device tensors; bf16 matrices, fp32 vectors)."""
     __slots__ = ("w_qk", "b_qk", "w_v", "b_v", "w_o", "b_o", "nq", "nk",
@@ -511,13 +526,8 @@ class WanTransformer3DModel(nn.Module):
         if self._fp8:
             raise NotImplementedError("fp8 projections with padded heads under sequence parallelism")
         H, C, d, dev = self.num_heads, self.dim, self.d, self._device
-        Hl = (H + P - 1) // P
-        Hp, Cp = Hl * P, Hl * P * d
-        cp = torch.arange(Cp, device=dev)
-        r, sl, j = cp // (Hl * d), (cp % (Hl * d)) // d, cp % d
-        hreal = sl * P + r
-        valid = hreal < H
-        src = torch.where(valid, hreal * d + j, torch.zeros_like(cp))
+        Hp, Cp, src, valid = ulysses_head_padding(H, P, d)
+        src, valid = src.to(dev), valid.to(dev)
         gain = math.sqrt(C / Cp)
 
         def rows(w):                         # [C, ...] -> [Cp, ...] in wire order, zero rows for the dummy heads
