@@ -26,7 +26,15 @@ Rank 0 prints ONE JSON line; it also carries
                    the host cores at the three points BASELINE.md section 4 names and extrapolated to
                    the workload with the FLOP formula (N=1, rank 0 only);
   parity        -- the last block + head of one more (untimed) forward of the same model and inputs,
-                   compared on sampled token rows with the fp32 oracle evaluated by torch on the GPU.
+                   compared on sampled token rows with the fp32 oracle evaluated by torch on the GPU; under
+                   sequence parallelism every rank's probe is gathered first, so the N > 1 line checks its
+                   own sharded forward (exchanges, rank-offset RoPE, padded keys, all-gather);
+  box           -- the box fingerprint: `wan_box_probe` (a fixed calibration workload inside libwan_hip.so)
+                   before and after the timed region, and the chip's clock / power / temperature sampled
+                   during it; `value_normalised` = value x (reference probe rate / this box's): the figure to
+                   compare across boxes and rounds (the chips are power-limited here and differ by ~4 %);
+  rank_wall_s   -- (N > 1) every rank's own wall clock of the timed region and max / min.
+`--force-sp` runs the whole sequence-parallel line over a 1-rank RCCL group (code path, not scaling).
 """
 from __future__ import annotations
 
