@@ -132,6 +132,11 @@ PY
     timeout 600 python tools/bench_vae.py > $out/bench_vae.log 2>&1; tail -4 $out/bench_vae.log
     timeout 300 python tools/bench_t5.py > $out/bench_t5.log 2>&1; tail -3 $out/bench_t5.log
     ;;
+  confirm)  # the last tree once more: suite, smoke, the default headline line
+    timeout 1800 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+    timeout 300 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+    timeout 900 $B 2>$out/bench_default.err | json > $out/bench_14b_final.json
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
