@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WAN_ABI_VERSION 10     /* 10: wan_box_probe (the benchmark's box fingerprint); 9: wan_attention_fwd_varlen (ragged batches in one launch); 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
+#define WAN_ABI_VERSION 11     /* 11: wan_gemm_fp8_ws / wan_gemm_fp8_ws_plan / wan_gemm_fp8_pk_segment (the e4m3 Linear on the persistent stream-K kernel); 10: wan_box_probe (the benchmark's box fingerprint); 9: wan_attention_fwd_varlen (ragged batches in one launch); 8: wan_qk_quantize_fp8 takes either operand alone, wan_gemm_ws_splits + the split-K form of the 128^2 GEMM, tuning key gemm_pk_form replaces gemm_pk_sched (and attn_w4 is gone with the 8-wave attention kernel), the persistent GEMM from K >= 1024, the library communicator records collectives on a capturing stream; 7: the *_split wire entry points (Ulysses head groups); 6: wan_gemm_bf16_ws / wan_gemm_workspace_bytes / wan_gemm_ws_plan (persistent stream-K GEMM with a caller workspace); 5: the fp8 attention family */
 
 typedef enum {
     WAN_OK = 0,
@@ -182,6 +182,18 @@ int wan_gemm_pk_segment(int M, int N, int K, int worker, int index, int* out);
 wan_status_t wan_gemm_fp8(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
                           const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
                           int epilogue, const float* gate, int64_t rows_per_batch, void* stream);
+/* wan_gemm_fp8_ws: wan_gemm_fp8 with a caller workspace (wan_gemm_workspace_bytes(M, N, K / 2) bytes, 16-byte aligned, not shared
+ * with another stream; w_row_scale 16-byte aligned).  Shapes whose bf16 product of the same TILE count would run on the persistent
+ * stream-K kernel (wan_gemm_fp8_ws_plan == WAN_GEMM_VARIANT_256_PK: K % 256 == 0 and wan_gemm_ws_plan(M, N, K / 2) says so) run its
+ * e4m3 instantiation -- same segments, stream-K combine (bitwise reproducible) and epilogues, 128-element K tiles consumed by one
+ * v_mfma_scale_f32_16x16x128_f8f6f4 per output tile in two phases ("schedule P", gemm_bf16_pk.hip); everything else, and a NULL
+ * workspace, is wan_gemm_fp8.  wan_gemm_fp8_pk_segment: wan_gemm_pk_segment for that plan (K tiles of 128 elements). */
+int wan_gemm_fp8_ws_plan(int M, int N, int K);
+wan_status_t wan_gemm_fp8_ws(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
+                             const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
+                             int epilogue, const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+int wan_gemm_fp8_pk_segment(int M, int N, int K, int worker, int index, int* out);
 wan_status_t wan_quantize_rows_fp8(const void* x_bf16, int64_t ldx, void* out_fp8, int64_t ldo, float* out_row_scale,
                                    int64_t rows, int cols, void* stream);
 wan_status_t wan_ln_modulate_fp8(const float* x, const float* scale, const float* shift, int add_one, void* out_fp8,

@@ -20,7 +20,7 @@ def header_symbols():
 def test_library_present_and_loads():
     assert os.path.isfile(_lib.LIB_PATH), "run `make` / __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.wan_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.wan_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_every_header_symbol_is_exported_and_bound():

@@ -14,24 +14,30 @@ SHAPES = [(67080, 5120, 5120), (67080, 10240, 5120), (67080, 13824, 5120), (6708
           (16776, 5120, 5120), (1024, 512, 4096), (300, 300, 128), (2304, 1536, 8960), (2304, 8960, 1536), (75600 * 2, 5120, 5120)]
 
 
-def plan(lib, M, N, K):
+def plan(lib, M, N, K, fp8=False):
     G = lib.wan_gemm_pk_grid(M, N)
     out = (ctypes.c_int * 11)()
     segs = []
+    segment = lib.wan_gemm_fp8_pk_segment if fp8 else lib.wan_gemm_pk_segment
     for w in range(G):
         i = 0
-        while lib.wan_gemm_pk_segment(M, N, K, w, i, out):
+        while segment(M, N, K, w, i, out):
             segs.append((w, i) + tuple(out))
             i += 1
     return G, segs
 
 
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
 @pytest.mark.parametrize("M,N,K", SHAPES)
-def test_every_k_tile_of_every_output_tile_is_computed_exactly_once(M, N, K):
+def test_every_k_tile_of_every_output_tile_is_computed_exactly_once(M, N, K, fp8):
+    """(e4m3: the same plan over K tiles of 128 elements -- wan_gemm_fp8_pk_segment; K % 256 == 0, two K tiles per unit)"""
     lib = _lib.load()
-    G, segs = plan(lib, M, N, K)
+    if fp8 and K % 256:
+        assert plan(lib, M, N, K, True)[1] == []
+        return
+    G, segs = plan(lib, M, N, K, fp8)
     assert G % 8 == 0 and G >= 8
-    nk, tiles_m, tiles_n = K // 64, (M + 255) // 256, (N + 255) // 256
+    nk, tiles_m, tiles_n = K // (128 if fp8 else 64), (M + 255) // 256, (N + 255) // 256
     cover, work, pieces, slots = collections.Counter(), collections.Counter(), collections.defaultdict(list), set()
     for (w, i, tm, tn, kb, ke, partial, slot, cnt, jlo, jhi, me, tau) in segs:
         assert 0 <= tm < tiles_m and 0 <= tn < tiles_n and 0 <= kb < ke <= nk
@@ -54,6 +60,8 @@ def test_every_k_tile_of_every_output_tile_is_computed_exactly_once(M, N, K):
         assert len(ps) >= 2
     if tiles_m * tiles_n * nk // 2 >= 4 * G:         # enough work to balance: no worker waits for a tail round
         assert max(work.values()) - min(work.values()) <= max(2 * 24, nk // 2 + 2)
+    if fp8:
+        return
     # (default dispatch: no workspace, the persistent kernel's, or -- small shapes on the 128^2 kernel -- the split-K form's)
     splits = int(lib.wan_gemm_ws_splits(M, N, K))
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
@@ -78,6 +86,12 @@ def test_workspace_entry_falls_back_and_validates():
     # without a workspace they stay on the 8-wave per-tile kernel, and shallow K (the VAE attention block's 384) stays there either way
     assert lib.wan_gemm_ws_plan(67080, 5120, 1536) == 3 and lib.wan_gemm_plan(67080, 5120, 1536) == 1
     assert lib.wan_gemm_ws_plan(67080, 1536, 8960) == 3 and lib.wan_gemm_ws_plan(67080, 3072, 1536) == 3
+    # round 6: the e4m3 Linear asks the same plan about the bf16 product of the same tile count (K / 2); K % 256 != 0 or no
+    # workspace -> wan_gemm_fp8 (whose own validation answers)
+    assert lib.wan_gemm_fp8_ws_plan(67080, 5120, 5120) == 3 and lib.wan_gemm_fp8_ws_plan(67080, 5120, 13824) == 3
+    assert lib.wan_gemm_fp8_ws_plan(67080, 5120, 1536) == 1 and lib.wan_gemm_fp8_ws_plan(67080, 5120, 5120 + 128) == 1
+    assert lib.wan_gemm_fp8_ws_plan(515, 64, 1024) == 1
+    assert lib.wan_gemm_fp8_ws(None, 128, None, None, 128, None, None, None, 64, 4, 64, 128, 0, None, 0, None, 0, None) == _lib.WAN_ERR_INVALID
     assert lib.wan_gemm_ws_plan(6240, 6240, 384) == lib.wan_gemm_plan(6240, 6240, 384) == 1
     assert lib.wan_gemm_ws_plan(2304, 3072, 1536) == lib.wan_gemm_plan(2304, 3072, 1536) == 0              # < 1 tile per 2 CUs: the 128^2 kernel
     assert lib.wan_gemm_ws_plan(2304, 8960, 1536) == lib.wan_gemm_plan(2304, 8960, 1536) == 1              # 315 tiles: shallow K needs >= 4 rounds

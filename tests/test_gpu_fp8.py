@@ -83,6 +83,94 @@ def test_gemm_fp8_is_exact_on_the_quantised_operands(M, N, K):
     assert 5e-3 < rel_l2(o_f32, exact) < 6e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 520, 512), (2304, 1536, 1792), (4100, 2100, 256), (9000, 5120, 1280), (3000, 1164, 768)])
+def test_persistent_gemm_e4m3_all_epilogues(M, N, K):
+    """wan_gemm_fp8_ws on the persistent stream-K kernel's e4m3 instantiation (gemm_pk_kernel<EPI, 1, true>, "schedule P": K tiles of
+    128 elements consumed by one MX-scaled 16x16x128 MFMA per output tile, in two phases) at shapes that are mostly or partly SPLIT
+    tiles, ragged M / N, a sample seam inside a wave's rows: every epilogue against the fp64 product of the SAME quantised operands
+    (exact arithmetic: fp32 accumulation is the only rounding), bitwise run-to-run with garbage in the workspace, and against the
+    8-wave per-tile kernel (wan_gemm_fp8) on the same inputs."""
+    from videocof_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 2).bfloat16()
+    w = torch.randn(N, K, device=DEV, generator=g) * 0.05
+    bias = torch.randn(N, device=DEV, generator=g) * 0.5
+    gate = torch.randn(2, N, device=DEV, generator=g)
+    resid = torch.randn(M, N, device=DEV, generator=g)
+    aq, sa = ops.quantize_rows_fp8(a)
+    wq, sw = ops.quantize_weight_fp8(w)
+    acc = (aq.double() * sa[:, None].double()) @ (wq.double() * sw[:, None].double()).t() + bias.double()
+    rpb = (M + 1) // 2
+
+    def run_all():
+        o_res = resid.clone()
+        ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_RESID_F32, out=o_res, gate=gate, rows_per_batch=rpb)
+        return (ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_BF16), ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_GELU_BF16),
+                ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_F32), o_res, ops.gemm_fp8(aq, sa, wq, sw, None, ops.EPI_BF16_T))
+
+    ops.set_tuning("gemm_pk", 2)                       # 2 = whenever the shape rules allow (the default takes the big Linears only)
+    try:
+        assert _lib.load().wan_gemm_fp8_ws_plan(M, N, K) == 3
+        ws = ops.gemm_workspace(aq.device, M, N, K // 2)
+        assert ws is not None
+        runs = []
+        for rep in range(2):
+            ws.fill_(0xA5 if rep else 0xFF)
+            runs.append(run_all())
+    finally:
+        ops.set_tuning("gemm_pk", 1)
+    ops.set_tuning("gemm_pk", 0)
+    try:
+        assert _lib.load().wan_gemm_fp8_ws_plan(M, N, K) == 1
+        per_tile = run_all()
+    finally:
+        ops.set_tuning("gemm_pk", 1)
+    o_bf, o_ge, o_f32, o_res, o_t = runs[0]
+    assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
+    assert rel_l2(o_f32, acc) < 1e-5 and rel_l2(o_bf, acc) < 4e-3
+    x = acc
+    assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3
+    gsel = gate.double()[torch.arange(M, device=DEV) // rpb]
+    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
+    assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc - bias.double()) < 4e-3
+    assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
+    for got, ref in zip(runs[0], per_tile):             # same products, another summation order for split tiles only
+        assert rel_l2(got, ref.double()) < 4e-3
+    assert rel_l2(runs[0][2], per_tile[2].double()) < 1e-5
+
+
+def test_persistent_gemm_e4m3_at_the_14b_shapes_vs_the_per_tile_kernel():
+    """The default dispatch at the headline shapes (M = 67 080; q|k, ffn.0 + GELU, ffn.2 + gate + residual, V^T): the e4m3 Linears run
+    the persistent kernel and agree with the 8-wave per-tile kernel on the same quantised operands."""
+    from videocof_amd import _lib
+    M = 67080
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for (N, K, epi) in [(10240, 5120, ops.EPI_BF16), (13824, 5120, ops.EPI_GELU_BF16), (5120, 13824, ops.EPI_RESID_F32), (5120, 5120, ops.EPI_BF16_T)]:
+        a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        w = torch.randn(N, K, device=DEV, generator=g) * 0.02
+        bias = torch.randn(N, device=DEV, generator=g) * 0.1
+        aq, sa = ops.quantize_rows_fp8(a)
+        wq, sw = ops.quantize_weight_fp8(w)
+        del a, w
+        outs = []
+        for pk in (1, 0):
+            ops.set_tuning("gemm_pk", pk)
+            try:
+                assert _lib.load().wan_gemm_fp8_ws_plan(M, N, K) == (3 if pk else 1)
+                if epi == ops.EPI_RESID_F32:
+                    o = torch.ones(M, N, device=DEV)
+                    ops.gemm_fp8(aq, sa, wq, sw, bias, epi, out=o, gate=torch.full((1, N), 0.5, device=DEV), rows_per_batch=M)
+                else:
+                    o = ops.gemm_fp8(aq, sa, wq, sw, bias, epi)
+                outs.append(o)
+            finally:
+                ops.set_tuning("gemm_pk", 1)
+        d = rel_l2(outs[0], outs[1].double())
+        assert d < (1e-5 if epi == ops.EPI_RESID_F32 else 4e-3), (N, K, epi, d)
+        assert bool(torch.isfinite(outs[0].float()).all())
+        del outs, aq, wq
+
+
 def test_fp8_mode_small_model_vs_oracle_and_bf16():
     tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
     cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)

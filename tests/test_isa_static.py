@@ -164,7 +164,7 @@ def test_persistent_gemm_kernels_are_clean(pk_asm, epi, what, form):
     fragment reads / 32 LDS-DMA requests / 4 barriers per two K tiles, and the one-request-per-lane epilogues: form 1 (product)
     moves every output with 16-byte accesses of whole row segments (bf16: 32 stores per lane and tile, fp32: 64 stores / 64 loads,
     transposed: 32) and needs no lane exchange; form 0 (round 4's epilogues, the developer A/B partner) is held to what it was."""
-    mangled = f"gemm_pk_kernelILi{epi}ELi{form}E"
+    mangled = f"gemm_pk_kernelILi{epi}ELi{form}ELb0E"
     body = _kernel(pk_asm, mangled)
     meta = "\n".join(pk_asm)
     priv = re.search(re.escape(mangled) + r"\w*\.private_seg_size, (\d+)", meta)
@@ -205,3 +205,42 @@ def test_persistent_gemm_kernels_are_clean(pk_asm, epi, what, form):
         assert whole("global_store_dwordx4") >= 120 and whole("global_store_dword") <= 8, (what, whole("global_store_dwordx4"), whole("global_store_dword"))
         if what == "resid":
             assert whole("global_load_dwordx4") >= 64 * 6 and whole("global_load_dword") == 0
+
+
+@pytest.mark.parametrize("epi,what", [(0, "bf16"), (1, "gelu"), (2, "f32"), (3, "resid"), (4, "transposed")])
+def test_persistent_gemm_e4m3_kernels_are_clean(pk_asm, epi, what):
+    """The e4m3 instantiation gemm_pk_kernel<EPI, 1, true> ("schedule P"): no scratch, and a main loop of exactly 128 MX-scaled
+    16x16x128 MFMAs / 64 fragment reads / 32 LDS-DMA requests / 4 barriers per two K tiles with the counted wait (vmcnt(7)) in front
+    of the publishing barrier of each tile and no accumulator <-> VGPR traffic; the epilogues keep the bf16 form's 16-byte accesses."""
+    mangled = f"gemm_pk_kernelILi{epi}ELi1ELb1E"
+    body = _kernel(pk_asm, mangled)
+    meta = "\n".join(pk_asm)
+    priv = re.search(re.escape(mangled) + r"\w*\.private_seg_size, (\d+)", meta)
+    assert priv and int(priv.group(1)) == 0, (what, "scratch", priv and priv.group(1))
+    assert not any("scratch_" in l for l in body), what
+    assert not any("v_mfma_f32_16x16x32_bf16" in l for l in body), what
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for j, l in enumerate(body):
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)\s*$", l)
+        if not m or labels.get(m.group(1), j) >= j:
+            continue
+        seg = body[labels[m.group(1)]:j + 1]
+        n = sum("v_mfma_scale_f32_16x16x128_f8f6f4" in x for x in seg)
+        if n and (best is None or len(seg) < len(best[1])):
+            best = (n, seg)
+    assert best is not None, what
+    n, seg = best
+    assert n == 128, (what, n)
+    count = lambda op: sum(1 for l in seg if re.match(r"\s+" + op + r"\b", l))
+    assert count("ds_read_b128") == 64 and count("buffer_load_dwordx4") == 32, (what, count("ds_read_b128"), count("buffer_load_dwordx4"))
+    assert count("s_barrier") == 4
+    assert sum(1 for l in seg if re.match(r"\s+s_waitcnt vmcnt\(7\)", l)) == 2, what
+    assert not any(re.match(r"\s+s_waitcnt vmcnt\(0\)", l) for l in seg), what
+    for bad in ("v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_accvgpr_mov_b32", "v_readlane_b32", "v_writelane_b32", "v_mov_b32_e32"):
+        assert count(bad) == 0, (what, bad)
+    whole = lambda op: sum(1 for l in body if re.match(r"\s+" + op + r"\b", l))
+    if what in ("bf16", "gelu", "transposed"):
+        assert whole("global_store_dwordx4") == 32, (what, whole("global_store_dwordx4"))
+    if what in ("f32", "resid"):
+        assert whole("global_store_dwordx4") >= 120 and whole("global_store_dword") <= 8, (what, whole("global_store_dwordx4"), whole("global_store_dword"))

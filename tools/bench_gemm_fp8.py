@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time wan_gemm_fp8 on the 14B per-layer shapes (developer aid).  usage: python tools/bench_gemm_fp8.py [gemm_phases ...]"""
+"""Time the e4m3 Linear on the 14B per-layer shapes (developer aid): the persistent stream-K kernel's e4m3 instantiation
+(wan_gemm_fp8_ws, gemm_pk = 1, the default) against the 8-wave per-tile kernel (wan_gemm_fp8, gemm_pk = 0), arms alternating in one
+process, and the bf16 Linear of the same shape beside them.  usage: python tools/bench_gemm_fp8.py"""
 import sys
 import time
 
@@ -12,7 +14,6 @@ dev = "cuda:0"
 L = 67080
 shapes = [("q|k", L, 10240, 5120, ops.EPI_BF16), ("o / cross-q", L, 5120, 5120, ops.EPI_BF16), ("ffn.0+gelu", L, 13824, 5120, ops.EPI_GELU_BF16),
           ("ffn.2+resid", L, 5120, 13824, ops.EPI_RESID_F32), ("v (T)", L, 5120, 5120, ops.EPI_BF16_T)]
-phases = [int(a) for a in sys.argv[1:]] or [0]
 g = torch.Generator(device=dev).manual_seed(0)
 for name, M, N, K, epi in shapes:
     a = torch.randn(M, K, device=dev, generator=g).bfloat16()
@@ -27,17 +28,26 @@ for name, M, N, K, epi in shapes:
     else:
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     gate = torch.zeros(1, N, device=dev) if epi == ops.EPI_RESID_F32 else None
-    for rnd in range(2):
-        for ph in phases:
-            if ph:
-                ops.set_tuning("gemm_phases", ph)
-            kw = dict(gate=gate, rows_per_batch=M) if gate is not None else {}
+    kw = dict(gate=gate, rows_per_batch=M) if gate is not None else {}
+    obf = out if out.dtype == torch.float32 or epi == ops.EPI_BF16_T else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    arms = [("e4m3 per-tile (8 waves)", 0, lambda: ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)),
+            ("e4m3 persistent       ", 1, lambda: ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)),
+            ("bf16 persistent       ", 1, lambda: ops.gemm(a, w, bias, epi, out=obf, **kw))]
+    best = {}
+    for rnd in range(3):
+        for label, pk, fn in arms:
+            ops.set_tuning("gemm_pk", pk)
             for _ in range(2):
-                ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)
+                fn()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(5):
-                ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)
+            for _ in range(6):
+                fn()
             torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 5 * 1e3
-            print(f"gemm_fp8 {name:12s} M={M} N={N} K={K} phases={ph or 'default'}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+            ms = (time.perf_counter() - t0) / 6 * 1e3
+            best[label] = min(best.get(label, 1e9), ms)
+        ops.set_tuning("gemm_pk", 1)
+    for label, _, _ in arms:
+        ms = best[label]
+        print(f"{name:12s} M={M} N={N} K={K}  {label}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"{name:12s} persistent / per-tile = {best[arms[0][0]] / best[arms[1][0]]:.3f}x, e4m3 persistent / bf16 = {best[arms[2][0]] / best[arms[1][0]]:.3f}x", flush=True)

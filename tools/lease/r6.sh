@@ -137,6 +137,15 @@ PY
     timeout 300 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log
     timeout 900 $B 2>$out/bench_default.err | json > $out/bench_14b_final.json
     ;;
+  h)  # the e4m3 Linear on the persistent stream-K kernel ("schedule P"): numerics, A/B against the 8-wave per-tile kernel, the lossy bench line
+    timeout 600 python -m pytest tests/test_gpu_fp8.py -x -q -k "gemm" > $out/pytest_fp8_gemm.log 2>&1; tail -5 $out/pytest_fp8_gemm.log
+    timeout 600 python tools/bench_gemm_fp8.py > $out/gemm_fp8_persistent_ab.log 2>&1; cat $out/gemm_fp8_persistent_ab.log
+    if [ "${2:-}" = "bench" ]; then
+      timeout 900 python -m pytest tests/test_gpu_fp8.py -x -q > $out/pytest_fp8.log 2>&1; tail -3 $out/pytest_fp8.log
+      timeout 600 $B --fp8 --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_fp8.err | json > $out/bench_14b_fp8_everything.json
+      timeout 600 $B --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_bf16.err | json > $out/bench_14b_bf16_same_box.json
+    fi
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # WAN_HIP_LIB: a developer A/B hook -- load ANOTHER build of the library (e.g. the tree of an earlier commit, tools/exp_lib/) through the
 # same binding, so that two builds can be timed back to back on one box.  Unset in every product / test / benchmark path.
 LIB_PATH = os.environ.get("WAN_HIP_LIB") or os.path.join(_HERE, "libwan_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 ATTN_Q_PRESCALED = 1          # wan_attention_fwd flag (include/wan_hip.h)
 LOG2E = 1.4426950408889634
 # wan_get_tuning("last_attn_variant") (include/wan_hip.h, WAN_ATTN_VARIANT_*)
@@ -122,6 +122,10 @@ SIGNATURES = {
     "wan_dit_block_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64)]),
     "wan_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                              c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "wan_gemm_fp8_ws": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "wan_gemm_fp8_ws_plan": (c_int, [c_int, c_int, c_int]),
+    "wan_gemm_fp8_pk_segment": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "wan_quantize_rows_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "wan_ln_modulate_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int64,
                                     c_float, c_void_p]),

@@ -28,6 +28,9 @@ wan_status_t wan_gemm_bf16_pk(const void* A, int64_t lda, const void* W, int64_t
                               void* out, int64_t ldo, int M, int N, int K, int epilogue,
                               const float* gate, int64_t rows_per_batch, void* workspace, hipStream_t s);
 int64_t wan_gemm_pk_workspace_bytes(int M, int N);
+wan_status_t wan_gemm_fp8_pk(const void* A, int64_t lda, const float* a_row_scale, const void* W, int64_t ldw, const float* w_row_scale,
+                             const float* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                             const float* gate, int64_t rows_per_batch, void* workspace, hipStream_t s);
 // gemm_bf16_256.hip: the 256 x 256 phased kernel used for large shapes
 wan_status_t wan_gemm_bf16_256(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                void* out, int64_t ldo, int M, int N, int K, int epilogue,
@@ -462,6 +465,40 @@ extern "C" wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void*
                 (long long)wan_gemm_pk_workspace_bytes(M, N));
     WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_gemm_bf16_ws: workspace must be 16-byte aligned");
     return wan_gemm_bf16_pk(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, workspace, (hipStream_t)stream);
+}
+
+// The e4m3 Linear with a caller workspace: the persistent stream-K kernel's FP8 instantiation (gemm_bf16_pk.hip, "schedule P") where
+// the bf16 product of the same tile count would run persistent -- a K tile is 128 e4m3 elements, so the plan is asked about K / 2 --
+// and wan_gemm_fp8 (the 8-wave per-tile kernel) otherwise.  Same contract as wan_gemm_bf16_ws: the workspace
+// (wan_gemm_workspace_bytes(M, N, K / 2) bytes) is not shared with another stream.
+extern "C" int wan_gemm_fp8_ws_plan(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 256 != 0) return WAN_GEMM_VARIANT_256_W8;
+    return wan_gemm_ws_plan(M, N, K / 2) == WAN_GEMM_VARIANT_256_PK ? WAN_GEMM_VARIANT_256_PK : WAN_GEMM_VARIANT_256_W8;
+}
+
+extern "C" wan_status_t wan_gemm_fp8_ws(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
+                                        const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
+                                        int epilogue, const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+    if (workspace == nullptr || wan_gemm_fp8_ws_plan(M, N, K) != WAN_GEMM_VARIANT_256_PK || (gate != nullptr && rows_per_batch < 128))
+        return wan_gemm_fp8(A_fp8, lda, a_row_scale, W_fp8, ldw, w_row_scale, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, stream);
+    WAN_REQUIRE(A_fp8 && W_fp8 && out && a_row_scale && w_row_scale, WAN_ERR_INVALID, "wan_gemm_fp8_ws: null tensor");
+    WAN_REQUIRE(N % 4 == 0, WAN_ERR_UNSUPPORTED, "wan_gemm_fp8_ws: N=%d must be a multiple of 4", N);
+    WAN_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K, WAN_ERR_INVALID,
+                "wan_gemm_fp8_ws: lda=%lld ldw=%lld must be multiples of 16 and >= K", (long long)lda, (long long)ldw);
+    WAN_REQUIRE(((uintptr_t)w_row_scale & 15) == 0, WAN_ERR_INVALID, "wan_gemm_fp8_ws: w_row_scale must be 16-byte aligned");
+    if (epilogue == WAN_EPI_BF16_T)
+        WAN_REQUIRE(ldo >= M && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_fp8_ws: transposed ldo=%lld < M=%d or not a multiple of 4", (long long)ldo, M);
+    else
+        WAN_REQUIRE(ldo >= N && ldo % 4 == 0, WAN_ERR_INVALID, "wan_gemm_fp8_ws: ldo=%lld < N=%d or not a multiple of 4", (long long)ldo, N);
+    WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
+                "wan_gemm_fp8_ws: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
+    WAN_REQUIRE(workspace_bytes >= wan_gemm_pk_workspace_bytes(M, N), WAN_ERR_INVALID,
+                "wan_gemm_fp8_ws: workspace of %lld bytes, wan_gemm_workspace_bytes(%d, %d, %d) = %lld", (long long)workspace_bytes, M, N, K / 2,
+                (long long)wan_gemm_pk_workspace_bytes(M, N));
+    WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_gemm_fp8_ws: workspace must be 16-byte aligned");
+    return wan_gemm_fp8_pk(A_fp8, lda, a_row_scale, W_fp8, ldw, w_row_scale, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, workspace,
+                           (hipStream_t)stream);
 }
 
 extern "C" wan_status_t wan_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

@@ -60,6 +60,10 @@ struct PkArgs {
     int dynamic;          // whole tiles by ticket from the per-XCD counters (1) or in lockstep order (0: developer A/B)
     int* counters;        // workspace head: [0, nworkers) arrival counters of the split tiles, [512 + 16 x] the ticket counter of XCD x
     char* slots;          // workspace + kCounterBytes: 2 slots of 256 KiB per worker
+    // FP8 instantiation (wan_gemm_fp8_ws): A / W point at e4m3 bytes, lda / ldw count bytes = elements; the product of the quantised
+    // operands is scaled by sa[m] * sw[n] (per token row, per output channel) on its way into the epilogue
+    const float* sa; const float* sw;
+    int ktile;            // host side only (the kernels know it at compile time): elements per K tile, 64 (bf16) or 128 (e4m3)
 };
 
 // One worker's view of its XCD slab: pure integer functions of (problem, grid, blockIdx) -- the host computes nothing per tile.
@@ -100,14 +104,14 @@ __host__ __device__ __forceinline__ void tile_of(const PkArgs& g, int t, int& tm
     tn = in / gm;
 }
 
-__host__ __device__ __forceinline__ Slab make_slab(const PkArgs& g, int worker) {
+__host__ __device__ __forceinline__ Slab make_slab(const PkArgs& g, int worker, int ktile) {
     Slab s;
     const int nt = g.tiles_m * g.tiles_n;
     s.x = worker & 7; s.c = worker >> 3; s.W = g.nworkers >> 3;
     const int q = nt >> 3, r = nt & 7;
     s.start = s.x < r ? s.x * (q + 1) : r * (q + 1) + (s.x - r) * q;
     s.n = q + (s.x < r ? 1 : 0);
-    s.nk = g.K / BK;
+    s.nk = g.K / ktile;
     s.n2 = s.nk >> 1;
     s.rounds = s.n / s.W;
     s.S = s.n - s.rounds * s.W;
@@ -184,8 +188,26 @@ __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast
 //     32 (i >> 1) + 8 (a >> 2) + 4 (i & 1) + (a & 3), so (acc[2 t][j][0..3], acc[2 t + 1][j][0..3]) are 8 consecutive tokens of one
 //     channel: one 16-byte store, the four kg lanes of a column = 64 contiguous bytes (round 4: 8-byte stores, 32 contiguous bytes).
 // Every output element is the same MFMA chain as before (same k order), so results do not change.
-template <int EPI, int FORM>
+// FP8 = true (round 6; wan_gemm_fp8_ws, opt-in lossy mode): the SAME stream, segments, LDS image, stream-K combine and FORM-1 epilogues
+// on e4m3 operands.  A K tile is 128 elements -- still 128 bytes per LDS row -- and the two bf16 MFMAs per (m, n) tile and K tile
+// become ONE v_mfma_scale_f32_16x16x128_f8f6f4 (every block scale 2^0): 32 matrix-pipe cycles for 4 x the K of a 16-cycle bf16 MFMA,
+// i.e. the same cycles, LDS bytes and requests per K tile for twice the FLOPs.  A lane's 32-byte operand = the two adjacent 16-byte
+// chunks 2 kg, 2 kg + 1 of its row (A and W use the same lane -> k assignment, which is all a dot product needs).
+// That MFMA consumes BOTH chunks of a fragment, so a K tile cannot be consumed half by half as in schedule D.  What replaces it
+// ("schedule P"): the 64 MFMAs of a K tile run in two PHASES over the W fragments -- phase 0 = (i, j < 4), phase 1 = (i, j >= 4),
+// i-major inside a phase -- so that registers die in an order the NEXT tile can follow with the same 128 fragment registers:
+//   * W 0..3 are dead after slot 31 and are refilled (next tile) during phase 1; W 4..7 are dead after slot 63 and are refilled
+//     (this tile!) during phase 0 -- they are first needed at slot 32;
+//   * A i is last read at slot 35 + 4 i and first needed at slot 4 i of the next tile: every refill has >= 28 slots (~900 cycles);
+//   * all reads of a tile's buffer are issued by slot 8 of its own tile (A 7 and W 4..7, whose registers the previous tile held to
+//     its end): barrier B1 at slot 12 frees the buffer, the 16 requests of K tile t + 2 go out at slots 13, 16, ... 58, and barrier
+//     B2 at slot 32 (`vmcnt(7)`: the seven requests issued since B1 stay in flight) publishes K tile t + 1, whose last request left
+//     38 slots (~1 200 cycles) earlier.
+// Two barriers, 32 fragment reads and 16 requests per 2 048 matrix-pipe cycles -- what schedule D has -- with half the MFMA issues.
+template <int EPI, int FORM, bool FP8 = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(PkArgs g) {
+    static_assert(!FP8 || FORM == 1, "the e4m3 instantiation runs the row-permuted (FORM 1) epilogues only");
+    constexpr int kEl = FP8 ? 1 : 2;                 // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // D = mfma(A fragment, W fragment): lane (l15, kg) holds output COLUMN .. + l15 and the four consecutive ROWS .. + 4 kg .. + 3 of a
     // tile -- the form of the transposed store, and (round 4) of the fp32 epilogues: there a register of the tile is 4 rows x 16
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     const int l15 = lane & 15, kg = lane >> 4;
-    const Slab slab = make_slab(g, (int)blockIdx.x);
+    const Slab slab = make_slab(g, (int)blockIdx.x, FP8 ? 2 * BK : BK);
 
     // ---- LDS-DMA lane offsets (see gemm_w4_kernel): piece j of wave w covers rows 64 w + 8 j + lane / 8 of an operand tile
     // (LDS row of a piece = wid * 64 + 8 j + lane / 8; its swizzle depends on j & 1 only.  Unpermuted, the panel row is the LDS row:
@@ -214,8 +236,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int arow = kAPerm ? 128 * (wid >> 1) + 64 * (wid & 1) + 8 * (lane >> 5) + ((lane >> 3) & 3) : row;
         const int wrow = kWPerm == 8 ? 128 * (wid >> 1) + 4 * (wid & 1) + 8 * (lane >> 3)
                        : kWPerm == 4 ? 128 * (wid >> 1) + 64 * (wid & 1) + 4 * (lane >> 3) : row;
-        a_voff[p] = (int)(((int64_t)arow * g.lda + c * 8) * 2);
-        w_voff[p] = (int)(((int64_t)wrow * g.ldw + c * 8) * 2);
+        a_voff[p] = (int)((int64_t)arow * g.lda * kEl + c * 16);
+        w_voff[p] = (int)((int64_t)wrow * g.ldw * kEl + c * 16);
     }
     // panel rows piece j adds to the lane part (compile-time per piece)
     auto a_srow = [](int j) { return kAPerm ? 32 * (j >> 2) + 16 * (j & 1) + 4 * ((j >> 1) & 1) : 16 * (j >> 1); };
@@ -226,7 +248,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) koff[b][h] = b * kBufBytes + l15 * 128 + (((4 * h + kg) ^ swz) << 4);
+        for (int h = 0; h < 2; ++h) koff[b][h] = b * kBufBytes + l15 * 128 + (((FP8 ? 2 * kg + h : 4 * h + kg) ^ swz) << 4);
     const int a_base = wr * 128 * 128, w_base = kOperandBytes + wc * 128 * 128;
 
     // ---- the stream: the current segment and the one behind it.  Whole tiles come by ticket from the XCD's counter (one returning
@@ -273,10 +295,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     auto panel = [&](const Seg& e) {
         Panel p;
         const int m0 = e.tm * BM, n0 = e.tn * BN;
-        p.a = (const char*)(g.A + (int64_t)m0 * g.lda);
-        p.w = (const char*)(g.W + (int64_t)n0 * g.ldw);
-        p.ab = (int)min(((int64_t)(min(g.M - m0, BM) - 1) * g.lda + g.K) * 2, (int64_t)0x7fffffff);
-        p.wb = (int)min(((int64_t)(min(g.N - n0, BN) - 1) * g.ldw + g.K) * 2, (int64_t)0x7fffffff);
+        p.a = (const char*)g.A + (int64_t)m0 * g.lda * kEl;
+        p.w = (const char*)g.W + (int64_t)n0 * g.ldw * kEl;
+        p.ab = (int)min(((int64_t)(min(g.M - m0, BM) - 1) * g.lda + g.K) * kEl, (int64_t)0x7fffffff);
+        p.wb = (int)min(((int64_t)(min(g.N - n0, BN) - 1) * g.ldw + g.K) * kEl, (int64_t)0x7fffffff);
         return p;
     };
     Panel pc = panel(cur), pn = panel(nxt);
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int operand, int j, int64_t ld) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             r, (__attribute__((address_space(3))) void*)(smem + buf * kBufBytes + operand * kOperandBytes + (wid * 8 + j) * 1024), 16,
-            operand ? w_voff[j & 1] : a_voff[j & 1], (int)((operand ? w_srow(j) : a_srow(j)) * ld * 2), 0, 0);
+            operand ? w_voff[j & 1] : a_voff[j & 1], (int)((operand ? w_srow(j) : a_srow(j)) * ld * kEl), 0, 0);
     };
 
     f32x4 acc[8][8];                         // [m tile][n tile]
@@ -315,6 +337,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #define GP_MFMA_A(ACC, X, Y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(X), "v"(Y))
 #define GP_MFMA_V(ACC, X, Y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(X), "v"(Y))
 #define GP_MFMA(ACC, X, Y) do { if (i < 6) GP_MFMA_A(ACC, X, Y); else GP_MFMA_V(ACC, X, Y); } while (0)
+// FP8: one MX-scaled MFMA over both 16-byte chunks of a fragment pair; formats 0, 0 = e4m3 x e4m3; every block scale = E8M0 127 = 2^0
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    unsigned sc1 = 0;
+    if constexpr (FP8) asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(sc1));
+#define GP_MFMA8_A(ACC, X, Y) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(ACC) : "v"(X), "v"(Y), "v"(sc1))
+#define GP_MFMA8_V(ACC, X, Y) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(ACC) : "v"(X), "v"(Y), "v"(sc1))
+#define GP_MFMA8(ACC, X, Y) do { if (i < 6) GP_MFMA8_A(ACC, X, Y); else GP_MFMA8_V(ACC, X, Y); } while (0)
     Stream sa, sq;
     // fragment f of a k half in fetch order = first-use order of the MFMA sequence below: A 0, W 0..7, A 1..7
     auto fetch = [&](int h, int f, int buf) __attribute__((always_inline)) {
@@ -357,6 +386,58 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
     };
 
+    // ---- schedule P (FP8; see the kernel header).  fetch8(f, buf): BOTH chunks of fragment f (0..7: A i; 8..15: W j)
+    auto fetch8 = [&](int f, int buf) __attribute__((always_inline)) {
+        if (f < 8) { af[0][f] = lds16(smem + a_base + f * 16 * 128 + koff[buf][0]); af[1][f] = lds16(smem + a_base + f * 16 * 128 + koff[buf][1]); }
+        else { wf[0][f - 8] = lds16(smem + w_base + (f - 8) * 16 * 128 + koff[buf][0]); wf[1][f - 8] = lds16(smem + w_base + (f - 8) * 16 * 128 + koff[buf][1]); }
+    };
+    auto pair8 = [](const u32x4& lo, const u32x4& hi) __attribute__((always_inline)) {
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    auto ktile_p = [&](int kt, int b) __attribute__((always_inline)) {
+        const bool jump = kt + 2 == cur.ke;
+        __amdgpu_buffer_rsrc_t ra, rw;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int s_ = ph * 32 + i * 4 + jj, j = ph * 4 + jj;
+            if (s_ == 12) { __builtin_amdgcn_s_barrier(); GP_SB(); ra = rsrc_of(sa); rw = rsrc_of(sq); }
+            if (s_ == 32) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); __builtin_amdgcn_s_barrier(); GP_SB(); }
+            {
+                const i32x8 a8 = pair8(af[0][i], af[1][i]), w8 = pair8(wf[0][j], wf[1][j]);
+                GP_MFMA8(acc[i][j], a8, w8);
+            }
+            GP_SB();
+            // this tile's late fragments (their registers were the previous tile's to its last slot)
+            if (s_ == 0) fetch8(7, b);
+            else if (s_ == 1) advance(sa, 0, jump);
+            else if (s_ == 3) advance(sq, 1, jump);
+            else if (s_ == 2 || s_ == 4 || s_ == 6 || s_ == 8) fetch8(8 + 4 + (s_ - 2) / 2, b);
+            // K tile kt + 2 -> buffer b: 16 requests, one per 3 MFMAs (96 cycles, as in schedule D)
+            else if (s_ >= 13 && s_ <= 58 && (s_ - 13) % 3 == 0) {
+                const int k = (s_ - 13) / 3;
+                if (k < 8) stage_piece(ra, b, 0, k, g.lda);
+                else stage_piece(rw, b, 1, k - 8, g.ldw);
+            }
+            // K tile kt + 1 (buffer 1 - b, published at slot 32): W 0..3 and A 0..6 into registers that have just died
+            else if (s_ == 33) fetch8(8 + 0, 1 - b);
+            else if (s_ == 35) fetch8(8 + 1, 1 - b);
+            else if (s_ == 36) fetch8(0, 1 - b);
+            else if (s_ == 38) fetch8(8 + 2, 1 - b);
+            else if (s_ == 41) fetch8(1, 1 - b);
+            else if (s_ == 42) fetch8(8 + 3, 1 - b);
+            else if (s_ == 44) fetch8(2, 1 - b);
+            else if (s_ == 48) fetch8(3, 1 - b);
+            else if (s_ == 53) fetch8(4, 1 - b);
+            else if (s_ == 56) fetch8(5, 1 - b);
+            else if (s_ == 60) fetch8(6, 1 - b);
+            GP_SB();
+        }
+    };
+
     // ---- stream prologue: position cur.kb -> buffer 0 (waited for), the A half of position cur.kb + 1 -> buffer 1 (in flight)
     {
         sa = stream_at(0, cur.kb); sq = stream_at(1, cur.kb);
@@ -385,12 +466,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FP8) {
+#pragma unroll
+            for (int f = 0; f < 7; ++f) fetch8(f, 0);              // A 0..6
+#pragma unroll
+            for (int f = 8; f < 12; ++f) fetch8(f, 0);             // W 0..3 (A 7 and W 4..7: slots 0..8 of the first K tile)
+            GP_STAMP(t_start);
+            for (int kt = cur.kb; kt < cur.ke; kt += 2) {
+                ktile_p(kt, 0);
+                ktile_p(kt + 1, 1);
+            }
+        } else {
 #pragma unroll
         for (int f = 0; f < 16; ++f) fetch(0, f, 0);
         GP_STAMP(t_start);
         for (int kt = cur.kb; kt < cur.ke; kt += 2) {
             ktile_d(kt, 0);
             ktile_d(kt + 1, 1);
+        }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA D -> the accumulator reads below
         GP_STAMP(t_loop);
@@ -473,20 +566,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const int mw = m0 + wr * 128 + l4, nb = n0 + wc * 128 + 8 * l15;
                 const bool c0 = nb < g.N, c1 = nb + 4 < g.N;             // N % 4 == 0: a 4-column group is wholly in or out
                 const bool aligned = (g.ldo & 7) == 0 && (((uintptr_t)g.out) & 15) == 0;       // wave-uniform
-                float bq[8];
+                float bq[8], sq8[8];
                 {
                     const float4 b0 = (g.bias && c0) ? *reinterpret_cast<const float4*>(g.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float4 b1 = (g.bias && c1) ? *reinterpret_cast<const float4*>(g.bias + nb + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                     bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
+                    if constexpr (FP8) {        // the output channels' weight scales
+                        const float4 s0 = c0 ? *reinterpret_cast<const float4*>(g.sw + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 s1 = c1 ? *reinterpret_cast<const float4*>(g.sw + nb + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        sq8[0] = s0.x; sq8[1] = s0.y; sq8[2] = s0.z; sq8[3] = s0.w; sq8[4] = s1.x; sq8[5] = s1.y; sq8[6] = s1.z; sq8[7] = s1.w;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v[8];
+                        float sm = 1.f;
+                        if constexpr (FP8) sm = g.sa[min(mw + 16 * i + r, g.M - 1)];       // the token row's activation scale
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            v[j] = acc[i][j][r] + bq[j];
+                            if constexpr (FP8) v[j] = __builtin_fmaf(acc[i][j][r], sm * sq8[j], bq[j]);
+                            else v[j] = acc[i][j][r] + bq[j];
                             if constexpr (EPI == WAN_EPI_GELU_BF16) v[j] = gelu_tanh_f32(v[j]);
                         }
                         const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
@@ -516,12 +617,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                     constexpr bool RESID = EPI == WAN_EPI_RESID_F32;
                     const int mw = m0 + wr * 128 + l4, nb = n0 + wc * 128 + 4 * l15;
                     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
-                    bool nok[2]; int nn[2]; float4 bq[2], gq[2];
+                    bool nok[2]; int nn[2]; float4 bq[2], gq[2], sq4[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         nok[h] = nb + 64 * h < g.N;
                         nn[h] = nok[h] ? nb + 64 * h : 0;                // clamped: a valid address, not stored
                         bq[h] = HAS_BIAS ? *reinterpret_cast<const float4*>(g.bias + nn[h]) : zero;
+                        sq4[h] = FP8 ? *reinterpret_cast<const float4*>(g.sw + nn[h]) : one;
                         gq[h] = (HAS_GATE && !SEAM) ? *reinterpret_cast<const float4*>(g.gate + (int64_t)seam_b_lo * g.N + nn[h]) : one;
                     }
                     struct Rows { float4 x[4][2]; };
@@ -543,11 +645,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                             if (m >= g.M) continue;
                             float* op = (float*)g.out + (int64_t)m * g.ldo;
                             const float* gp = SEAM ? g.gate + (int64_t)(seam_b_lo + (m >= seam_next ? 1 : 0)) * g.N : nullptr;
+                            float sm = 1.f;
+                            if constexpr (FP8) sm = g.sa[m];
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 if (!nok[h]) continue;
-                                float4 v = make_float4(acc[i][4 * h][r] + bq[h].x, acc[i][4 * h + 1][r] + bq[h].y,
-                                                       acc[i][4 * h + 2][r] + bq[h].z, acc[i][4 * h + 3][r] + bq[h].w);
+                                float4 v;
+                                if constexpr (FP8)
+                                    v = make_float4(__builtin_fmaf(acc[i][4 * h][r], sm * sq4[h].x, bq[h].x), __builtin_fmaf(acc[i][4 * h + 1][r], sm * sq4[h].y, bq[h].y),
+                                                    __builtin_fmaf(acc[i][4 * h + 2][r], sm * sq4[h].z, bq[h].z), __builtin_fmaf(acc[i][4 * h + 3][r], sm * sq4[h].w, bq[h].w));
+                                else
+                                    v = make_float4(acc[i][4 * h][r] + bq[h].x, acc[i][4 * h + 1][r] + bq[h].y,
+                                                    acc[i][4 * h + 2][r] + bq[h].z, acc[i][4 * h + 3][r] + bq[h].w);
                                 if constexpr (RESID) {
                                     const float4 gv = SEAM ? *reinterpret_cast<const float4*>(gp + nn[h]) : gq[h];
                                     const float4 x = R.x[r][h];
@@ -593,11 +702,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
                     const bool nok = n < g.N;
                     const float bv = (g.bias && nok) ? g.bias[n] : 0.f;
                     if (!nok) continue;
+                    const float sn = FP8 ? g.sw[n] : 1.f;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int m = m0 + wr * 128 + 32 * t + 8 * kg;
                         if (m >= g.M) continue;
-                        const f32x4 a0 = acc[2 * t][j], a1 = acc[2 * t + 1][j];
+                        f32x4 a0 = acc[2 * t][j], a1 = acc[2 * t + 1][j];
+                        if constexpr (FP8) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                a0[r] *= sn * g.sa[min(m + r, g.M - 1)];
+                                a1[r] *= sn * g.sa[min(m + 4 + r, g.M - 1)];
+                            }
+                        }
                         const float vv[8] = {a0[0] + bv, a0[1] + bv, a0[2] + bv, a0[3] + bv, a1[0] + bv, a1[1] + bv, a1[2] + bv, a1[3] + bv};
                         bf16_t* p = (bf16_t*)g.out + (int64_t)n * g.ldo + m;
                         if (m + 7 < g.M && aligned) {
@@ -836,11 +953,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef GP_SB
 }
 
-template <int EPI, int FORM>
+template <int EPI, int FORM, bool FP8 = false>
 wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     const wan_status_t st = wan_once_per_device(attr_done, +[]() -> wan_status_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI, FORM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<EPI, FORM, FP8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 64);
         if (e != hipSuccess) {
             wan_set_error("wan_gemm_bf16_ws: cannot reserve %d B of LDS: %s", kLdsBytes + 64, hipGetErrorString(e));
@@ -853,7 +970,7 @@ wan_status_t launch_pk(const PkArgs& g, hipStream_t s) {
         wan_set_error("wan_gemm_bf16_ws: cannot clear the arrival counters: %s", hipGetErrorString(hipGetLastError()));
         return WAN_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemm_pk_kernel<EPI, FORM>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
+    hipLaunchKernelGGL((gemm_pk_kernel<EPI, FORM, FP8>), dim3((unsigned)g.nworkers), dim3(kThreads), kLdsBytes + 64, s, g);
     WAN_CHECK_LAUNCH("wan_gemm_bf16_ws");
     return WAN_OK;
 }
@@ -874,8 +991,9 @@ int64_t wan_gemm_pk_workspace_bytes(int M, int N) {
     return kCounterBytes + (int64_t)wan_gemm_pk_workers(M, N) * 2 * kSlotBytes;
 }
 
-static void pk_plan_args(PkArgs& g, int M, int N, int K) {
-    g.M = M; g.N = N; g.K = K;
+static void pk_plan_args(PkArgs& g, int M, int N, int K, int ktile = BK) {
+    g.M = M; g.N = N; g.K = K; g.ktile = ktile;
+    g.sa = g.sw = nullptr;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     // M tiles per rasterisation group = the shape of the 32 tiles in flight on an XCD (GM x 32 / GM): GM + 32 / GM distinct operand panels feed
     // 64 panel reads, so 4 x 8 is the minimum.  Round-6 sweep on the 14B shapes (profiles/r06/gemm_gm_sweep.log, gemm_gm_fetch.log): the L2 ->
@@ -886,7 +1004,7 @@ static void pk_plan_args(PkArgs& g, int M, int N, int K) {
     if (const int gm = wan_tune(WAN_TUNE_GEMM_GM); gm > 0) g.gm = gm;
     g.nworkers = wan_gemm_pk_workers(M, N);
     // smallest range worth a worker: a quarter of a tile's K range (a tile is then cut into at most ~5 pieces), at least one unit
-    g.min_units = (K / BK / 2 + 3) / 4;
+    g.min_units = (K / ktile / 2 + 3) / 4;
     if (const int mu = wan_tune(WAN_TUNE_GEMM_PK_MIN_UNITS); mu > 0) g.min_units = mu;
     g.dynamic = wan_tune(WAN_TUNE_GEMM_PK_ORDER) != 1;
     g.form = wan_tune(WAN_TUNE_GEMM_PK_FORM);      // bit e: epilogue e (WAN_EPI_*) runs from the row-permuted tile
@@ -901,7 +1019,7 @@ extern "C" int wan_gemm_pk_segment(int M, int N, int K, int worker, int index, i
     PkArgs g;
     pk_plan_args(g, M, N, K);
     if (worker >= g.nworkers) return 0;
-    const Slab slab = make_slab(g, worker);
+    const Slab slab = make_slab(g, worker, g.ktile);
     const Seg e = get_seg(g, slab, index);
     const int v[11] = {e.tm, e.tn, e.kb, e.ke, e.partial, e.slot, e.cnt, e.j_lo, e.j_hi, e.me, e.tau};
     for (int i = 0; i < 11; ++i) out[i] = v[i];
@@ -931,4 +1049,39 @@ wan_status_t wan_gemm_bf16_pk(const void* A, int64_t lda, const void* W, int64_t
         default: wan_set_error("wan_gemm_bf16_ws: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
     }
 #undef WAN_PK
+}
+
+// the e4m3 instantiation (wan_gemm_fp8_ws, gemm_bf16_256.hip): same plan with K tiles of 128 elements; arguments already validated there
+wan_status_t wan_gemm_fp8_pk(const void* A, int64_t lda, const float* a_row_scale, const void* W, int64_t ldw, const float* w_row_scale,
+                             const float* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                             const float* gate, int64_t rows_per_batch, void* workspace, hipStream_t s) {
+    PkArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.gate = gate; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    pk_plan_args(g, M, N, K, 2 * BK);
+    g.sa = a_row_scale; g.sw = w_row_scale;
+    WAN_REQUIRE(g.nworkers <= kMaxWorkers && g.nworkers % 8 == 0, WAN_ERR_INVALID, "wan_gemm_fp8_ws: %d workers (at most %d, a multiple of 8)", g.nworkers, kMaxWorkers);
+    g.counters = (int*)workspace;
+    g.slots = (char*)workspace + kCounterBytes;
+    switch (epilogue) {
+        case WAN_EPI_BF16: return launch_pk<WAN_EPI_BF16, 1, true>(g, s);
+        case WAN_EPI_GELU_BF16: return launch_pk<WAN_EPI_GELU_BF16, 1, true>(g, s);
+        case WAN_EPI_F32: return launch_pk<WAN_EPI_F32, 1, true>(g, s);
+        case WAN_EPI_RESID_F32: return launch_pk<WAN_EPI_RESID_F32, 1, true>(g, s);
+        case WAN_EPI_BF16_T: return launch_pk<WAN_EPI_BF16_T, 1, true>(g, s);
+        default: wan_set_error("wan_gemm_fp8_ws: unknown epilogue %d", epilogue); return WAN_ERR_INVALID;
+    }
+}
+
+// segment `index` of worker `worker` of the e4m3 plan (K tiles of 128 elements): see wan_gemm_pk_segment
+extern "C" int wan_gemm_fp8_pk_segment(int M, int N, int K, int worker, int index, int* out) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 256 != 0 || worker < 0 || index < 0 || out == nullptr) return 0;
+    PkArgs g;
+    pk_plan_args(g, M, N, K, 2 * BK);
+    if (worker >= g.nworkers) return 0;
+    const Slab slab = make_slab(g, worker, g.ktile);
+    const Seg e = get_seg(g, slab, index);
+    const int v[11] = {e.tm, e.tn, e.kb, e.ke, e.partial, e.slot, e.cnt, e.j_lo, e.j_hi, e.me, e.tau};
+    for (int i = 0; i < 11; ++i) out[i] = v[i];
+    return e.valid;
 }

@@ -461,8 +461,11 @@ def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: t
     if epilogue != EPI_BF16_T and tuple(out.shape) != (M, N):
         raise ValueError(f"gemm_fp8: out shape {tuple(out.shape)} != ({M},{N})")
     lib = _lib.load()
-    _lib.check(lib.wan_gemm_fp8(_p(a), a.stride(0), _p(a_scale), _p(w), w.stride(0), _p(w_scale), _p(bias), _p(out),
-                                out.stride(0), M, N, K, epilogue, _p(gate), int(rows_per_batch), _stream()), "wan_gemm_fp8")
+    # the persistent stream-K kernel's e4m3 instantiation where the plan says so (its workspace is the bf16 GEMM's: one per stream)
+    ws = gemm_workspace(dev, M, N, K // 2) if (K % 256 == 0 and lib.wan_gemm_fp8_ws_plan(M, N, K) == 3) else None
+    _lib.check(lib.wan_gemm_fp8_ws(_p(a), a.stride(0), _p(a_scale), _p(w), w.stride(0), _p(w_scale), _p(bias), _p(out),
+                                   out.stride(0), M, N, K, epilogue, _p(gate), int(rows_per_batch), _p(ws),
+                                   ws.numel() if ws is not None else 0, _stream()), "wan_gemm_fp8_ws")
     return out
 
 
