@@ -127,16 +127,16 @@ def test_persistent_gemm_e4m3_all_epilogues(M, N, K):
         ops.set_tuning("gemm_pk", 1)
     o_bf, o_ge, o_f32, o_res, o_t = runs[0]
     assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
-    assert rel_l2(o_f32, acc) < 1e-5 and rel_l2(o_bf, acc) < 4e-3
+    assert rel_l2(o_f32, acc) < 1e-4 and rel_l2(o_bf, acc) < 4e-3          # (fp32 accumulation of e4m3 products: the per-tile kernel's bound)
     x = acc
     assert rel_l2(o_ge, 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))) < 5e-3
     gsel = gate.double()[torch.arange(M, device=DEV) // rpb]
-    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-5
+    assert rel_l2(o_res, resid.double() + acc * gsel) < 1e-4
     assert o_t.shape[0] == N and rel_l2(o_t[:, :M].t(), acc - bias.double()) < 4e-3
     assert float(o_t[:, M:].abs().max()) == 0.0 if o_t.shape[1] > M else True
     for got, ref in zip(runs[0], per_tile):             # same products, another summation order for split tiles only
         assert rel_l2(got, ref.double()) < 4e-3
-    assert rel_l2(runs[0][2], per_tile[2].double()) < 1e-5
+    assert rel_l2(runs[0][2], per_tile[2].double()) < 1e-4
 
 
 def test_persistent_gemm_e4m3_at_the_14b_shapes_vs_the_per_tile_kernel():
@@ -166,7 +166,7 @@ def test_persistent_gemm_e4m3_at_the_14b_shapes_vs_the_per_tile_kernel():
             finally:
                 ops.set_tuning("gemm_pk", 1)
         d = rel_l2(outs[0], outs[1].double())
-        assert d < (1e-5 if epi == ops.EPI_RESID_F32 else 4e-3), (N, K, epi, d)
+        assert d < (1e-4 if epi == ops.EPI_RESID_F32 else 4e-3), (N, K, epi, d)
         assert bool(torch.isfinite(outs[0].float()).all())
         del outs, aq, wq
 
