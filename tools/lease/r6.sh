@@ -138,12 +138,20 @@ PY
     timeout 900 $B 2>$out/bench_default.err | json > $out/bench_14b_final.json
     ;;
   h)  # the e4m3 Linear on the persistent stream-K kernel ("schedule P"): numerics, A/B against the 8-wave per-tile kernel, the lossy bench line
-    timeout 600 python -m pytest tests/test_gpu_fp8.py -x -q -k "gemm" > $out/pytest_fp8_gemm.log 2>&1; tail -5 $out/pytest_fp8_gemm.log
-    timeout 600 python tools/bench_gemm_fp8.py > $out/gemm_fp8_persistent_ab.log 2>&1; cat $out/gemm_fp8_persistent_ab.log
+    if [ "${2:-}" != "bench" ]; then
+      timeout 600 python -m pytest tests/test_gpu_fp8.py -x -q -k "gemm" > $out/pytest_fp8_gemm.log 2>&1; tail -5 $out/pytest_fp8_gemm.log
+      timeout 600 python tools/bench_gemm_fp8.py > $out/gemm_fp8_persistent_ab.log 2>&1; cat $out/gemm_fp8_persistent_ab.log
+    fi
     if [ "${2:-}" = "bench" ]; then
+      ALL="--fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv"
       timeout 900 python -m pytest tests/test_gpu_fp8.py -x -q > $out/pytest_fp8.log 2>&1; tail -3 $out/pytest_fp8.log
-      timeout 600 $B --fp8 --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_fp8.err | json > $out/bench_14b_fp8_everything.json
+      timeout 600 $B $ALL --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_fp8.err | json > $out/bench_14b_fp8_everything.json
       timeout 600 $B --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_bf16.err | json > $out/bench_14b_bf16_same_box.json
+      timeout 600 $B --fp8 --fp8-layers qkv,ffn,o,cross --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_fp8_lin.err | json > $out/bench_14b_fp8_linears_only.json
+      PASSES="trace" PASS_TIMEOUT=600 bash tools/profile_bench.sh r06_fp8_pk $ALL > $out/prof_fp8.log 2>&1
+      cp gpurun_out/prof_r06_fp8_pk/kernel_stats.csv $out/bench14b_fp8_everything_kernel_stats.csv
+      BENCH_ARGS="$ALL" bash tools/profile_bench_sq.sh r06_fp8_pk > $out/profsq_fp8.log 2>&1
+      cp gpurun_out/profsq_r06_fp8_pk/sq_summary.json $out/bench14b_fp8_everything_sq_insitu.json
     fi
     ;;
   *) echo "unknown stage $stage"; exit 2;;

@@ -394,6 +394,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     auto pair8 = [](const u32x4& lo, const u32x4& hi) __attribute__((always_inline)) {
         return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
+#ifndef WAN_PKP_B1
+#define WAN_PKP_B1 12
+#endif
+#ifndef WAN_PKP_STRIDE
+#define WAN_PKP_STRIDE 3
+#endif
+    constexpr int kB1 = WAN_PKP_B1, kReq0 = kB1 + 1, kReqStride = WAN_PKP_STRIDE;
+    static_assert(kB1 >= 9 && kReq0 + 15 * kReqStride < 64, "all reads of the buffer are issued by slot 8; the 16 requests fit the tile");
+    constexpr int kInFlightAtB2 = kReq0 >= 32 ? 0 : (31 - kReq0) / kReqStride + 1 > 16 ? 16 : (31 - kReq0) / kReqStride + 1;     // requests issued before slot 32
     auto ktile_p = [&](int kt, int b) __attribute__((always_inline)) {
         const bool jump = kt + 2 == cur.ke;
         __amdgpu_buffer_rsrc_t ra, rw;
@@ -404,8 +413,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int s_ = ph * 32 + i * 4 + jj, j = ph * 4 + jj;
-            if (s_ == 12) { __builtin_amdgcn_s_barrier(); GP_SB(); ra = rsrc_of(sa); rw = rsrc_of(sq); }
-            if (s_ == 32) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); __builtin_amdgcn_s_barrier(); GP_SB(); }
+            if (s_ == kB1) { __builtin_amdgcn_s_barrier(); GP_SB(); ra = rsrc_of(sa); rw = rsrc_of(sq); }
+            if (s_ == 32) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(kInFlightAtB2) : "memory"); __builtin_amdgcn_s_barrier(); GP_SB(); }
             {
                 const i32x8 a8 = pair8(af[0][i], af[1][i]), w8 = pair8(wf[0][j], wf[1][j]);
                 GP_MFMA8(acc[i][j], a8, w8);
@@ -416,12 +425,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             else if (s_ == 1) advance(sa, 0, jump);
             else if (s_ == 3) advance(sq, 1, jump);
             else if (s_ == 2 || s_ == 4 || s_ == 6 || s_ == 8) fetch8(8 + 4 + (s_ - 2) / 2, b);
-            // K tile kt + 2 -> buffer b: 16 requests, one per 3 MFMAs (96 cycles, as in schedule D)
-            else if (s_ >= 13 && s_ <= 58 && (s_ - 13) % 3 == 0) {
-                const int k = (s_ - 13) / 3;
-                if (k < 8) stage_piece(ra, b, 0, k, g.lda);
-                else stage_piece(rw, b, 1, k - 8, g.ldw);
-            }
             // K tile kt + 1 (buffer 1 - b, published at slot 32): W 0..3 and A 0..6 into registers that have just died
             else if (s_ == 33) fetch8(8 + 0, 1 - b);
             else if (s_ == 35) fetch8(8 + 1, 1 - b);
@@ -434,6 +437,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             else if (s_ == 53) fetch8(4, 1 - b);
             else if (s_ == 56) fetch8(5, 1 - b);
             else if (s_ == 60) fetch8(6, 1 - b);
+            // K tile kt + 2 -> buffer b: 16 requests, one per kReqStride MFMAs (3: 96 cycles, as in schedule D)
+            if (s_ >= kReq0 && s_ < kReq0 + 16 * kReqStride && (s_ - kReq0) % kReqStride == 0) {
+                const int k = (s_ - kReq0) / kReqStride;
+                if (k < 8) stage_piece(ra, b, 0, k, g.lda);
+                else stage_piece(rw, b, 1, k - 8, g.ldw);
+            }
             GP_SB();
         }
     };
