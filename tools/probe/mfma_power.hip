@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i) { a[i] = sm[(threadIdx.x * 8 + i) & 4095]; b[i] = sm[(threadIdx.x * 8 + i + 1024) & 4095]; }
     const u32x4* lp = sm + (threadIdx.x & 63);
     float xs[8], ex[8], sum = 0.f; unsigned pk[4] = {0, 0, 0, 0};
+    unsigned ones; asm volatile("v_mov_b32 %0, 0x3f803f80" : "=v"(ones));
     for (int i = 0; i < 8; ++i) { xs[i] = -0.37f * (float)((threadIdx.x * 7 + i * 13) % 29); ex[i] = 0.f; }
     if constexpr (SHAPE == 32) {
         f32x16 acc[16];
@@ -32,10 +33,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (LDS >= 2) {      // the softmax stream of an attention tile: per 32x32x16 MFMA one v_exp_f32, one v_add_f32, half a v_cvt_pk_bf16_f32
                         // LDS == 3: HALF the exponentials (the optimistic bound of an exponential that produces two values per instruction,
                         // e.g. a packed-f16 form, with nothing else added); LDS == 4: none at all (adds and converts only)
-                        if (LDS == 2 || (LDS == 3 && ((i * 4 + j) & 1) == 0))
+                        if (LDS == 2 || LDS >= 5 || (LDS == 3 && ((i * 4 + j) & 1) == 0))
                         asm volatile("v_exp_f32 %0, %1" : "=v"(ex[(i * 4 + j) & 7]) : "v"(xs[(i * 4 + j) & 7]));
-                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(i * 4 + j + 4) & 7]));
+                        // LDS == 5 (round 6): the row sums taken from the PACKED bf16 pair with one v_dot2c_f32_bf16 (pair . (1, 1) + sum) per
+                        // conversion instead of one v_add_f32 per exponential; LDS == 6: no row-sum instruction at all (the bound of that idea)
+                        if (LDS < 5) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(i * 4 + j + 4) & 7]));
                         if (((i * 4 + j) & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(i * 4 + j) >> 1 & 3]) : "v"(ex[(i * 4 + j) & 7]), "v"(ex[(i * 4 + j + 1) & 7]));
+                        if (LDS == 5 && ((i * 4 + j) & 1) == 0) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(sum) : "v"(pk[((i * 4 + j) >> 1) + 2 & 3]), "v"(ones));
                     }
                 }
             if (LDS) for (int f = 0; f < 4; ++f) { a[f] = a[4 + f]; }
@@ -160,6 +164,9 @@ int main() {
         snprintf(nm, sizeof nm, "MIXED 32x32x16 (QK^T) + 16x16x32 (P.V), %s, + LDS + softmax", d); run_mix(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with HALF the v_exp", d); run<32, 3>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with NO v_exp", d); run<32, 4>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s, + LDS + softmax stream (reference again)", d); run<32, 2>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s, + LDS + stream, row sums by v_dot2c_f32_bf16", d); run<32, 5>(nm, src, out);
+        snprintf(nm, sizeof nm, "32x32x16, %s, + LDS + stream with NO row-sum op", d); run<32, 6>(nm, src, out);
     }
     return 0;
 }
