@@ -148,7 +148,7 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     # cross-attention: one lazy-reference launch, on the PERSISTENT form (10 520 query blocks > 256 CUs; tuning key attn_persist = 1)
     assert vc & 15 == 1 and lib.wan_get_tuning(b"attn_persist") == 1 and seen("attn_fwd_w4_kernel<1, false, 1, false, false, true>")
     # the lossy mode's profile (bench.py --fp8 --fp8-layers qkv,ffn,o,cross,attn,attn_pv): the all-fp8 attention kernel and its fix-up launch
-    # (the fp8-QK^T lazy form), the split tail, the V^T MX quantiser, the fp8 instantiation of the 256^2 GEMM and the K-smoothing kernels
+    # (the fp8-QK^T lazy form), the split tail, the V^T MX quantiser, the e4m3 instantiation of the persistent stream-K GEMM and the K-smoothing kernels
     v8 = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED | 2, ws)
     assert v8 & 15 == 4 and v8 & _lib.ATTN_VARIANT_SPLIT_TAIL
     vf8 = lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED | 2 | 4, ws)        # WAN_ATTN_QK_FP8 | WAN_ATTN_PV_FP8
@@ -158,7 +158,7 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     with open(p8[-1]) as f:
         names8 = [row["Name"] for row in csv.DictReader(f)]
     for sub in ("attn_fwd_f8_kernel", "attn_fwd_w4_kernel<0, false, 1, true, true, false>", "attn_fwd_w4_kernel<0, true, 1, false, true, false>",
-                "vt_quantize_mx_kernel", "gemm256_kernel<3, 2, true>", "col_partial_sums_kernel", "qk_quantize_fp8_kernel"):
+                "vt_quantize_mx_kernel", "gemm_pk_kernel<3, 1, true>", "gemm_pk_kernel<1, 1, true>", "col_partial_sums_kernel", "qk_quantize_fp8_kernel"):
         assert any(sub in n for n in names8), (sub, p8[-1])
     # without scratch, or with plain q: one lazy launch (the packed-shift form for plain q)
     assert lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED, 0) & 15 == 1
