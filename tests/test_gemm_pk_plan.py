@@ -98,3 +98,37 @@ def test_workspace_entry_falls_back_and_validates():
     need = int(lib.wan_gemm_workspace_bytes(67080, 5120, 5120))
     st = lib.wan_gemm_bf16_ws(16, 5120, 16, 5120, None, 16, 5120, 67080, 5120, 5120, 0, None, 0, 16, need - 1, None)
     assert st == _lib.WAN_ERR_INVALID and b"workspace" in lib.wan_last_error()
+
+
+def test_random_shapes_are_covered_exactly_once_property():
+    """Property check of the plan over random shapes (hypothesis; host arithmetic only): whatever (M, N, K) -- one tile, a sliver of a
+    tile, fewer tiles than workers, K of a single unit -- every (output tile, K unit) is computed exactly once, segments are whole units,
+    a split tile's pieces chain in K order, and no two pieces share a workspace slot; bf16 (64-element K tiles) and e4m3 (128)."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    lib = _lib.load()
+
+    @settings(max_examples=40, deadline=None, derandomize=True)
+    @given(M=st.integers(1, 9000), N=st.integers(1, 2400).map(lambda n: 4 * n), units=st.integers(1, 40), fp8=st.booleans())
+    def check(M, N, units, fp8):
+        ktile = 128 if fp8 else 64
+        K = units * 2 * ktile
+        G, segs = plan(lib, M, N, K, fp8)
+        nk, tiles_m, tiles_n = K // ktile, (M + 255) // 256, (N + 255) // 256
+        cover, slots, pieces = collections.Counter(), set(), collections.defaultdict(list)
+        for (w, i, tm, tn, kb, ke, partial, slot, cnt, jlo, jhi, me, tau) in segs:
+            assert 0 <= tm < tiles_m and 0 <= tn < tiles_n and 0 <= kb < ke <= nk and kb % 2 == 0 and ke % 2 == 0
+            for k in range(kb, ke, 2):
+                cover[(tm, tn, k)] += 1
+            assert bool(partial) == (not (kb == 0 and ke == nk))
+            if partial:
+                assert slot not in slots and 0 <= cnt < 512
+                slots.add(slot)
+                pieces[(w % 8, cnt)].append((kb, ke, me, jlo, jhi))
+        assert len(cover) == tiles_m * tiles_n * nk // 2 and set(cover.values()) == {1}, (M, N, K, fp8)
+        for ps in pieces.values():
+            ps.sort()
+            assert ps[0][0] == 0 and ps[-1][1] == nk and all(a[1] == b[0] for a, b in zip(ps, ps[1:]))
+            assert [p[2] for p in ps] == list(range(ps[0][3], ps[0][4] + 1))
+
+    check()
