@@ -200,7 +200,8 @@ __device__ __forceinline__ u32x4 lds16(const char* p) { return *reinterpret_cast
 //     (this tile!) during phase 0 -- they are first needed at slot 32;
 //   * A i is last read at slot 35 + 4 i and first needed at slot 4 i of the next tile: every refill has >= 28 slots (~900 cycles);
 //   * all reads of a tile's buffer are issued by slot 8 of its own tile (A 7 and W 4..7, whose registers the previous tile held to
-//     its end): barrier B1 at slot 12 frees the buffer, the 16 requests of K tile t + 2 go out at slots 13, 16, ... 58, and barrier
+//     its end): barrier B1 at slot 12 (behind `lgkmcnt(0)`: those reads have returned) frees the buffer, the 16 requests of K tile t + 2
+//     go out at slots 13, 16, ... 58, and barrier
 //     B2 at slot 32 (`vmcnt(7)`: the seven requests issued since B1 stay in flight) publishes K tile t + 1, whose last request left
 //     38 slots (~1 200 cycles) earlier.
 // Two barriers, 32 fragment reads and 16 requests per 2 048 matrix-pipe cycles -- what schedule D has -- with half the MFMA issues.
@@ -413,6 +414,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int s_ = ph * 32 + i * 4 + jj, j = ph * 4 + jj;
+            // B1: my reads of buffer b have RETURNED (not merely been issued) before I say so -- measured free (the last one is 4 slots old:
+            // profiles/r06/gemm_fp8_schedule_p_b1_wait.log), so the hand-over of the buffer does not lean on DMA latency
+            if (s_ == kB1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             if (s_ == kB1) { __builtin_amdgcn_s_barrier(); GP_SB(); ra = rsrc_of(sa); rw = rsrc_of(sq); }
             if (s_ == 32) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(kInFlightAtB2) : "memory"); __builtin_amdgcn_s_barrier(); GP_SB(); }
             {
