@@ -114,6 +114,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Round 6: would TWO waves per SIMD on 16x16x32 (an 8-wave workgroup, 32 query rows per wave: half the accumulators, every K / V^T fragment
+// read feeding 2 MFMAs instead of 4) lift the issue bound that holds the one-wave 16x16x32 form at 1.35-1.43?  Same softmax stream and
+// FLOPs per iteration pair as k<16, 2>: per wave and iteration 32 MFMAs, 16 ds_read_b128, 16 v_exp + 16 v_add + 8 v_cvt_pk.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k8w(const u32x4* src, float* out, int iters) {
+    __shared__ u32x4 sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 512) sm[i] = src[i];
+    __syncthreads();
+    u32x4 a[4], b[8];
+    for (int i = 0; i < 4; ++i) a[i] = sm[(threadIdx.x * 8 + i) & 4095];
+    for (int i = 0; i < 8; ++i) b[i] = sm[(threadIdx.x * 8 + i + 1024) & 4095];
+    const u32x4* lp = sm + (threadIdx.x & 63);
+    float xs[8], ex[8], sum = 0.f; unsigned pk[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) { xs[i] = -0.37f * (float)((threadIdx.x * 7 + i * 13) % 29); ex[i] = 0.f; }
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i * 8 + j]) : "v"(a[i]), "v"(b[j]));
+                if (((i * 8 + j) & 1) == 0) { const int f = (i * 8 + j) / 2; if (f < 4) a[f] = lp[(f * 64 + it * 7) & 4032]; else if (f < 12) b[f - 4] = lp[(f * 64 + it * 5) & 4032]; else a[f - 12] = lp[(f * 64 + it * 3) & 4032]; }
+                if (((i * 8 + j) & 1) == 0) {
+                    const int q = (i * 8 + j) >> 1;
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(ex[q & 7]) : "v"(xs[q & 7]));
+                    asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(ex[(q + 4) & 7]));
+                    if ((q & 1) == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(q >> 1) & 3]) : "v"(ex[q & 7]), "v"(ex[(q + 1) & 7]));
+                }
+            }
+    }
+    float s = sum + (float)pk[0] + (float)pk[1] + (float)pk[2] + (float)pk[3]; for (int i = 0; i < 32; ++i) s += acc[i][0];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+void run_8w(const char* name, const u32x4* src, float* out) {
+    const int iters = 10000;                                  // 8 waves x 32 MFMAs = the 4 waves x 64 of k<16, .> per iteration
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k8w, dim3(256), dim3(512), 0, 0, src, out, iters / 10);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k8w, dim3(256), dim3(512), 0, 0, src, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 256.0 * 8 * iters * (32 * 16.0 * 16 * 32 * 2);
+        printf("%-58s %8.3f ms  %7.0f TFLOP/s\n", name, ms, fl / ms / 1e9);
+    }
+}
+
 void run_mix(const char* name, const u32x4* src, float* out) {
     const int iters = 40000;                                  // 16 x 32x32x16-equivalents per iteration, as run<32, .>
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -145,7 +193,7 @@ template <int SHAPE, int LDS> void run(const char* name, const u32x4* src, float
 }
 int main() {
     std::vector<unsigned> h(4096 * 4);
-    u32x4* src; float* out; hipMalloc(&src, 65536); hipMalloc(&out, 256 * 256 * 4);
+    u32x4* src; float* out; hipMalloc(&src, 65536); hipMalloc(&out, 256 * 512 * 4);
     for (int pass = 0; pass < 2; ++pass) {
         srand(1);
         for (auto& x : h) {                                   // two bf16 values ~ U(-1, 1) per word, or zeros
@@ -164,6 +212,7 @@ int main() {
         snprintf(nm, sizeof nm, "MIXED 32x32x16 (QK^T) + 16x16x32 (P.V), %s, + LDS + softmax", d); run_mix(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with HALF the v_exp", d); run<32, 3>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS reads + stream with NO v_exp", d); run<32, 4>(nm, src, out);
+        snprintf(nm, sizeof nm, "16x16x32, TWO waves / SIMD, %s, + LDS (1 per 2 MFMA) + softmax", d); run_8w(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS + softmax stream (reference again)", d); run<32, 2>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS + stream, row sums by v_dot2c_f32_bf16", d); run<32, 5>(nm, src, out);
         snprintf(nm, sizeof nm, "32x32x16, %s, + LDS + stream with NO row-sum op", d); run<32, 6>(nm, src, out);
