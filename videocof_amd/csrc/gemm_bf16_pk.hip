@@ -395,6 +395,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     auto pair8 = [](const u32x4& lo, const u32x4& hi) __attribute__((always_inline)) {
         return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
+// (developer A/B builds only, never set by the Makefile: where barrier B1 sits and how densely the requests follow it --
+// profiles/r06/gemm_fp8_schedule_p_variants.log: B1 at slot 9 / 12 / 16 within 0.5 %, one request per 2 MFMAs instead of 3 loses 2-5 %)
 #ifndef WAN_PKP_B1
 #define WAN_PKP_B1 12
 #endif
