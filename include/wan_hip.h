@@ -182,13 +182,15 @@ int wan_gemm_pk_segment(int M, int N, int K, int worker, int index, int* out);
 wan_status_t wan_gemm_fp8(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
                           const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
                           int epilogue, const float* gate, int64_t rows_per_batch, void* stream);
-/* wan_gemm_fp8_ws: wan_gemm_fp8 with a caller workspace (wan_gemm_workspace_bytes(M, N, K / 2) bytes, 16-byte aligned, not shared
+/* wan_gemm_fp8_ws: wan_gemm_fp8 with a caller workspace (wan_gemm_fp8_workspace_bytes(M, N, K) bytes, 16-byte aligned, not shared
  * with another stream; w_row_scale 16-byte aligned).  Shapes whose bf16 product of the same TILE count would run on the persistent
- * stream-K kernel (wan_gemm_fp8_ws_plan == WAN_GEMM_VARIANT_256_PK: K % 256 == 0 and wan_gemm_ws_plan(M, N, K / 2) says so) run its
+ * stream-K kernel (wan_gemm_fp8_ws_plan == WAN_GEMM_VARIANT_256_PK: K % 256 == 0 and wan_gemm_ws_plan(M, N, K / 2) says so, or K >= 4096
+ * and wan_gemm_ws_plan(M, N, K) does: the 8-way Ulysses shard) run its
  * e4m3 instantiation -- same segments, stream-K combine (bitwise reproducible) and epilogues, 128-element K tiles consumed by one
  * v_mfma_scale_f32_16x16x128_f8f6f4 per output tile in two phases ("schedule P", gemm_bf16_pk.hip); everything else, and a NULL
  * workspace, is wan_gemm_fp8.  wan_gemm_fp8_pk_segment: wan_gemm_pk_segment for that plan (K tiles of 128 elements). */
 int wan_gemm_fp8_ws_plan(int M, int N, int K);
+int64_t wan_gemm_fp8_workspace_bytes(int M, int N, int K);
 wan_status_t wan_gemm_fp8_ws(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
                              const float* w_row_scale, const float* bias, void* out, int64_t ldo, int M, int N, int K,
                              int epilogue, const float* gate, int64_t rows_per_batch, void* workspace, int64_t workspace_bytes,

@@ -91,6 +91,11 @@ def test_workspace_entry_falls_back_and_validates():
     assert lib.wan_gemm_fp8_ws_plan(67080, 5120, 5120) == 3 and lib.wan_gemm_fp8_ws_plan(67080, 5120, 13824) == 3
     assert lib.wan_gemm_fp8_ws_plan(67080, 5120, 1536) == 1 and lib.wan_gemm_fp8_ws_plan(67080, 5120, 5120 + 128) == 1
     assert lib.wan_gemm_fp8_ws_plan(515, 64, 1024) == 1
+    # ... and the 8-way Ulysses shard (M = 8 392: 660 tiles of 40 K tiles) runs persistent too: measured 1.09-1.33x the per-tile kernel
+    assert lib.wan_gemm_fp8_ws_plan(8392, 5120, 5120) == 3 and lib.wan_gemm_fp8_ws_plan(8392, 5120, 13824) == 3
+    assert lib.wan_gemm_fp8_ws_plan(8392, 5120, 2048) == 1 and lib.wan_gemm_ws_plan(8392, 5120, 2560) == 1
+    assert lib.wan_gemm_fp8_workspace_bytes(8392, 5120, 5120) == lib.wan_gemm_workspace_bytes(8392, 5120, 5120) > 0
+    assert lib.wan_gemm_fp8_workspace_bytes(8392, 5120, 2048) == 0 and lib.wan_gemm_fp8_workspace_bytes(67080, 5120, 5120 + 128) == 0
     assert lib.wan_gemm_fp8_ws(None, 128, None, None, 128, None, None, None, 64, 4, 64, 128, 0, None, 0, None, 0, None) == _lib.WAN_ERR_INVALID
     assert lib.wan_gemm_ws_plan(6240, 6240, 384) == lib.wan_gemm_plan(6240, 6240, 384) == 1
     assert lib.wan_gemm_ws_plan(2304, 3072, 1536) == lib.wan_gemm_plan(2304, 3072, 1536) == 0              # < 1 tile per 2 CUs: the 128^2 kernel

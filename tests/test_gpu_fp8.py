@@ -111,7 +111,7 @@ def test_persistent_gemm_e4m3_all_epilogues(M, N, K):
     ops.set_tuning("gemm_pk", 2)                       # 2 = whenever the shape rules allow (the default takes the big Linears only)
     try:
         assert _lib.load().wan_gemm_fp8_ws_plan(M, N, K) == 3
-        ws = ops.gemm_workspace(aq.device, M, N, K // 2)
+        ws = ops.gemm_workspace(aq.device, M, N, K, fp8=True)
         assert ws is not None
         runs = []
         for rep in range(2):
@@ -139,11 +139,11 @@ def test_persistent_gemm_e4m3_all_epilogues(M, N, K):
     assert rel_l2(runs[0][2], per_tile[2].double()) < 1e-4
 
 
-def test_persistent_gemm_e4m3_at_the_14b_shapes_vs_the_per_tile_kernel():
-    """The default dispatch at the headline shapes (M = 67 080; q|k, ffn.0 + GELU, ffn.2 + gate + residual, V^T): the e4m3 Linears run
-    the persistent kernel and agree with the 8-wave per-tile kernel on the same quantised operands."""
+@pytest.mark.parametrize("M", [67080, 8392])
+def test_persistent_gemm_e4m3_at_the_14b_shapes_vs_the_per_tile_kernel(M):
+    """The default dispatch at the headline shapes (M = 67 080, and the 8-way Ulysses shard's 8 392; q|k, ffn.0 + GELU, ffn.2 + gate +
+    residual, V^T): the e4m3 Linears run the persistent kernel and agree with the 8-wave per-tile kernel on the same quantised operands."""
     from videocof_amd import _lib
-    M = 67080
     g = torch.Generator(device=DEV).manual_seed(5)
     for (N, K, epi) in [(10240, 5120, ops.EPI_BF16), (13824, 5120, ops.EPI_GELU_BF16), (5120, 13824, ops.EPI_RESID_F32), (5120, 5120, ops.EPI_BF16_T)]:
         a = torch.randn(M, K, device=DEV, generator=g).bfloat16()

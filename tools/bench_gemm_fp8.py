@@ -11,7 +11,8 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from videocof_amd import ops  # noqa: E402
 
 dev = "cuda:0"
-L = 67080
+L = 8392 if "--sp8" in sys.argv else 67080          # --sp8: the token count of an 8-way Ulysses shard (the plan may keep those per-tile: --force-pk)
+PK_ON = 2 if "--force-pk" in sys.argv else 1
 shapes = [("q|k", L, 10240, 5120, ops.EPI_BF16), ("o / cross-q", L, 5120, 5120, ops.EPI_BF16), ("ffn.0+gelu", L, 13824, 5120, ops.EPI_GELU_BF16),
           ("ffn.2+resid", L, 5120, 13824, ops.EPI_RESID_F32), ("v (T)", L, 5120, 5120, ops.EPI_BF16_T)]
 g = torch.Generator(device=dev).manual_seed(0)
@@ -31,7 +32,7 @@ for name, M, N, K, epi in shapes:
     kw = dict(gate=gate, rows_per_batch=M) if gate is not None else {}
     obf = out if out.dtype == torch.float32 or epi == ops.EPI_BF16_T else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     arms = [("e4m3 per-tile (8 waves)", 0, lambda: ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)),
-            ("e4m3 persistent       ", 1, lambda: ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)),
+            ("e4m3 persistent       ", PK_ON, lambda: ops.gemm_fp8(aq, asc, wq, wsc, bias, epi, out=out, **kw)),
             ("bf16 persistent       ", 1, lambda: ops.gemm(a, w, bias, epi, out=obf, **kw))]
     best = {}
     for rnd in range(3):

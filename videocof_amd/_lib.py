@@ -125,6 +125,7 @@ SIGNATURES = {
     "wan_gemm_fp8_ws": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "wan_gemm_fp8_ws_plan": (c_int, [c_int, c_int, c_int]),
+    "wan_gemm_fp8_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "wan_gemm_fp8_pk_segment": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "wan_quantize_rows_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "wan_ln_modulate_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int64,

@@ -468,12 +468,18 @@ extern "C" wan_status_t wan_gemm_bf16_ws(const void* A, int64_t lda, const void*
 }
 
 // The e4m3 Linear with a caller workspace: the persistent stream-K kernel's FP8 instantiation (gemm_bf16_pk.hip, "schedule P") where
-// the bf16 product of the same tile count would run persistent -- a K tile is 128 e4m3 elements, so the plan is asked about K / 2 --
-// and wan_gemm_fp8 (the 8-wave per-tile kernel) otherwise.  Same contract as wan_gemm_bf16_ws: the workspace
-// (wan_gemm_workspace_bytes(M, N, K / 2) bytes) is not shared with another stream.
+// the bf16 product of the same TILE count would run persistent -- a K tile is 128 e4m3 elements, so the plan is asked about K / 2 --
+// or where the bf16 product of the same SHAPE would and K >= 4096 (the 8-way Ulysses shard's M = 8 392: 660 tiles of 40 K tiles; measured
+// 1.09-1.33x the per-tile kernel there, profiles/r06/gemm_fp8_sp8_shard.log); wan_gemm_fp8 (the 8-wave per-tile kernel) otherwise.
+// Same contract as wan_gemm_bf16_ws: the workspace (wan_gemm_fp8_workspace_bytes(M, N, K) bytes) is not shared with another stream.
 extern "C" int wan_gemm_fp8_ws_plan(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 256 != 0) return WAN_GEMM_VARIANT_256_W8;
-    return wan_gemm_ws_plan(M, N, K / 2) == WAN_GEMM_VARIANT_256_PK ? WAN_GEMM_VARIANT_256_PK : WAN_GEMM_VARIANT_256_W8;
+    if (wan_gemm_ws_plan(M, N, K / 2) == WAN_GEMM_VARIANT_256_PK) return WAN_GEMM_VARIANT_256_PK;
+    return (K >= 4096 && wan_gemm_ws_plan(M, N, K) == WAN_GEMM_VARIANT_256_PK) ? WAN_GEMM_VARIANT_256_PK : WAN_GEMM_VARIANT_256_W8;
+}
+
+extern "C" int64_t wan_gemm_fp8_workspace_bytes(int M, int N, int K) {
+    return wan_gemm_fp8_ws_plan(M, N, K) == WAN_GEMM_VARIANT_256_PK ? wan_gemm_pk_workspace_bytes(M, N) : 0;
 }
 
 extern "C" wan_status_t wan_gemm_fp8_ws(const void* A_fp8, int64_t lda, const float* a_row_scale, const void* W_fp8, int64_t ldw,
@@ -494,7 +500,7 @@ extern "C" wan_status_t wan_gemm_fp8_ws(const void* A_fp8, int64_t lda, const fl
     WAN_REQUIRE(gate == nullptr || (epilogue == WAN_EPI_RESID_F32 && rows_per_batch > 0), WAN_ERR_INVALID,
                 "wan_gemm_fp8_ws: gate needs WAN_EPI_RESID_F32 and rows_per_batch > 0");
     WAN_REQUIRE(workspace_bytes >= wan_gemm_pk_workspace_bytes(M, N), WAN_ERR_INVALID,
-                "wan_gemm_fp8_ws: workspace of %lld bytes, wan_gemm_workspace_bytes(%d, %d, %d) = %lld", (long long)workspace_bytes, M, N, K / 2,
+                "wan_gemm_fp8_ws: workspace of %lld bytes, wan_gemm_fp8_workspace_bytes(%d, %d, %d) = %lld", (long long)workspace_bytes, M, N, K,
                 (long long)wan_gemm_pk_workspace_bytes(M, N));
     WAN_REQUIRE(((uintptr_t)workspace & 15) == 0, WAN_ERR_INVALID, "wan_gemm_fp8_ws: workspace must be 16-byte aligned");
     return wan_gemm_fp8_pk(A_fp8, lda, a_row_scale, W_fp8, ldw, w_row_scale, bias, out, ldo, M, N, K, epilogue, gate, rows_per_batch, workspace,

@@ -282,7 +282,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogu
 _GEMM_WS = {}
 
 
-def gemm_workspace(dev: torch.device, M: int, N: int, K: int) -> Optional[torch.Tensor]:
+def gemm_workspace(dev: torch.device, M: int, N: int, K: int, fp8: bool = False) -> Optional[torch.Tensor]:
     """The caller-owned workspace of ``wan_gemm_bf16_ws`` (the persistent stream-K GEMM's partial tiles, arrival and
     ticket counters): ONE buffer per (device, STREAM), grown to the largest request and then kept for the life of the
     process.  The kernel keeps its counters and split-tile partial sums in it, so two launches that share a workspace must
@@ -293,8 +293,8 @@ def gemm_workspace(dev: torch.device, M: int, N: int, K: int) -> Optional[torch.
     of that device, whose replays must not overlap each other; when a capture asks for more than the capture workspace holds, a new
     buffer is allocated and the old one stays alive for the launches already recorded.  The buffer is NOT cleared here -- the launch clears the
     4 KiB of counters it uses with a memset node of its own.  None when the shape does not use a workspace
-    (``wan_gemm_workspace_bytes`` == 0)."""
-    need = int(_lib.load().wan_gemm_workspace_bytes(M, N, K))
+    (``wan_gemm_workspace_bytes`` == 0).  ``fp8``: the request of the e4m3 Linear (``wan_gemm_fp8_workspace_bytes``; same buffer)."""
+    need = int(_lib.load().wan_gemm_fp8_workspace_bytes(M, N, K) if fp8 else _lib.load().wan_gemm_workspace_bytes(M, N, K))
     if need <= 0:
         return None
     index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -462,7 +462,7 @@ def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: t
         raise ValueError(f"gemm_fp8: out shape {tuple(out.shape)} != ({M},{N})")
     lib = _lib.load()
     # the persistent stream-K kernel's e4m3 instantiation where the plan says so (its workspace is the bf16 GEMM's: one per stream)
-    ws = gemm_workspace(dev, M, N, K // 2) if (K % 256 == 0 and lib.wan_gemm_fp8_ws_plan(M, N, K) == 3) else None
+    ws = gemm_workspace(dev, M, N, K, fp8=True)
     _lib.check(lib.wan_gemm_fp8_ws(_p(a), a.stride(0), _p(a_scale), _p(w), w.stride(0), _p(w_scale), _p(bias), _p(out),
                                    out.stride(0), M, N, K, epilogue, _p(gate), int(rows_per_batch), _p(ws),
                                    ws.numel() if ws is not None else 0, _stream()), "wan_gemm_fp8_ws")
