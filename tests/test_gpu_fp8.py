@@ -109,6 +109,7 @@ def test_persistent_gemm_e4m3_all_epilogues(M, N, K):
                 ops.gemm_fp8(aq, sa, wq, sw, bias, ops.EPI_F32), o_res, ops.gemm_fp8(aq, sa, wq, sw, None, ops.EPI_BF16_T))
 
     ops.set_tuning("gemm_pk", 2)                       # 2 = whenever the shape rules allow (the default takes the big Linears only)
+    ops.set_tuning("gemm_pk_min_units", max(1, (K // 256 + 3) // 4))        # the stream-K cut at a quarter tile, whatever the plan would choose
     try:
         assert _lib.load().wan_gemm_fp8_ws_plan(M, N, K) == 3
         ws = ops.gemm_workspace(aq.device, M, N, K, fp8=True)
@@ -117,8 +118,12 @@ def test_persistent_gemm_e4m3_all_epilogues(M, N, K):
         for rep in range(2):
             ws.fill_(0xA5 if rep else 0xFF)
             runs.append(run_all())
+        ops.set_tuning("gemm_pk_min_units", 0)         # ... and the plan's own choice (whole leftover tiles at some of these shapes)
+        own = run_all()
     finally:
         ops.set_tuning("gemm_pk", 1)
+        ops.set_tuning("gemm_pk_min_units", 0)
+    assert rel_l2(own[2], acc) < 1e-4 and rel_l2(own[0], acc) < 4e-3
     ops.set_tuning("gemm_pk", 0)
     try:
         assert _lib.load().wan_gemm_fp8_ws_plan(M, N, K) == 1

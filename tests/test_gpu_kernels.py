@@ -753,6 +753,9 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, form):
     rpb = (M + 1) // 2
     ops.set_tuning("gemm_pk", 2)                       # 2 = whenever K % 128 == 0 (the default takes shapes the 4-wave kernel would)
     ops.set_tuning("gemm_pk_form", 31 if form else 0)
+    # the stream-K cut at a quarter of a tile's K range, whatever the plan's own choice for the shape (round 6: leftover tiles of short
+    # launches go whole where the fix-up would cost more than the idle lanes -- this test is about the cut)
+    ops.set_tuning("gemm_pk_min_units", max(1, (K // 128 + 3) // 4))
     try:
         from videocof_amd import _lib
         assert _lib.load().wan_gemm_ws_plan(M, N, K) == 3
@@ -765,9 +768,13 @@ def test_persistent_stream_k_gemm_all_epilogues(M, N, K, form):
             ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=o_res, gate=gate.to(DEV), rows_per_batch=rpb)
             runs.append((ops.gemm(ad, wd, bd, ops.EPI_BF16), ops.gemm(ad, wd, bd, ops.EPI_GELU_BF16), ops.gemm(ad, wd, bd, ops.EPI_F32),
                          o_res, ops.gemm(ad, wd, None, ops.EPI_BF16_T)))
+        ops.set_tuning("gemm_pk_min_units", 0)         # ... and once with the plan's own choice (whole leftover tiles at some of these shapes)
+        own = (ops.gemm(ad, wd, bd, ops.EPI_BF16), ops.gemm(ad, wd, bd, ops.EPI_F32))
     finally:
         ops.set_tuning("gemm_pk", 1)
         ops.set_tuning("gemm_pk_form", 31)
+        ops.set_tuning("gemm_pk_min_units", 0)
+    assert rel_l2(own[0], acc) < 4e-3 and rel_l2(own[1], acc) < 1e-5
     o_bf, o_ge, o_f32, o_res, o_t = runs[0]
     assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
     assert rel_l2(o_bf, acc) < 4e-3 and rel_l2(o_f32, acc) < 1e-5

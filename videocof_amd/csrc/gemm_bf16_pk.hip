@@ -1020,6 +1020,19 @@ static void pk_plan_args(PkArgs& g, int M, int N, int K, int ktile = BK) {
     g.nworkers = wan_gemm_pk_workers(M, N);
     // smallest range worth a worker: a quarter of a tile's K range (a tile is then cut into at most ~5 pieces), at least one unit
     g.min_units = (K / ktile / 2 + 3) / 4;
+    // ... unless cutting costs more than it saves.  The S leftover tiles of an XCD's slab (S = slab mod W lanes) either go WHOLE to S lanes
+    // while W - S lanes idle for one tile -- (W - S) / W x n2 units of a lane's time (n2 = units per tile) -- or are cut stream-K fashion, whose
+    // fix-up (the partial tiles' 256 KiB round trips through the workspace, the arrival counter, the last arriver's serial combine ahead of
+    // its epilogue) was measured at ~ 9 + 0.36 n2 units (profiles/r06/gemm_split.log: whole tiles +7...+10 % on the 660 tiles of the 8-way
+    // Ulysses shard's N = K = 5 120 Linears, +4 % at its K = 13 824, +4...+5 % on the 1.3B model's K = 1 536 ones, -4 % where a slab leaves
+    // 5 of 32 lanes' worth).  Whole tiles (min_units = n2: range j is exactly tile j) when the idle time is the smaller price -- for launches of
+    // at most 16 rounds only: behind 20+ rounds of tiles drawn by ticket the lanes no longer end together and either form is within +-1 %
+    // (the 14B Linears at M = 67 080 stay as they were).
+    {
+        const int n2 = K / ktile / 2, W = g.nworkers >> 3;
+        const int slab = g.tiles_m * g.tiles_n / 8, S = slab % W;
+        if (S > 0 && n2 > 0 && slab / W <= 16 && (int64_t)(W - S) * n2 * 100 < (int64_t)W * (900 + 36 * n2)) g.min_units = n2;
+    }
     if (const int mu = wan_tune(WAN_TUNE_GEMM_PK_MIN_UNITS); mu > 0) g.min_units = mu;
     g.dynamic = wan_tune(WAN_TUNE_GEMM_PK_ORDER) != 1;
     g.form = wan_tune(WAN_TUNE_GEMM_PK_FORM);      // bit e: epilogue e (WAN_EPI_*) runs from the row-permuted tile
