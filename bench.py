@@ -35,6 +35,9 @@ Rank 0 prints ONE JSON line; it also carries
                    compare across boxes and rounds (the chips are power-limited here and differ by ~4 %);
   rank_wall_s   -- (N > 1) every rank's own wall clock of the timed region and max / min.
 `--force-sp` runs the whole sequence-parallel line over a 1-rank RCCL group (code path, not scaling).
+`--emulate-sp P` (one GPU) runs what ONE rank of a P-way Ulysses group computes -- the shard shapes of every kernel, device-local
+copies where the exchanges would be (videocof_amd.dist.EmulatedRank) -- and prints a PROJECTION line: the compute-side bound of a
+P-GPU run, not a measurement of one (`projection` object; `parity` is skipped, the output is not a latent).
 """
 from __future__ import annotations
 
@@ -510,6 +513,9 @@ def main():
                     help="ONE rank, the whole sequence-parallel line: a 1-rank RCCL process group + model.force_ulysses -- every exchange is a "
                          "real (identity) RCCL all-to-all issued async on the group's stream, the parity probe is gathered through the group, "
                          "the walls through all_gather: the N > 1 code path of this file on a box with one GPU.  Never a headline line.")
+    ap.add_argument("--emulate-sp", type=int, default=0, metavar="P",
+                    help="one GPU: run what ONE rank of a P-way Ulysses group computes (shard shapes, device-local copies in place of "
+                         "the exchanges) and print a PROJECTION of the P-GPU line's compute side; not a measurement of P GPUs")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-box-probe", action="store_true",
                     help="skip the ~0.4 s box fingerprint (wan_box_probe) before and after the timed region")
@@ -553,6 +559,9 @@ def main():
     from videocof_amd import dist as vdist
     from videocof_amd.weights import random_dit_state_dict
 
+    emu = int(args.emulate_sp) if world == 1 else 0
+    if emu and (emu < 2 or args.force_sp or args.graph or args.graph_loop or args.mode != "sp"):
+        raise SystemExit("--emulate-sp P: P >= 2, on one GPU, without --force-sp / --graph / --graph-loop / --mode dp")
     force_sp = args.force_sp and world == 1
     if force_sp:
         import socket
@@ -584,7 +593,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.layers > 0:
         wl["num_layers"] = min(args.layers, wl["num_layers"])
-    sp = (world > 1 or force_sp) and args.mode == "sp"
+    sp = (world > 1 or force_sp or emu > 0) and args.mode == "sp"
+    sp_degree = emu if emu else world          # the Ulysses degree the shapes of this run belong to
     # (num_heads % world != 0 -- the 12-head 1.3B model on 8 GPUs -- runs with heads padded to a multiple of the degree:
     # WanTransformer3DModel._pad_heads_for_ulysses; the line says so in config.sp_padded_heads)
 
@@ -606,7 +616,10 @@ def main():
     if args.fp8:
         model.enable_fp8_linear(tuple(args.fp8_layers.split(",")), attn_smooth_k=not args.fp8_no_smooth_k)
     if sp:
-        vdist.init_sequence_parallel()
+        if emu:
+            vdist.init_sequence_parallel(backend="emulated", rank=0, world_size=emu)
+        else:
+            vdist.init_sequence_parallel()
         model.enable_multi_gpus_inference()
         model.force_ulysses = force_sp
     Fs, G, Ft = wl["fs"], wl["g"], wl["ft"]
@@ -710,7 +723,9 @@ def main():
     # sharded forward's output -- exchanges, rank-offset RoPE, padded-key masking, final all-gather and all -- against the oracle's
     # single-device block + head + unpatchify on the gathered stream.
     parity = None
-    if not args.no_verify and (rank == 0 or sp) and not args.graph_loop:
+    if emu:
+        parity = {"skipped": "--emulate-sp: the arrived operands are this rank's own slabs, the output is not a denoised latent"}
+    elif not args.no_verify and (rank == 0 or sp) and not args.graph_loop:
         model._attn_events = None
         model._comm_events = None
         model.mask_source_frames = 0
@@ -743,14 +758,14 @@ def main():
     if prof:
         ms = [a.elapsed_time(b) for a, b in prof]
         avg_ms = sum(ms) / len(ms)
-        heads_local = (model._sp_pad.H if getattr(model, "_sp_pad", None) is not None else wl["num_heads"]) // (world if sp else 1)
+        heads_local = (model._sp_pad.H if getattr(model, "_sp_pad", None) is not None else wl["num_heads"]) // (sp_degree if sp else 1)
         Lk = L
         Lq = model._last_attn_rows
         flop = 4.0 * Lq * Lk * heads_local * 128
         ach = flop / (avg_ms * 1e-3) / 1e12
         from videocof_amd import _lib
         vcode = int(model._last_attn_variant)
-        traffic, traffic_detail = pmc_traffic(args.workload, world if sp else 1, vcode)
+        traffic, traffic_detail = pmc_traffic(args.workload, sp_degree if sp else 1, vcode)
         hdr = model._ws_self.buf[:16].view(torch.int32).tolist() if model._ws_self.buf is not None else [None] * 4
         repairs = hdr[2]
         roof = {"kernel": "self-attention wan_attention_fwd: " + _lib.attn_variant_name(vcode), "variant_code": vcode,
@@ -794,7 +809,8 @@ def main():
                    "tokens_per_sample": L, "global_batch": units, "guidance_scale": 1.0,
                    "layers_override": (wl["num_layers"] if args.layers > 0 else None),
                    "sp_padded_heads": (model._sp_pad.pad_heads if getattr(model, "_sp_pad", None) is not None else None),
-                   "parallelism": ("ulysses-sp%d" % world) if sp else ("replicas-dp%d" % world if world > 1 else "single")},
+                   "parallelism": ("EMULATED rank 0 of ulysses-sp%d on one GPU (projection)" % emu) if emu else
+                                  ("ulysses-sp%d" % world) if sp else ("replicas-dp%d" % world if world > 1 else "single")},
         "tokens_per_s_per_gpu": round(value / world, 1),
         "sec_per_video_4step": round(wall / args.steps * 4, 3),
         "denoised_only_tokens_per_s": round(value * (G + Ft) / Ftot, 1),
@@ -815,7 +831,18 @@ def main():
         "attn_stress": bool(args.attn_stress),
         "fp8_attn_smooth_k": (not args.fp8_no_smooth_k) if (args.fp8 and "attn" in args.fp8_layers.split(",")) else None,
     }
-    if rank == 0 and world == 1 and not force_sp and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
+    if emu:
+        res["metric"] = "PROJECTION (one rank of a %d-way Ulysses group emulated on one GPU): " % emu + res["metric"]
+        res["tokens_per_s_per_gpu"] = round(value / emu, 1)
+        res["mfma_frac_whole_step"] = round(tot_flop * args.steps / wall / 1e12 / (PEAK_BF16_TFLOPS * emu), 4)
+        res["projection"] = {
+            "of_n_gpus": emu, "emulated_rank": 0, "ms_per_step_compute_side": round(wall / args.steps * 1e3, 2),
+            "what": "ONE GPU ran what rank 0 of %d computes per step -- token-local kernels on L/%d rows, self-attention on H/%d heads over all "
+                    "L keys, wire layouts, pack / unpack passes, head-group pipelining -- with device-local copies of the send buffers where "
+                    "the RCCL exchanges would be.  `value` = L * steps / wall: the whole-job rate a %d-GPU run reaches if every rank takes "
+                    "this long, i.e. its compute-side bound; exposed xGMI time comes on top.  No byte crossed a link; the output is not a "
+                    "latent (parity skipped)." % (emu, emu, emu, emu)}
+    if rank == 0 and world == 1 and not force_sp and not emu and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
         try:        # the metric's second half (sec / video of a whole edit); separate from the timed region above, never takes it down
             res["e2e"] = e2e_edit(model, wl, dev)
         except Exception as e:
@@ -823,7 +850,7 @@ def main():
     if rank == 0 and isinstance(res.get("e2e"), dict) and "error" not in res["e2e"]:
         res["e2e"]["ingest"] = committed_ingest()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not emu and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(wl, L)
                 res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -160,6 +160,14 @@ def test_profiled_kernel_names_are_the_dispatchers_choice():
     for sub in ("attn_fwd_f8_kernel", "attn_fwd_w4_kernel<0, false, 1, true, true, false>", "attn_fwd_w4_kernel<0, true, 1, false, true, false>",
                 "vt_quantize_mx_kernel", "gemm_pk_kernel<3, 1, true>", "gemm_pk_kernel<1, 1, true>", "col_partial_sums_kernel", "qk_quantize_fp8_kernel"):
         assert any(sub in n for n in names8), (sub, p8[-1])
+    # an 8-way Ulysses rank's launches (5 local heads as head groups of 2 and 3: 2.05 / 3.08 rounds of 1 049 KV tiles) and the whole
+    # 5-head shard take the max-free attempt too -- few rounds, but milliseconds of launch (bench.py --emulate-sp 8 found them on the lazy
+    # form); short key streams on few rounds stay on the one-launch lazy form
+    for hl in (2, 3, 5):
+        wsl = lib.wan_attention_workspace_bytes(1, L, L, hl, 128)
+        assert lib.wan_attention_plan(1, L, L, hl, 128, _lib.ATTN_Q_PRESCALED, wsl) & 15 == 2, hl
+    ws_s = lib.wan_attention_workspace_bytes(1, 2304, 2304, 12, 128)
+    assert lib.wan_attention_plan(1, 2304, 2304, 12, 128, _lib.ATTN_Q_PRESCALED, ws_s) & 15 == 1          # configs[0]: 108 workgroups x 36 tiles
     # without scratch, or with plain q: one lazy launch (the packed-shift form for plain q)
     assert lib.wan_attention_plan(1, L, L, H, 128, _lib.ATTN_Q_PRESCALED, 0) & 15 == 1
     assert lib.wan_attention_plan(1, L, L, H, 128, 0, ws) & 15 == 1

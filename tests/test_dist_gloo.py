@@ -157,3 +157,34 @@ def test_degree_checks_without_process_group():
         vdist.set_multi_gpus_devices(1, ring_degree=2)
     assert vdist.get_sequence_parallel_world_size() == 1
     assert str(vdist.set_multi_gpus_devices(1, 1)) == "cuda"
+
+
+def test_emulated_rank_has_the_exchange_interface_and_no_peers():
+    """bench.py --emulate-sp: one rank of a P-way group with device-local copies where the exchanges would be (measurement only)."""
+    import torch
+    from videocof_amd import dist as vdist
+    try:
+        sp = vdist.init_sequence_parallel(backend="emulated", rank=0, world_size=8)
+        assert (sp.world_size, sp.rank) == (8, 0) and vdist.get_sequence_parallel_world_size() == 8 and vdist.get_sp_group() is sp
+        send = torch.arange(64, dtype=torch.float32)
+        recv = torch.zeros(64)
+        wait = sp.exchange(recv, send, async_op=True)
+        wait()
+        assert torch.equal(recv, send) and sp.exchange(recv, send) is None
+        with pytest.raises(ValueError, match="divisible"):
+            sp.exchange(torch.zeros(12), torch.zeros(12))
+        y = torch.randn(1, 5, 3)
+        g = sp.all_gather_tokens(y)
+        assert g.shape == (1, 40, 3) and all(torch.equal(g[:, 5 * r:5 * r + 5], y) for r in range(8))
+        y2 = torch.randn(2, 5, 3)
+        g2 = sp.all_gather_tokens(y2)
+        assert g2.shape == (2, 40, 3) and torch.equal(g2[1, 10:15], y2[1])
+        t = torch.tensor([1.0, 2.0])
+        assert sp.all_reduce_max(t) is t
+        with pytest.raises(ValueError):
+            vdist.init_sequence_parallel(backend="emulated", rank=8, world_size=8)
+        with pytest.raises(ValueError, match="emulated"):
+            vdist.init_sequence_parallel(backend="nope")
+    finally:
+        vdist.destroy_sequence_parallel()
+    assert vdist.get_sp_group() is None

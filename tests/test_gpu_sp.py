@@ -637,3 +637,40 @@ def test_bench_sequence_parallel_line_over_rccl_with_one_rank():
     assert set(line["exposed_comm_ms"]["per_step_by_exchange"]) == {"q_g0", "o_g1", "all_gather"}
     assert line["rank_wall_s"]["per_rank"] and line["rank_wall_s"]["max_over_min"] == 1.0
     assert line["roofline"]["heads_local"] == 12 and "e2e" not in line
+
+
+def test_emulated_rank_runs_the_shard_shapes_and_degree_one_is_the_single_device():
+    """`bench.py --emulate-sp P` (videocof_amd.dist.EmulatedRank): ONE rank's work of a P-way group with device-local copies for the
+    exchanges.  With P = 1 the copies ARE the exchanges of a one-rank group, so the forward must equal the single-device one
+    (to the tolerance of the SP == single tests); with P = 2 the rank sees its own slabs where its peer's would arrive -- the output
+    is not a latent, but it is finite, complete, and the attention ran on H / P heads over the padded full sequence."""
+    from videocof_amd import WanTransformer3DModel
+    from videocof_amd import dist as vdist
+    from videocof_amd.weights import deterministic_dit_state_dict, det_uniform
+    heads = 4
+    cfgd = dict(dim=128 * heads, ffn_dim=1024, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    m = WanTransformer3DModel(dim=128 * heads, ffn_dim=1024, num_heads=heads, num_layers=2, text_dim=64)
+    m.load_state_dict(deterministic_dit_state_dict(**cfgd), device="cuda:0")
+    lat = det_uniform("sp.lat", (1, 16, 7, 12, 20), 1.0).cuda()
+    ctx = [det_uniform("sp.c0", (37, 64), 1.0).cuda()]
+    t = torch.tensor([749], device="cuda:0")
+    kw = dict(frame_split_indices=[3], ground_frame_indices=[(3, 4)])
+    single = m(lat, t, ctx, 420, **kw)
+    try:
+        vdist.init_sequence_parallel(backend="emulated", rank=0, world_size=1)
+        m.enable_multi_gpus_inference()
+        m.force_ulysses = True
+        one = m(lat, t, ctx, 420, **kw)
+        assert float((one - single).norm() / single.norm()) < 2e-3
+        vdist.init_sequence_parallel(backend="emulated", rank=0, world_size=2)
+        m.enable_multi_gpus_inference()
+        m.force_ulysses = False
+        ev = m._attn_events = []
+        two = m(lat, t, ctx, 420, **kw)
+        torch.cuda.synchronize()
+        assert two.shape == single.shape and torch.isfinite(two.float()).all()
+        assert m.sp_world_size == 2 and m._last_attn_rows == 432 and len(ev) == 2        # 420 -> a multiple of 8 * P; one event pair per layer
+        assert float((two - single).norm() / single.norm()) > 1e-2                        # (its own slabs, not the peer's: another function)
+    finally:
+        m._attn_events = None
+        vdist.destroy_sequence_parallel()

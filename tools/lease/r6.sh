@@ -154,6 +154,49 @@ PY
       cp gpurun_out/profsq_r06_fp8_pk/sq_summary.json $out/bench14b_fp8_everything_sq_insitu.json
     fi
     ;;
+  emu)  # one rank of a P-way Ulysses group emulated on one GPU (bench.py --emulate-sp P): the compute-side projection of the N = 2 / 4 / 8 lines
+    timeout 600 python -m pytest tests/test_gpu_sp.py -x -q -k "emulated" > $out/pytest_emu.log 2>&1; tail -3 $out/pytest_emu.log
+    timeout 500 $B --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_n1.err | json > $out/bench_14b_n1_same_box.json
+    for p in 8 4 2; do
+      timeout 500 $B --emulate-sp $p --steps 4 --warmup 2 2>$out/bench_emu$p.err | json > $out/bench_14b_emulated_rank_of_sp$p.json
+    done
+    timeout 500 $B --steps 4 --no-cpu-baseline --no-e2e --no-verify 2>$out/bench_n1b.err | json > $out/bench_14b_n1_same_box_after.json
+    timeout 500 $B --workload 1.3b-cof --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_1p3b_n1.err | json > $out/bench_1p3b_n1_same_box.json
+    timeout 500 $B --workload 1.3b-cof --emulate-sp 8 --steps 4 --warmup 2 2>$out/bench_1p3b_emu8.err | json > $out/bench_1p3b_emulated_rank_of_sp8.json
+    timeout 500 $B --workload 1.3b-cof --emulate-sp 4 --steps 4 --warmup 2 2>$out/bench_1p3b_emu4.err | json > $out/bench_1p3b_emulated_rank_of_sp4.json
+    PASSES="trace" PASS_TIMEOUT=400 bash tools/profile_bench.sh r06_emu8 --emulate-sp 8 > $out/prof_emu8.log 2>&1
+    cp gpurun_out/prof_r06_emu8/kernel_stats.csv $out/bench14b_emulated_rank_of_sp8_kernel_stats.csv 2>/dev/null
+    ;;
+  emu2)  # after the dispatch change (max-free attempt on few-round launches of long key streams): attention + SP tests, the emulated ranks again
+    timeout 1200 python -m pytest tests/test_gpu_sp.py tests/test_gpu_kernels.py -x -q -k "sp_ or emulated or attention" > $out/pytest_attn_sp.log 2>&1; tail -3 $out/pytest_attn_sp.log
+    timeout 500 $B --steps 4 --no-cpu-baseline --no-e2e 2>$out/bench_n1.err | json > $out/bench_14b_n1_same_box.json
+    for p in 8 4; do
+      timeout 500 $B --emulate-sp $p --steps 4 --warmup 2 2>$out/bench_emu$p.err | json > $out/bench_14b_emulated_rank_of_sp$p.json
+    done
+    WAN_ATTN_FAST=0 timeout 500 $B --emulate-sp 8 --steps 4 --warmup 2 2>$out/bench_emu8_lazy.err | json > $out/bench_14b_emulated_rank_of_sp8_lazy_form.json
+    timeout 500 $B --workload 1.3b-cof --emulate-sp 8 --steps 4 --warmup 2 2>$out/bench_1p3b_emu8.err | json > $out/bench_1p3b_emulated_rank_of_sp8.json
+    PASSES="trace" PASS_TIMEOUT=400 bash tools/profile_bench.sh r06_emu8 --emulate-sp 8 > $out/prof_emu8.log 2>&1
+    cp gpurun_out/prof_r06_emu8/kernel_stats.csv $out/bench14b_emulated_rank_of_sp8_kernel_stats.csv 2>/dev/null
+    ;;
+  emu3)  # same-box A/B of the dispatch change at the 8-way shard: max-free attempt (new default) vs the lazy form (WAN_ATTN_FAST=0), alternating, 20 steps each
+    for i in 1 2 3; do
+      timeout 300 $B --emulate-sp 8 --steps 20 --warmup 5 --no-box-probe 2>/dev/null | json > $out/emu8_maxfree_$i.json
+      WAN_ATTN_FAST=0 timeout 300 $B --emulate-sp 8 --steps 20 --warmup 5 --no-box-probe 2>/dev/null | json > $out/emu8_lazy_$i.json
+    done
+    python - $out <<'PY'
+import json, sys
+out = sys.argv[1]
+with open(out + "/emulated_sp8_maxfree_vs_lazy_ab.log", "w") as fo:
+    for i in (1, 2, 3):
+        for tag in ("maxfree", "lazy"):
+            try:
+                d = json.load(open(f"{out}/emu8_{tag}_{i}.json"))
+                line = f"{tag:8s} run {i}: {d['ms_per_step']:.2f} ms/step  attention {d['roofline']['avg_ms']:.3f} ms/layer (variant {d['roofline']['variant_code']})  exposed copies {d['exposed_comm_ms']['per_step']:.2f} ms/step"
+            except Exception as e:
+                line = f"{tag} run {i}: no line ({e})"
+            print(line); fo.write(line + "\n")
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'

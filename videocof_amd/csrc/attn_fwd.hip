@@ -1346,10 +1346,14 @@ AttnPlan plan_attention(int batch, int Lq, int Lk, int num_heads, bool pre, int6
     const int64_t fb = flag_bytes(batch, Lq, num_heads);
     if (workspace_bytes >= fb) {
         // the attempt is worth its second launch (~5-15 us of workgroups that exit at once) only on long launches: self-attention
-        // over >= 4 rounds of workgroups; short launches (cross-attention's 8 KV tiles, small grids) take the one-launch lazy form.
-        // attn_fast = 2 forces the attempt whenever there is scratch (tests)
+        // over >= 4 rounds of workgroups, or -- round 6 -- fewer rounds of LONG key streams (rounds x KV tiles >= 1024, i.e. >= ~1.5 ms of
+        // launch at ~1.5 us per tile: the 2- and 3-head launches of an 8-way Ulysses rank at L = 67 080 are 2.05 / 3.08 rounds of 1 049
+        // tiles and sat on the lazy form until `bench.py --emulate-sp 8` showed it); short launches (cross-attention's 8 KV tiles,
+        // small grids) take the one-launch lazy form.  attn_fast = 2 forces the attempt whenever there is scratch (tests)
         const int fast_mode = wan_tune(WAN_TUNE_ATTN_FAST);
-        const bool long_launch = self && (int64_t)nqb_all * num_heads * batch >= 4LL * wan_cu_count();
+        const int64_t nwg_all = (int64_t)nqb_all * num_heads * batch, cus = wan_cu_count();
+        const int64_t rounds = (nwg_all + cus - 1) / cus, kv_tiles = (Lk + kKV - 1) / kKV;
+        const bool long_launch = self && (nwg_all >= 4 * cus || rounds * kv_tiles >= 1024);
         p.fast = pre && !qk8 && (fast_mode == 2 || (fast_mode == 1 && long_launch));
         p.tail = plan_tail(batch, Lq, Lk, num_heads);
         if (p.tail.tq > 0 && workspace_bytes - fb < p.tail.ws_bytes) p.tail = TailPlan();

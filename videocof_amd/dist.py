@@ -281,6 +281,39 @@ class LibraryComm:
             pass
 
 
+class EmulatedRank:
+    """MEASUREMENT ONLY: the exchange interface of ONE rank of a P-way Ulysses group on one device, with no peers
+    (``init_sequence_parallel(backend="emulated", rank=r, world_size=P)``; ``bench.py --emulate-sp P``).  The model then runs
+    exactly what rank r of P would: the token-local Linears / norms on L/P rows, attention on H/P heads over all L keys, the wire
+    layouts, pack / unpack passes and head-group pipelining -- and every exchange becomes a device-local copy of the send buffer
+    into the receive buffer (the byte count a rank receives, the wrong contents: its own slabs where the peers' would arrive), the
+    all-gather P copies of the local shard.  The OUTPUT IS THEREFORE NOT A DENOISED LATENT; what the mode gives is the compute side
+    of one rank's step on the shard shapes, i.e. the bound a P-GPU run cannot beat and the number its exposed-communication time
+    adds to.  Nothing in the product path or the tests' parity statements uses it."""
+
+    def __init__(self, rank: int = 0, world_size: int = 1):
+        if not (0 <= int(rank) < int(world_size)):
+            raise ValueError(f"EmulatedRank: rank {rank} outside a group of {world_size}")
+        self.rank, self.world_size, self.group = int(rank), int(world_size), None
+        self._host_staged = False
+
+    def exchange(self, recv: torch.Tensor, send: torch.Tensor, async_op: bool = False):
+        if send.numel() != recv.numel() or send.numel() % self.world_size or not (send.is_contiguous() and recv.is_contiguous()):
+            raise ValueError("exchange: send / recv must be contiguous, of equal size, divisible by the group size")
+        recv.view(-1).copy_(send.view(-1))
+        return (lambda: None) if async_op else None
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def all_gather_tokens(self, y: torch.Tensor) -> torch.Tensor:
+        P = self.world_size
+        y = y.contiguous()
+        recv, out = _gather_buffers(self, y, P)
+        recv.copy_(y.unsqueeze(0).expand_as(recv))
+        return _gathered_view(recv, out)
+
+
 def get_sp_group() -> Optional[SequenceParallelGroup]:
     return _SP
 
@@ -301,8 +334,10 @@ def init_sequence_parallel(group=None, backend: str = "torch", rank: Optional[in
         _SP = LibraryComm(rank, world_size, group)
     elif backend == "torch":
         _SP = SequenceParallelGroup(group)
+    elif backend == "emulated":         # measurement only: one rank's compute on the shard shapes, no peers (EmulatedRank)
+        _SP = EmulatedRank(0 if rank is None else rank, 1 if world_size is None else world_size)
     else:
-        raise ValueError(f"init_sequence_parallel: backend {backend!r} (\"torch\" or \"library\")")
+        raise ValueError(f"init_sequence_parallel: backend {backend!r} (\"torch\", \"library\" or \"emulated\")")
     return _SP
 
 
