@@ -516,6 +516,9 @@ def main():
     ap.add_argument("--emulate-sp", type=int, default=0, metavar="P",
                     help="one GPU: run what ONE rank of a P-way Ulysses group computes (shard shapes, device-local copies in place of "
                          "the exchanges) and print a PROJECTION of the P-GPU line's compute side; not a measurement of P GPUs")
+    ap.add_argument("--sp-head-groups", type=int, default=2, choices=[1, 2],
+                    help="sequence parallel: 2 (default) = q and o travel as two head groups, the second under the first group's attention and "
+                         "vice versa (two attention launches per layer); 1 = one exchange + one launch (an A/B knob for a real N-GPU box)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-box-probe", action="store_true",
                     help="skip the ~0.4 s box fingerprint (wan_box_probe) before and after the timed region")
@@ -622,6 +625,7 @@ def main():
             vdist.init_sequence_parallel()
         model.enable_multi_gpus_inference()
         model.force_ulysses = force_sp
+        model.sp_head_groups = args.sp_head_groups
     Fs, G, Ft = wl["fs"], wl["g"], wl["ft"]
     Ftot = Fs + G + Ft
     cof = Fs > 0
@@ -809,6 +813,7 @@ def main():
                    "tokens_per_sample": L, "global_batch": units, "guidance_scale": 1.0,
                    "layers_override": (wl["num_layers"] if args.layers > 0 else None),
                    "sp_padded_heads": (model._sp_pad.pad_heads if getattr(model, "_sp_pad", None) is not None else None),
+                   "sp_head_groups": args.sp_head_groups if sp else None,
                    "parallelism": ("EMULATED rank 0 of ulysses-sp%d on one GPU (projection)" % emu) if emu else
                                   ("ulysses-sp%d" % world) if sp else ("replicas-dp%d" % world if world > 1 else "single")},
         "tokens_per_s_per_gpu": round(value / world, 1),

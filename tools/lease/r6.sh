@@ -197,6 +197,29 @@ with open(out + "/emulated_sp8_maxfree_vs_lazy_ab.log", "w") as fo:
             print(line); fo.write(line + "\n")
 PY
     ;;
+  emu4)  # head groups on / off at the 8- and 4-way shards (compute side only: what the second attention launch per layer costs before it hides anything)
+    for i in 1 2; do
+      for p in 8 4; do
+        for g in 2 1; do
+          timeout 300 $B --emulate-sp $p --sp-head-groups $g --steps 20 --warmup 5 --no-box-probe 2>/dev/null | json > $out/emu${p}_groups${g}_$i.json
+        done
+      done
+    done
+    python - $out <<'PY'
+import json, sys
+out = sys.argv[1]
+with open(out + "/emulated_sp_head_groups_ab.log", "w") as fo:
+    for i in (1, 2):
+        for p in (8, 4):
+            for g in (2, 1):
+                try:
+                    d = json.load(open(f"{out}/emu{p}_groups{g}_{i}.json"))
+                    line = f"rank of {p}, head groups {g}, run {i}: {d['ms_per_step']:.2f} ms/step  attention {d['roofline']['avg_ms']:.3f} ms/layer  exposed copies {d['exposed_comm_ms']['per_step']:.2f} ms/step"
+                except Exception as e:
+                    line = f"rank of {p}, head groups {g}, run {i}: no line ({e})"
+                print(line); fo.write(line + "\n")
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
