@@ -784,6 +784,13 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_detail": traffic_detail, "launches": len(ms),
                 "avg_ms": round(avg_ms, 3), "flop_per_launch": flop, "dtype_peak": "bf16 dense MFMA"}
+        if box is not None and (vcode & 15) in (1, 2):
+            # the same instruction mix (32x32x16 bf16 MFMAs + LDS fragment reads + softmax VALU stream) with nothing else to do, on this box
+            # in this run: what the chip SUSTAINS at its power limit -- the ceiling the kernel can be held against next to the 2.5 PF spec
+            probe = 0.5 * (box["before"]["mfma_mix_tflops"] + box["after"]["mfma_mix_tflops"])
+            roof["sustained_mix"] = {"probe_tflops": round(probe, 1), "frac_of_probe": round(ach / probe, 4),
+                                     "what": "wan_box_probe of this run (box.mfma_mix_tflops): the kernel's own instruction mix, no loads from HBM, "
+                                             "no barriers, at the chip's power limit; `frac` above stays against the dense bf16 spec peak"}
         if (vcode & 15) == 5:       # both products at the fp8 rate (2 x bf16)
             peak = 2 * PEAK_BF16_TFLOPS
             roof.update(peak=round(peak, 1), frac=round(ach / peak, 4), traffic=None,

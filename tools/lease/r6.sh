@@ -220,6 +220,20 @@ with open(out + "/emulated_sp_head_groups_ab.log", "w") as fo:
                 print(line); fo.write(line + "\n")
 PY
     ;;
+  last)  # the round's LAST tree: whole suite, smoke, headline line (default + driver form), rocprofv3 passes (trace, FETCH / WRITE, SQ), the emulated-rank table on the same box
+    timeout 1800 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+    timeout 300 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+    timeout 900 $B 2>$out/bench_default.err | json > $out/bench_14b_last_tree.json
+    for p in 2 4 8; do
+      timeout 500 $B --emulate-sp $p --steps 8 --warmup 2 2>$out/bench_emu$p.err | json > $out/bench_14b_emulated_rank_of_sp${p}_last_tree.json
+    done
+    timeout 900 $B --steps 20 --warmup 5 2>$out/bench_driver.err | json > $out/bench_14b_last_tree_driver_like_20_steps.json
+    bash tools/profile_bench.sh r06_last > $out/prof.log 2>&1
+    bash tools/profile_bench_sq.sh r06_last > $out/prof_sq.log 2>&1
+    cp gpurun_out/prof_r06_last/kernel_stats.csv $out/bench14b_kernel_stats.csv 2>/dev/null
+    cp gpurun_out/prof_r06_last/pmc_summary.json $out/bench14b_pmc_summary.json 2>/dev/null
+    cp gpurun_out/profsq_r06_last/sq_summary.json $out/bench14b_sq_insitu.json 2>/dev/null
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
