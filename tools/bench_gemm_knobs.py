@@ -26,7 +26,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 base_arms = arms
 for name, M, N, K, epi in shapes:
     if "--split" in sys.argv:      # whole leftover tiles (min_units = units per tile: no stream-K cut) and half tiles against the default quarter
-        arms = [("default", {}), ("no split", {"gemm_pk_min_units": K // 128}), ("half tiles", {"gemm_pk_min_units": max(1, K // 256)})]
+        arms = [("default", {}), ("no split", {"gemm_pk_min_units": K // 128}), ("half tiles", {"gemm_pk_min_units": max(1, K // 256)}),
+                ("quarter tiles", {"gemm_pk_min_units": max(1, (K // 128 + 3) // 4)})]
     a = torch.randn(M, K, device=dev, generator=g).bfloat16()
     w = (torch.randn(N, K, device=dev, generator=g) * 0.05).bfloat16()
     bias = torch.zeros(N, device=dev)

@@ -234,6 +234,15 @@ PY
     cp gpurun_out/prof_r06_last/pmc_summary.json $out/bench14b_pmc_summary.json 2>/dev/null
     cp gpurun_out/profsq_r06_last/sq_summary.json $out/bench14b_sq_insitu.json 2>/dev/null
     ;;
+  sc1)  # stream-K fix-up without the agent-scope acquire fence (buffer_inv sc1 = the XCD's L2 dropped at every split tile): agent-coherent loads instead
+    ALT=$PWD/tools/exp_lib/libwan_hip_sc1.so
+    WAN_HIP_LIB=$ALT timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "gemm or stream_k or persistent" > $out/pytest_gemm_sc1.log 2>&1; tail -3 $out/pytest_gemm_sc1.log
+    for i in 1 2; do
+      timeout 600 python tools/bench_gemm_knobs.py --split > $out/gemm_split_fence_$i.log 2>&1
+      WAN_HIP_LIB=$ALT timeout 600 python tools/bench_gemm_knobs.py --split > $out/gemm_split_sc1_$i.log 2>&1
+    done
+    for f in $out/gemm_split_fence_1.log $out/gemm_split_sc1_1.log $out/gemm_split_fence_2.log $out/gemm_split_sc1_2.log; do echo "== $f"; grep -v amdgpu.ids $f; done
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
 for f in $out/*.json; do echo "== $f"; python - "$f" <<'PY'
