@@ -136,3 +136,72 @@ def test_product_host_code_vs_reference(ns):
     assert merge_lora_state_dict(got, lora, 0.6) == 3
     for k in want:
         assert rel_l2(got[k], want[k]) < 1e-6, k
+
+
+def test_call_signatures_are_the_references():
+    """Drop-in surface: every seam the reference calls has, on the mirror, the reference's
+    parameter NAMES in the reference's ORDER with the reference's DEFAULTS -- read from the reference's source with `ast` (no import: its
+    pipeline needs the real diffusers), compared with `inspect.signature` of the product classes.  What the mirrors may add: trailing
+    parameters WITH defaults (listed below); what may differ in a default: listed below, each a widening (a float where the reference writes
+    the same number as an int; None = "the model's device" where the reference says 'cpu'; optional components)."""
+    import ast
+    import inspect
+    import os
+    from oracle.ref_import import REFERENCE_ROOT as REF_ROOT
+    import videocof_amd as V
+    from videocof_amd import attention_utils, dist, fm_solvers_unipc, lora_utils, pipeline_wan, wan_text_encoder, wan_vae
+
+    def ref_sig(path, cls, fn):
+        with open(os.path.join(REF_ROOT, "videox_fun", path)) as f:
+            body = ast.parse(f.read()).body
+        if cls:
+            body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == cls).body
+        a = next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == fn).args
+        names = [x.arg for x in a.posonlyargs + a.args]
+        defaults = [None] * (len(names) - len(a.defaults)) + list(a.defaults)
+        out = [(n, None if d is None else ast.unparse(d)) for n, d in zip(names, defaults)]
+        out += [(x.arg, None if d is None else ast.unparse(d)) for x, d in zip(a.kwonlyargs, a.kw_defaults)]
+        return [(n, d) for n, d in out if n != "cls"]
+
+    def my_sig(obj):
+        ps = [p for p in inspect.signature(obj).parameters.values() if p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD)]
+        return [(p.name, None if p.default is p.empty else repr(p.default)) for p in ps]
+
+    seams = [
+        ("models/wan_transformer3d.py", "WanTransformer3DModel", "forward", V.WanTransformer3DModel.forward, (), {}),
+        ("models/wan_transformer3d.py", "WanTransformer3DModel", "__init__", V.WanTransformer3DModel.__init__, (), {}),
+        ("models/wan_transformer3d.py", "WanTransformer3DModel", "from_pretrained", V.WanTransformer3DModel.from_pretrained, (), {}),
+        ("models/wan_transformer3d.py", "WanTransformer3DModel", "enable_teacache", V.WanTransformer3DModel.enable_teacache, (), {}),
+        ("models/attention_utils.py", None, "attention", attention_utils.attention, (), {}),
+        ("models/attention_utils.py", None, "flash_attention", attention_utils.flash_attention, (), {}),
+        ("utils/fm_solvers_unipc.py", "FlowUniPCMultistepScheduler", "__init__", fm_solvers_unipc.FlowUniPCMultistepScheduler.__init__, (), {}),
+        ("utils/fm_solvers_unipc.py", "FlowUniPCMultistepScheduler", "set_timesteps", fm_solvers_unipc.FlowUniPCMultistepScheduler.set_timesteps, (), {}),
+        ("utils/fm_solvers_unipc.py", "FlowUniPCMultistepScheduler", "step", fm_solvers_unipc.FlowUniPCMultistepScheduler.step, (), {}),
+        ("pipeline/pipeline_wan.py", "WanPipeline", "__call__", pipeline_wan.WanPipeline.__call__,
+         ("source_latents", "device", "weight_dtype", "cache_context", "skip_source_prediction", "capture_graph"),
+         {"guidance_scale": ("6", "6.0"), "shift": ("5", "5.0"), "callback_on_step_end_tensor_inputs": ("['latents']", "('latents',)")}),
+        ("pipeline/pipeline_wan.py", "WanPipeline", "__init__", pipeline_wan.WanPipeline.__init__, (),
+         {k: (None, "None") for k in ("tokenizer", "text_encoder", "vae", "transformer", "scheduler")}),
+        ("models/wan_vae.py", "AutoencoderKLWan", "encode", wan_vae.AutoencoderKLWan.encode, (), {}),
+        ("models/wan_vae.py", "AutoencoderKLWan", "decode", wan_vae.AutoencoderKLWan.decode, (), {}),
+        ("models/wan_vae.py", "AutoencoderKLWan", "__init__", wan_vae.AutoencoderKLWan.__init__, (), {}),
+        ("models/wan_vae.py", "AutoencoderKLWan", "from_pretrained", wan_vae.AutoencoderKLWan.from_pretrained, (), {}),
+        ("models/wan_text_encoder.py", "WanT5EncoderModel", "forward", wan_text_encoder.WanT5EncoderModel.forward, (), {}),
+        ("models/wan_text_encoder.py", "WanT5EncoderModel", "__init__", wan_text_encoder.WanT5EncoderModel.__init__, ("text_length",), {}),
+        ("models/wan_text_encoder.py", "WanT5EncoderModel", "from_pretrained", wan_text_encoder.WanT5EncoderModel.from_pretrained, ("device",), {}),
+        ("utils/lora_utils.py", None, "merge_lora", lora_utils.merge_lora, (), {"device": ("'cpu'", "None")}),
+        ("utils/lora_utils.py", None, "unmerge_lora", lora_utils.unmerge_lora, ("state_dict",), {"device": ("'cpu'", "None")}),
+        ("dist/fuser.py", None, "set_multi_gpus_devices", dist.set_multi_gpus_devices, (), {"ring_degree": (None, "1")}),
+    ]
+    for path, cls, fn, obj, extras, widened in seams:
+        ref, mine = ref_sig(path, cls, fn), my_sig(obj)
+        where = f"{cls + '.' if cls else ''}{fn} ({path})"
+        mine_d = dict(mine)
+        assert [n for n, _ in mine if n not in extras] == [n for n, _ in ref], (where, ref, mine)          # names and order
+        assert [n for n, _ in mine][len(ref):] == list(extras), (where, "additions must trail the reference's parameters", mine)
+        assert all(mine_d[n] is not None for n in extras), (where, "additions must be optional")
+        for n, d in ref:
+            if n in widened:
+                assert (d, mine_d[n]) == widened[n], (where, n, d, mine_d[n])
+            else:
+                assert d == mine_d[n], (where, n, d, mine_d[n])

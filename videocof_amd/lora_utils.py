@@ -151,7 +151,7 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
     return pipeline
 
 
-def unmerge_lora(pipeline, lora_path, multiplier=1, device=None, dtype=torch.float32, state_dict=None,
-                 sub_transformer_name="transformer"):
+def unmerge_lora(pipeline, lora_path, multiplier=1, device=None, dtype=torch.float32, sub_transformer_name="transformer",
+                 state_dict=None):
     """Inverse of ``merge_lora`` (lora_utils.py:503-620); exact up to the bf16 rounding of the merged weights."""
     return merge_lora(pipeline, lora_path, -multiplier, device, dtype, state_dict, sub_transformer_name=sub_transformer_name)
