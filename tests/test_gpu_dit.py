@@ -288,6 +288,20 @@ def test_graph_entries_pin_their_buffers_and_follow_the_model(model):
     assert torch.equal(model(lat_a, ta, ctx, 80), want_a)
 
 
+def test_unpatchify_method_is_the_references_einsum(model):
+    """``WanTransformer3DModel.unpatchify(x, grid_sizes)`` (wan_transformer3d.py:1108-1131): per sample the first prod(grid) rows,
+    `fhwpqrc->cfphqwr`; fp32 and bf16 token lists, a tensor or a list of grids, rows beyond the grid ignored."""
+    grids = [(3, 4, 5), (2, 2, 3)]
+    xs = [torch.randn(3 * 4 * 5 + 7, 64, device=DEV), torch.randn(2 * 2 * 3, 64, device=DEV)]
+    for dt in (torch.float32, torch.bfloat16):
+        got = model.unpatchify([x.to(dt) for x in xs], torch.tensor(grids))
+        for x, v, o in zip(xs, grids, got):
+            u = x.to(dt)[:v[0] * v[1] * v[2]].view(*v, 1, 2, 2, 16)
+            want = torch.einsum("fhwpqrc->cfphqwr", u).reshape(16, v[0], v[1] * 2, v[2] * 2)
+            assert o.dtype == dt and torch.equal(o, want)
+    assert torch.equal(model.unpatchify(xs[:1], [grids[0]])[0], model.unpatchify(xs[:1], torch.tensor(grids[:1]))[0])
+
+
 def test_unpatchify_zero_frames_is_the_cof_mask(model):
     lat = det_uniform("zf.lat", (1, 16, 5, 8, 8), 1.0).to(DEV)
     ctx = [det_uniform("zf.ctx", (9, 64), 1.0).to(DEV)]

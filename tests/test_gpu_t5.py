@@ -214,7 +214,7 @@ def test_pipeline_encodes_prompt_strings_with_the_hip_encoder():
     ref_emb = T.T5EncoderOracle(tsd, 1, 2, 32).forward(enc.input_ids, enc.attention_mask)
     n = enc.attention_mask.sum(1).tolist()
     assert n == [9, 4]
-    embeds = pipe.encode_prompt(prompt, neg, True, None, None, torch.device(DEV))
+    embeds = pipe.encode_prompt(prompt, neg, True, device=torch.device(DEV))
     assert [tuple(e.shape) for e in embeds[0]] == [(9, 64)] and [tuple(e.shape) for e in embeds[1]] == [(4, 64)]
     assert rel_l2(embeds[0][0], ref_emb[0, :9]) < 1.5e-2 and rel_l2(embeds[1][0], ref_emb[1, :4]) < 1.5e-2
     want = pipe(prompt_embeds=[ref_emb[0, :9].to(DEV)], negative_prompt_embeds=[ref_emb[1, :4].to(DEV)], **kw).latents

@@ -151,6 +151,58 @@ def test_pipeline_input_checks():
         pipe()
     with pytest.raises(ValueError, match="text_encoder"):
         pipe(prompt="remove the cup", latents=torch.zeros(1, 16, 2, 4, 4), output_type="latent", num_inference_steps=1)
+    # the rest of the reference's check_inputs (pipeline_wan.py:449-498) and encode_prompt's own errors (:228-240)
+    with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
+        pipe(prompt_embeds=[torch.zeros(1, 64)], callback_on_step_end_tensor_inputs=["latents", "nope"])
+    with pytest.raises(ValueError, match="negative_prompt_embeds"):
+        pipe.check_inputs("a cup", 480, 832, None, None, None, [torch.zeros(1, 64)])
+    with pytest.raises(ValueError, match="same shape"):
+        pipe.check_inputs(None, 480, 832, None, None, torch.zeros(1, 3, 64), torch.zeros(1, 4, 64))
+    with pytest.raises(TypeError, match="same type"):
+        pipe.encode_prompt(["a cup"], ("blurry",), True, prompt_embeds=[torch.zeros(1, 64)])
+    with pytest.raises(ValueError, match="batch size"):
+        pipe.encode_prompt(["a cup"], ["blurry", "dark"], True, prompt_embeds=[torch.zeros(1, 64)])
+    pe, ne = pipe.encode_prompt(None, None, False, prompt_embeds=torch.zeros(2, 5, 64))        # a [B, len, C] tensor becomes the list the DiT takes
+    assert len(pe) == 2 and pe[0].shape == (5, 64) and ne is None
+
+
+def test_pipeline_latent_helpers_have_the_reference_behaviour():
+    """prepare_latents / prepare_video_latents / prepare_video_latents_new / prepare_cot_video_latents / prepare_extra_step_kwargs
+    (pipeline_wan.py:258-446) on CPU tensors with a stand-in VAE: shapes, which frames are noise, the generator's stream."""
+    class _Dist:
+        def __init__(self, z):
+            self.z = z
+
+        def mode(self):
+            return self.z
+
+    class _VAE:
+        temporal_compression_ratio, spatial_compression_ratio, latent_channels, dtype = 4, 8, 16, torch.float32
+
+        def encode(self, v):          # [1, 3, T, H, W] -> a "distribution" whose mode is a deterministic function of the clip
+            t, h, w = (v.shape[2] - 1) // 4 + 1, v.shape[3] // 8, v.shape[4] // 8
+            return (_Dist(v.mean() + torch.arange(16 * t * h * w, dtype=torch.float32).view(1, 16, t, h, w)),)
+    sched = FlowUniPCMultistepScheduler()
+    pipe = WanPipeline(vae=_VAE(), transformer=_OracleTransformer({}), scheduler=sched)
+    g = lambda: torch.Generator().manual_seed(5)
+    video = torch.zeros(1, 3, 9, 32, 48)
+    lat = pipe.prepare_latents(2, 16, 9, 32, 48, torch.float32, "cpu", g())
+    assert lat.shape == (2, 16, 3, 4, 6) and torch.equal(lat, torch.randn(2, 16, 3, 4, 6, generator=g()))
+    with pytest.raises(ValueError, match="list of generators"):
+        pipe.prepare_latents(2, 16, 9, 32, 48, torch.float32, "cpu", [g()])
+    src = _VAE().encode(video)[0].mode()
+    pv = pipe.prepare_video_latents(video, 1, 16, 32, 48, torch.float32, "cpu", g(), condition_count=1)
+    assert torch.equal(pv[:, :, :1], src[:, :, :1]) and torch.equal(pv[:, :, 1:], torch.randn(1, 16, 3, 4, 6, generator=g())[:, :, 1:])
+    new = pipe.prepare_video_latents_new(video, 1, 16, 32, 48, torch.float32, "cpu", g(), 3)
+    assert new.shape == (1, 16, 6, 4, 6) and torch.equal(new[:, :, :3], src) and torch.equal(new[:, :, 3:], torch.randn(1, 16, 3, 4, 6, generator=g()))
+    cot = pipe.prepare_cot_video_latents(video, 1, 1, 16, 32, 48, torch.float32, "cpu", g(), 3)
+    assert cot.shape == (1, 16, 7, 4, 6) and torch.equal(cot[:, :, :3], src) and torch.equal(cot[:, :, 3:], torch.randn(1, 16, 4, 4, 6, generator=g()))
+    assert torch.equal(pipe.prepare_cot_video_latents(None, 1, source_latents=src, generator=g(), device="cpu"), cot)     # the extension: no VAE pass
+    given = torch.ones(1, 16, 7, 4, 6)
+    assert torch.equal(pipe.prepare_cot_video_latents(video, 1, dtype=torch.float32, device="cpu", latents=given), given)
+    gen = g()
+    assert pipe.prepare_extra_step_kwargs(gen, 0.3) == {"generator": gen}          # UniPC's step takes a generator and no eta
+    assert pipe.attention_kwargs is None
 
 
 def test_no_cpu_fallback():
@@ -246,9 +298,18 @@ def test_transformer_surface_the_reference_pipeline_touches():
     for kw in ("x", "context", "t", "seq_len", "frame_split_indices", "ground_frame_indices"):
         assert kw in params, kw
     assert m.dtype == torch.bfloat16 and m.freqs.shape == (1024, 64)
-    for name in ("enable_teacache", "disable_teacache", "share_teacache", "enable_cfg_skip", "disable_cfg_skip",
-                 "enable_multi_gpus_inference", "load_state_dict", "state_dict", "from_pretrained"):
+    for name in ("enable_teacache", "disable_teacache", "share_teacache", "enable_cfg_skip", "disable_cfg_skip", "share_cfg_skip",
+                 "enable_riflex", "disable_riflex", "unpatchify", "enable_multi_gpus_inference", "load_state_dict", "state_dict",
+                 "from_pretrained"):
         assert callable(getattr(m, name)), name
+    # the switches of features that are out of scope exist and say so (or are the identity they are on this path)
+    other = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64)
+    other.enable_cfg_skip(0, 4)
+    m.share_cfg_skip(other)
+    assert (m.cfg_skip_ratio, m.current_steps, m.num_inference_steps) == (None, 0, None)
+    with pytest.raises(NotImplementedError, match="RIFLEx"):
+        m.enable_riflex(k=6, L_test=21)
+    assert m.disable_riflex() is None
 
 
 # ------------------------------------------------------------------ checkpoint loader rules (wan_transformer3d.py:1259-1288)

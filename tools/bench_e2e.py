@@ -79,7 +79,7 @@ def main():
 
     pipe(**{**kw, "num_inference_steps": 1})            # warm-up: allocator, workspaces, LDS attributes
     # stage timings with the same calls the pipeline makes
-    timed("text_encoder", lambda: pipe.encode_prompt(prompt, None, False, None, None, dev))
+    timed("text_encoder", lambda: pipe.encode_prompt(prompt, None, False, device=dev))
     timed("vae_encode", lambda: vae.encode(video)[0].mode())
     out = timed("pipeline_total", lambda: pipe(**kw))
     lat = out.latents if getattr(out, "latents", None) is not None else None

@@ -167,9 +167,27 @@ class FlowUniPCMultistepScheduler:
         return acc.to(dtype)
 
     # ------------------------------------------------------------------ step
-    def index_for_timestep(self, timestep):
-        idx = (self.timesteps == timestep).nonzero()
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        """fm_solvers_unipc.py:628-640: a timestep that occurs twice resolves to its SECOND position."""
+        idx = ((self.timesteps if schedule_timesteps is None else schedule_timesteps) == timestep).nonzero()
         return idx[1 if len(idx) > 1 else 0].item()
+
+    def __len__(self):
+        return self.config.num_train_timesteps          # fm_solvers_unipc.py:798-799
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """fm_solvers_unipc.py:758-797: (1 - sigma) x0 + sigma noise with sigma looked up per sample -- by timestep before a loop has a
+        begin index, else at the current (or the begin) step."""
+        sigmas = self.sigmas.to(device=original_samples.device, dtype=original_samples.dtype)
+        ts = timesteps.to(original_samples.device)
+        if self._begin_index is None:
+            sched = self.timesteps.to(original_samples.device)
+            idx = [self.index_for_timestep(t, sched) for t in ts]
+        else:
+            idx = [self._step_index if self._step_index is not None else self._begin_index] * ts.shape[0]
+        sigma = sigmas[idx].flatten()
+        sigma = sigma.view(-1, *([1] * (original_samples.dim() - 1)))
+        return (1 - sigma) * original_samples + sigma * noise
 
     def step(self, model_output: torch.Tensor, timestep: Union[int, torch.Tensor], sample: torch.Tensor,
              return_dict: bool = True, generator=None):

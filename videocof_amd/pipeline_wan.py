@@ -93,10 +93,13 @@ class WanPipeline:
 
     enable_sequential_cpu_offload = enable_model_cpu_offload
 
-    # -------------------------------------------------------------- prompt handling (:595-608)
-    def _get_t5_prompt_embeds(self, prompt, max_sequence_length: int = 512, device=None):
+    # -------------------------------------------------------------- prompt handling (:140-256, :449-495) -- the reference's argument lists
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]              # :112-116
+
+    def _get_t5_prompt_embeds(self, prompt=None, num_videos_per_prompt: int = 1, max_sequence_length: int = 512, device=None, dtype=None):
         """tokenizer(padding="max_length", max_length=512, truncation) -> text_encoder(ids, mask)[0], each
-        sample trimmed to its own token count (pipeline_wan.py:140-181)."""
+        sample trimmed to its own token count (pipeline_wan.py:140-181); ``num_videos_per_prompt`` repeats every sample in place."""
+        device = device if device is not None else self.transformer.device
         prompt = [prompt] if isinstance(prompt, str) else list(prompt)
         enc = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
                              add_special_tokens=True, return_tensors="pt")
@@ -104,57 +107,146 @@ class WanPipeline:
         mask = enc.attention_mask if hasattr(enc, "attention_mask") else enc["attention_mask"]
         seq_lens = mask.gt(0).sum(dim=1).long().tolist()
         hidden = self.text_encoder(ids.to(device), attention_mask=mask.to(device))[0]
-        return [u[:v] for u, v in zip(hidden, seq_lens)]
+        if dtype is not None:
+            hidden = hidden.to(dtype)
+        out = [u[:v] for u, v in zip(hidden, seq_lens)]
+        # (:176-179 repeats along the sequence axis and views as [B * n, seq, C]: sample b's n copies are consecutive)
+        return [e for e in out for _ in range(int(num_videos_per_prompt))]
 
-    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device,
-                      max_sequence_length: int = 512):
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance: bool = True, num_videos_per_prompt: int = 1,
+                      prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length: int = 512, device=None, dtype=None):
+        """:183-256.  Embeddings are LISTS of [len_i, 4096] tensors (what the transformer's ``context`` takes); a [len, 4096] or
+        [B, len, 4096] tensor passed in is split into one.  Without a tokenizer the text encoder is called on the strings themselves."""
+        device = device if device is not None else self.transformer.device
+
+        def as_list(e):
+            if torch.is_tensor(e):
+                return [e] if e.dim() == 2 else list(e)
+            return list(e)
+
         def enc(p):
             if self.text_encoder is None:
                 raise ValueError("no text_encoder: provide `prompt_embeds`, or build the pipeline with a tokenizer "
                                  "and a WanT5EncoderModel")
-            p = [p] if isinstance(p, str) else list(p)
             if self.tokenizer is not None:
-                return self._get_t5_prompt_embeds(p, max_sequence_length, device)
-            return [e.to(device) for e in self.text_encoder(p)]
+                return self._get_t5_prompt_embeds(p, num_videos_per_prompt, max_sequence_length, device, dtype)
+            return [e.to(device) for e in self.text_encoder(p) for _ in range(int(num_videos_per_prompt))]
+        prompt = [prompt] if isinstance(prompt, str) else prompt
         if prompt_embeds is None:
             prompt_embeds = enc(prompt)
-        prompt_embeds = [prompt_embeds] if torch.is_tensor(prompt_embeds) and prompt_embeds.dim() == 2 else list(prompt_embeds)
-        if do_cfg:
-            if negative_prompt_embeds is None:
-                negative_prompt_embeds = enc(negative_prompt if negative_prompt is not None else [""] * len(prompt_embeds))
-            negative_prompt_embeds = ([negative_prompt_embeds] if torch.is_tensor(negative_prompt_embeds)
-                                      and negative_prompt_embeds.dim() == 2 else list(negative_prompt_embeds))
-            if len(negative_prompt_embeds) != len(prompt_embeds):
+        prompt_embeds = as_list(prompt_embeds)
+        batch_size = len(prompt) if prompt is not None else len(prompt_embeds)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            if batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                                 f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                                 " the batch size of `prompt`.")
+            negative_prompt_embeds = enc(negative_prompt)
+        if negative_prompt_embeds is not None:
+            negative_prompt_embeds = as_list(negative_prompt_embeds)
+            if do_classifier_free_guidance and len(negative_prompt_embeds) != len(prompt_embeds):
                 raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same batch size")
         return prompt_embeds, negative_prompt_embeds
 
-    def check_inputs(self, prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds):
+    def check_inputs(self, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds=None,
+                     negative_prompt_embeds=None):
         if height % 8 != 0 or width % 8 != 0:                                                   # :458-459
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(k in self._callback_tensor_inputs
+                                                                       for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found "
+                             f"{[k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]}")
         if prompt is not None and prompt_embeds is not None:
             raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
         if prompt is None and prompt_embeds is None:
             raise ValueError("Provide either `prompt` or `prompt_embeds`.")
         if prompt is not None and not isinstance(prompt, (str, list)):
             raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if prompt is not None and negative_prompt_embeds is not None:                           # :481-485
+            raise ValueError("Cannot forward both `prompt` and `negative_prompt_embeds`.")
         if negative_prompt is not None and negative_prompt_embeds is not None:
             raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if torch.is_tensor(prompt_embeds) and torch.is_tensor(negative_prompt_embeds) and \
+                prompt_embeds.shape != negative_prompt_embeds.shape:                            # :492-498
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                             f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
 
-    # -------------------------------------------------------------- latents (:381-419)
-    def prepare_cot_video_latents(self, video, reasoning_latent_count, dtype, device, generator,
-                                  latents=None, source_latents=None):
+    # -------------------------------------------------------------- latents (:258-419), with the reference's names and argument lists
+    @staticmethod
+    def _randn(shape, generator, device, dtype):
+        """diffusers' randn_tensor for one generator: drawn on the generator's device, then moved."""
+        return torch.randn(tuple(shape), generator=generator, device=generator.device if generator is not None else device,
+                           dtype=dtype).to(device)
+
+    def _encode_modes(self, video, device, dtype):
+        if self.vae is None:
+            raise ValueError("no VAE: provide `source_latents` (or full `latents`)")
+        video = video.to(device=device, dtype=dtype)
+        return torch.cat([self.vae.encode(video[i:i + 1])[0].mode() for i in range(video.shape[0])])      # mode, no mean / std (:404-409)
+
+    def prepare_latents(self, batch_size, num_channels_latents, num_frames, height, width, dtype, device, generator, latents=None):
+        """:258-290 -- plain T2V noise [B, C, (num_frames - 1) / 4 + 1, H / 8, W / 8] (x ``scheduler.init_noise_sigma`` if it has one)."""
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        tr, sr = getattr(self.vae, "temporal_compression_ratio", 4), getattr(self.vae, "spatial_compression_ratio", 8)
+        shape = (batch_size, num_channels_latents, (num_frames - 1) // tr + 1, height // sr, width // sr)
+        latents = self._randn(shape, generator, device, dtype) if latents is None else latents.to(device)
+        if hasattr(self.scheduler, "init_noise_sigma"):
+            latents = latents * self.scheduler.init_noise_sigma
+        return latents
+
+    def prepare_video_latents(self, video, batch_size=1, num_channels_latents=16, height=480, width=832, dtype=torch.float32,
+                              device=None, generator=None, condition_count=None, latents=None, timestep=None):
+        """:292-341 -- the clip's latents with every frame from ``condition_count`` on replaced by noise."""
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype)
+        init = self._encode_modes(video, device, dtype)
+        tr, sr = getattr(self.vae, "temporal_compression_ratio", 4), getattr(self.vae, "spatial_compression_ratio", 8)
+        shape = (batch_size, num_channels_latents, (video.shape[2] - 1) // tr + 1, height // sr, width // sr)
+        noise = self._randn(shape, generator, device, dtype)
+        init[:, :, condition_count:] = noise[:, :, condition_count:]
+        return init
+
+    def prepare_video_latents_new(self, video, batch_size=1, num_channels_latents=16, height=480, width=832, dtype=torch.float32,
+                                  device=None, generator=None, condition_count=None, latents=None, timestep=None, source_latents=None):
+        """:343-378 -- [source latents | noise of the same shape] (the repeat / org layouts)."""
+        return self.prepare_cot_video_latents(video, 0, batch_size, num_channels_latents, height, width, dtype, device, generator,
+                                              condition_count, latents, timestep, source_latents)
+
+    def prepare_cot_video_latents(self, video, reasoning_latent_count=1, batch_size=1, num_channels_latents=16, height=480, width=832,
+                                  dtype=torch.float32, device=None, generator=None, condition_count=None, latents=None, timestep=None,
+                                  source_latents=None):
+        """:381-419 -- [source latents | noise over reasoning_latent_count + Fs frames].  The reference's argument list (its unused
+        entries -- batch_size, num_channels_latents, height, width, condition_count, timestep -- are accepted and unused here too) plus
+        ``source_latents``: the clip already encoded (no VAE in the pipeline, or the encode done elsewhere)."""
         if latents is not None:
             return latents.to(device=device, dtype=dtype)
         if source_latents is None:
-            if self.vae is None:
-                raise ValueError("no VAE: provide `source_latents` (or full `latents`)")
-            video = video.to(device=device, dtype=dtype)
-            source_latents = torch.cat([self.vae.encode(video[i:i + 1])[0].mode() for i in range(video.shape[0])])
+            source_latents = self._encode_modes(video, device, dtype)
         org = source_latents.to(device=device, dtype=dtype)
         B, Cl, Fs, h, w = org.shape
-        noise = torch.randn((B, Cl, Fs + reasoning_latent_count, h, w), generator=generator,
-                            device=generator.device if generator is not None else device, dtype=dtype).to(device)
-        return torch.cat([org, noise], dim=2)
+        return torch.cat([org, self._randn((B, Cl, Fs + reasoning_latent_count, h, w), generator, device, dtype)], dim=2)
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """:431-446 -- ``eta`` / ``generator`` only for schedulers whose ``step`` takes them (FlowUniPC takes ``generator``)."""
+        import inspect
+        names = set(inspect.signature(self.scheduler.step).parameters.keys())
+        kw = {}
+        if "eta" in names:
+            kw["eta"] = eta
+        if "generator" in names:
+            kw["generator"] = generator
+        return kw
+
+    @property
+    def attention_kwargs(self):
+        return getattr(self, "_attention_kwargs", None)
 
     def decode_latents(self, latents: torch.Tensor, out: Optional[torch.Tensor] = None) -> np.ndarray:
         """:423-428 -- decode, (x / 2 + 0.5).clamp(0, 1), float32 numpy.  The reference converts on the host
@@ -196,14 +288,16 @@ class WanPipeline:
         del timesteps
         if num_videos_per_prompt != 1:
             raise NotImplementedError("num_videos_per_prompt must be 1 (as in fast_infer.py / inference.py)")
-        self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        self.check_inputs(prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds, negative_prompt_embeds)
         self._guidance_scale = guidance_scale
+        self._attention_kwargs = attention_kwargs                                               # :575 (stored, read by nothing, as there)
         self._interrupt = False
         device = torch.device(device) if device is not None else self.transformer.device
         do_cfg = guidance_scale > 1.0                                                           # :592
         t_stage = self._stage("text_encoder")
         prompt_embeds, negative_prompt_embeds = self.encode_prompt(
-            prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds, device, max_sequence_length)
+            prompt, negative_prompt, do_cfg, num_videos_per_prompt=num_videos_per_prompt, prompt_embeds=prompt_embeds,
+            negative_prompt_embeds=negative_prompt_embeds, max_sequence_length=max_sequence_length, device=device)
         self._stage("text_encoder", t_stage)
         in_prompt_embeds = (negative_prompt_embeds + prompt_embeds) if do_cfg else prompt_embeds   # :605-608
 
@@ -219,12 +313,12 @@ class WanPipeline:
         t_stage = self._stage("vae_encode")
         if cot:
             ground_latent_count = 1 if reasoning_frames <= 1 else (reasoning_frames - 1) // ratio + 1   # :637
-            latents = self.prepare_cot_video_latents(video, ground_latent_count, weight_dtype, device,
-                                                     generator, latents, source_latents)
+            latents = self.prepare_cot_video_latents(video, ground_latent_count, dtype=weight_dtype, device=device, generator=generator,
+                                                     condition_count=condition_count, latents=latents, source_latents=source_latents)
         else:
-            # repeat / org layouts: noise block has the source's frame count (:370-379)
-            latents = self.prepare_cot_video_latents(video, 0, weight_dtype, device, generator, latents,
-                                                     source_latents)
+            # repeat / org layouts: noise block has the source's frame count (:653-677 -> :343-378)
+            latents = self.prepare_video_latents_new(video, dtype=weight_dtype, device=device, generator=generator,
+                                                     condition_count=condition_count, latents=latents, source_latents=source_latents)
         self._stage("vae_encode", t_stage)
         B, _, Ftot, hl, wl = latents.shape
         ps = self.transformer.config.patch_size

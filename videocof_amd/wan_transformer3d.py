@@ -646,6 +646,32 @@ class WanTransformer3DModel(nn.Module):
     def disable_cfg_skip(self):
         self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
 
+    def share_cfg_skip(self, transformer=None):
+        """wan_transformer3d.py:762-768 (the second transformer of a two-stage pipeline takes the first one's counters)."""
+        self.cfg_skip_ratio = transformer.cfg_skip_ratio
+        self.current_steps = transformer.current_steps
+        self.num_inference_steps = transformer.num_inference_steps
+
+    def enable_riflex(self, k=6, L_test=66, L_test_scale=4.886):
+        """wan_transformer3d.py:775-789 replaces the temporal RoPE table by the RIFLEx one; only the Gradio UI reaches it
+        (ui/wan_ui.py:247-250), no CLI of the path does, and it changes outputs: not built (OUT OF SCOPE)."""
+        raise NotImplementedError("RIFLEx temporal frequencies are not built (SURVEY.md section 2: out of scope; no CLI of this path enables them)")
+
+    def disable_riflex(self):
+        """wan_transformer3d.py:791-800 restores the default table -- which is the only one this model ever holds."""
+        return None
+
+    def unpatchify(self, x, grid_sizes):
+        """wan_transformer3d.py:1108-1131: per sample, the first prod(grid) token rows [L, prod(patch) * C_out] -> [C_out, F, H / 8, W / 8]
+        (`fhwpqrc->cfphqwr`), on the layout kernel the forward itself uses.  ``grid_sizes``: [B, 3] tensor or sequence of (F, Hp, Wp)."""
+        grids = grid_sizes.tolist() if torch.is_tensor(grid_sizes) else [tuple(g) for g in grid_sizes]
+        out = []
+        for u, v in zip(x, grids):
+            o = ops.unpatchify(u.float().contiguous(), tuple(int(i) for i in v), tuple(self.patch_size), self.out_dim,
+                               torch.float32 if u.dtype == torch.float32 else torch.bfloat16)
+            out.append(o if o.dtype == u.dtype else o.to(u.dtype))
+        return out
+
     # ------------------------------------------------------------------ pieces of forward
     def _time_embed(self, t: torch.Tensor):
         w = self._w
