@@ -129,6 +129,11 @@ def test_product_host_code_vs_reference(ns):
     assert mine.index_for_timestep(ref.timesteps[4]) == ref.index_for_timestep(ref.timesteps[4]) == 4
     assert mine.index_for_timestep(ref.timesteps[4], ref.timesteps[2:]) == ref.index_for_timestep(ref.timesteps[4], ref.timesteps[2:]) == 2
     assert len(mine) == len(ref) == 1000
+    # .config holds every constructor argument, by attribute and by key, as @register_to_config's does; from_config round-trips it
+    assert dict(mine.config) == {k: v for k, v in vars(ref.config).items() if not k.startswith("_")}      # (the import shim's config is a namespace)
+    assert mine.config.solver_type == mine.config["solver_type"] == "bh2"
+    again = FlowUniPCMultistepScheduler.from_config(mine.config, shift=3.0, not_an_argument=1)
+    assert again.config.shift == 3.0 and again.config.solver_order == 2
     for sch in (ref, mine):
         sch.set_begin_index(3)
     assert torch.equal(mine.add_noise(x0, nz, tsel), ref.add_noise(x0, nz, tsel))
@@ -137,6 +142,10 @@ def test_product_host_code_vs_reference(ns):
     m = ns.transformer.WanTransformer3DModel(model_type="t2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64,
                                              in_dim=16, out_dim=16, freq_dim=256, cross_attn_norm=True, qk_norm=True)
     m.load_state_dict(sd, strict=True)
+    from videocof_amd import WanTransformer3DModel
+    mine_m = WanTransformer3DModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    want_cfg = {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in vars(m.config).items() if not k.startswith("_")}
+    assert vars(mine_m.config) == want_cfg                    # every constructor argument, as @register_to_config holds them
     lora = {}
     for name, (o, i) in {"blocks.1.self_attn.v": (256, 256), "blocks.0.ffn.2": (256, 512), "blocks.1.cross_attn.k": (256, 256)}.items():
         lora[f"diffusion_model.{name}.lora_down.weight"] = torch.randn(8, i, generator=g) * 0.1

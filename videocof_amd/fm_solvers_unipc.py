@@ -41,8 +41,23 @@ def _lam(sigma: float) -> float:
     return math.log1p(-sigma) - math.log(sigma) if sigma < 1.0 else -math.inf
 
 
+class _Config(dict):
+    """The constructor arguments, readable as attributes and as keys (diffusers' FrozenDict, without the freezing machinery)."""
+    __getattr__ = dict.__getitem__
+
+
 class FlowUniPCMultistepScheduler:
     order = 1
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        """diffusers' ``SchedulerMixin.from_config``: a scheduler from another one's ``.config`` (or a plain dict), keyword overrides on
+        top; entries the constructor does not take are ignored."""
+        import inspect
+        names = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        cfg = {k: v for k, v in dict(config).items() if k in names}
+        cfg.update({k: v for k, v in kwargs.items() if k in names})
+        return cls(**cfg)
 
     def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2,
                  prediction_type: str = "flow_prediction", shift: Optional[float] = 1.0,
@@ -61,10 +76,13 @@ class FlowUniPCMultistepScheduler:
             raise ValueError(f"solver_order={solver_order} must be >= 1")
         if use_dynamic_shifting or thresholding or solver_p is not None or final_sigmas_type != "zero":
             raise NotImplementedError("dynamic shifting / thresholding / solver_p / sigma_min are not on the VideoCoF path")
-        self.config = type("Config", (), dict(
-            num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type,
-            shift=shift, use_dynamic_shifting=False, thresholding=False, predict_x0=True, solver_type=solver_type,
-            lower_order_final=lower_order_final, final_sigmas_type="zero"))()
+        # what diffusers' @register_to_config would hold: EVERY constructor argument, by attribute and by key (fm_solvers_unipc.py:73-92)
+        self.config = _Config(
+            num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type, shift=shift,
+            use_dynamic_shifting=False, thresholding=False, dynamic_thresholding_ratio=dynamic_thresholding_ratio,
+            sample_max_value=sample_max_value, predict_x0=True, solver_type=solver_type, lower_order_final=lower_order_final,
+            disable_corrector=list(disable_corrector), solver_p=None, timestep_spacing=timestep_spacing, steps_offset=steps_offset,
+            final_sigmas_type="zero")
         self.predict_x0 = True
         self.disable_corrector = list(disable_corrector)
         alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()

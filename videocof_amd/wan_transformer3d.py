@@ -110,7 +110,12 @@ class WanTransformer3DModel(nn.Module):
             model_type=model_type, patch_size=tuple(patch_size), text_len=text_len, in_dim=in_dim, dim=dim,
             ffn_dim=ffn_dim, freq_dim=freq_dim, text_dim=text_dim, out_dim=out_dim, num_heads=num_heads,
             num_layers=num_layers, window_size=tuple(window_size), qk_norm=qk_norm,
-            cross_attn_norm=cross_attn_norm, eps=eps, in_channels=in_dim, hidden_size=dim)
+            cross_attn_norm=cross_attn_norm, eps=eps,
+            # as @register_to_config stores them: the constructor's own `in_channels` / `hidden_size` arguments (defaults 16 / 2048,
+            # independent of in_dim / dim: wan_transformer3d.py:579-604) and the switches of the other model families
+            in_channels=in_channels, hidden_size=hidden_size, add_control_adapter=add_control_adapter,
+            in_dim_control_adapter=in_dim_control_adapter, downscale_factor_control_adapter=downscale_factor_control_adapter,
+            add_ref_conv=add_ref_conv, in_dim_ref_conv=in_dim_ref_conv, cross_attn_type=cross_attn_type)
         self.model_type, self.patch_size, self.text_len = model_type, tuple(patch_size), text_len
         self.in_dim, self.dim, self.ffn_dim, self.freq_dim = in_dim, dim, ffn_dim, freq_dim
         self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
