@@ -448,3 +448,22 @@ def test_ulysses_head_padding_is_an_exact_rearrangement():
     vp = x @ rows(wv).t() + rows(bv)
     got = attend(qp, kp, vp, Hp) @ rows(wo.t().contiguous())          # (the model stores this as an nn.Linear weight: [C, C_pad])
     assert float((got - ref).abs().max()) < 1e-10
+
+
+def test_vae_posterior_surface():
+    """``encode(x)[0]``: mean | clamped log-variance, mode / sample (on the generator's stream) / kl / nll."""
+    from videocof_amd.wan_vae import AutoencoderKLOutput, DiagonalGaussianDistribution
+    p = torch.randn(2, 32, 3, 4, 5, generator=torch.Generator().manual_seed(1)) * 20
+    d = DiagonalGaussianDistribution(p)
+    assert torch.equal(d.mode(), p[:, :16]) and float(d.logvar.max()) <= 20.0 and float(d.logvar.min()) >= -30.0
+    assert torch.equal(d.std, torch.exp(0.5 * d.logvar)) and torch.equal(d.var, torch.exp(d.logvar))
+    g = torch.Generator().manual_seed(3)
+    want = d.mean + d.std * torch.randn(d.mean.shape, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(d.sample(g), want)
+    unit = DiagonalGaussianDistribution(torch.zeros(2, 32, 1, 2, 2))
+    assert torch.equal(unit.kl(), torch.zeros(2, 2)) and torch.allclose(d.kl(d), torch.zeros(2, 5), atol=1e-3)      # (sums over dims 1..3 of a 5-D latent, as diffusers' class does)
+    assert unit.nll(torch.zeros(2, 16, 1, 2, 2)).shape == (2, 2) and abs(float(unit.nll(torch.zeros(2, 16, 1, 2, 2))[0, 0]) - 0.5 * 16 * 2 * 1.8378770664) < 1e-4
+    det = DiagonalGaussianDistribution(p, deterministic=True)
+    assert torch.equal(det.sample(), det.mean) and float(det.kl()) == 0.0
+    out = AutoencoderKLOutput(d)
+    assert out[0] is d and out.latent_dist is d

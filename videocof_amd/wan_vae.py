@@ -39,18 +39,41 @@ _STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
 
 
 class DiagonalGaussianDistribution:
-    """The two methods of diffusers' class that the pipeline calls."""
-    def __init__(self, parameters: torch.Tensor):
+    """What ``encode(x)[0]`` / ``.latent_dist`` is (wan_vae.py:655-668 builds diffusers' class of this name from the encoder's 32 channels):
+    mean | log-variance halves of dim 1, the log-variance clamped to [-30, 20]; ``mode()`` is what the pipeline takes
+    (pipeline_wan.py:406-407), ``sample`` / ``kl`` / ``nll`` complete the surface."""
+
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
         self.parameters = parameters
-        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.deterministic = deterministic
+        self.std, self.var = torch.exp(0.5 * self.logvar), torch.exp(self.logvar)
+        if deterministic:
+            self.std = self.var = torch.zeros_like(self.mean)
 
     def mode(self) -> torch.Tensor:
         return self.mean
 
     def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-        std = torch.exp(0.5 * self.logvar.clamp(-30.0, 20.0))
-        return self.mean + std * torch.randn(self.mean.shape, generator=generator, device=self.mean.device,
-                                             dtype=self.mean.dtype)
+        dev = self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=generator.device if generator is not None else dev,
+                            dtype=self.mean.dtype).to(dev)          # drawn on the generator's device, as diffusers' randn_tensor does
+        return self.mean + self.std * noise
+
+    def kl(self, other: Optional["DiagonalGaussianDistribution"] = None) -> torch.Tensor:
+        if self.deterministic:
+            return torch.zeros(1)
+        if other is None:
+            t = self.mean.pow(2) + self.var - 1.0 - self.logvar
+        else:
+            t = (self.mean - other.mean).pow(2) / other.var + self.var / other.var - 1.0 - self.logvar + other.logvar
+        return 0.5 * t.sum(dim=[1, 2, 3])
+
+    def nll(self, sample: torch.Tensor, dims=(1, 2, 3)) -> torch.Tensor:
+        if self.deterministic:
+            return torch.zeros(1)
+        return 0.5 * (math.log(2.0 * math.pi) + self.logvar + (sample - self.mean).pow(2) / self.var).sum(dim=list(dims))
 
 
 class AutoencoderKLOutput:
