@@ -62,6 +62,42 @@ def test_g6_forward_batch2_and_bf16_latents(golden, model):
     assert torch.equal(out_l, out)
 
 
+def test_forward_random_layouts_vs_oracle(model):
+    """A randomised sweep of what a caller can vary at the forward seam (wan_transformer3d.py:818-833) -- latent grid (odd and even
+    frame / row / column counts, i.e. clips at their native resolution), how the frames split into source | grounding | target (incl.
+    no split, the paired-only form without grounding frames, several grounding frames), batch 1 / 2, seq_len == L and seq_len > L,
+    prompt lengths 1 ... 77, timestep -- against the CPU oracle.  seq_len > L: the product follows the reference's flash-attn branch,
+    which trims the keys to `k_lens = seq_lens` (wan_transformer3d.py:298, attention_utils.py:95-100), so padding must not change a
+    valid row (test_seq_len_padding_and_assert); the oracle restates the SDPA branch, which cannot mask (attention_utils.py:198-210),
+    and is therefore evaluated WITHOUT the padding."""
+    import random
+    rnd = random.Random(7)
+    sd = deterministic_dit_state_dict(**TINY)
+    worst = 0.0
+    for case in range(14):
+        F, Hl, Wl = rnd.randint(1, 9), 2 * rnd.randint(1, 7), 2 * rnd.randint(1, 9)
+        B = rnd.choice([1, 1, 2])
+        L = F * (Hl // 2) * (Wl // 2)
+        seq_len = L + rnd.choice([0, 0, 1, 5, 64])
+        mode = ("t2v", "paired", "cof", "cof")[case % 4] if F >= 3 else "t2v"
+        fsi = gfi = None
+        if mode != "t2v":
+            fs = rnd.randint(1, F - 2)
+            fsi = [fs] * B
+            if mode == "cof":
+                gfi = [(fs, fs + rnd.randint(1, F - 1 - fs))] * B
+        lat = det_uniform(f"fz.lat{case}", (B, 16, F, Hl, Wl), 1.0)
+        ctx = [det_uniform(f"fz.ctx{case}.{b}", (rnd.randint(1, 77), 64), 1.0) for b in range(B)]
+        t = torch.tensor([rnd.choice([999, 899, 749, 499, 37])] * B)
+        ref = O.dit_forward(sd, CFG, lat, t, ctx, L, fsi, gfi)
+        out = model(lat.to(DEV), t.to(DEV), [c.to(DEV) for c in ctx], seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+        assert out.shape == ref.shape
+        r, c = rel_l2(out, ref), cosine(out, ref)
+        assert r < 1e-2 and c > 0.9999, (case, (B, F, Hl, Wl), seq_len, mode, fsi, gfi, r, c)
+        worst = max(worst, r)
+    print(f"[fuzz] 14 random layouts: worst rel-L2 {worst:.2e}")
+
+
 def test_samples_with_different_cof_maps_in_one_call(golden, model):
     """rope_apply_qk takes the CoF position map per sample (wan_transformer3d.py:160-179): a call whose samples split their frames
     differently is served group by group -- against the oracle with per-sample maps, bitwise equal to the samples run alone, output
