@@ -205,12 +205,12 @@ def test_fp8_then_merge_lora_equals_merge_then_fp8():
     from videocof_amd.lora_utils import merge_lora, unmerge_lora
     tiny = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
     r, C = 4, 256
-    lora = {"blocks.0.self_attn.q.lora_down.weight": det_uniform("f8l.a.down", (r, C), 0.3),
-            "blocks.0.self_attn.q.lora_up.weight": det_uniform("f8l.a.up", (C, r), 0.3),
-            "blocks.1.ffn.0.lora_down.weight": det_uniform("f8l.b.down", (r, C), 0.3),
-            "blocks.1.ffn.0.lora_up.weight": det_uniform("f8l.b.up", (512, r), 0.3),
-            "blocks.1.self_attn.o.lora_down.weight": det_uniform("f8l.c.down", (r, C), 0.3),
-            "blocks.1.self_attn.o.lora_up.weight": det_uniform("f8l.c.up", (C, r), 0.3)}
+    lora = {"diffusion_model.blocks.0.self_attn.q.lora_down.weight": det_uniform("f8l.a.down", (r, C), 0.3),
+            "diffusion_model.blocks.0.self_attn.q.lora_up.weight": det_uniform("f8l.a.up", (C, r), 0.3),
+            "diffusion_model.blocks.1.ffn.0.lora_down.weight": det_uniform("f8l.b.down", (r, C), 0.3),
+            "diffusion_model.blocks.1.ffn.0.lora_up.weight": det_uniform("f8l.b.up", (512, r), 0.3),
+            "diffusion_model.blocks.1.self_attn.o.lora_down.weight": det_uniform("f8l.c.down", (r, C), 0.3),
+            "diffusion_model.blocks.1.self_attn.o.lora_up.weight": det_uniform("f8l.c.up", (C, r), 0.3)}
     lat = det_uniform("fp8.lat", (1, 16, 7, 12, 20), 1.0).to(DEV)
     ctx = [det_uniform("fp8.ctx", (37, 64), 1.0).to(DEV)]
     t = torch.tensor([899], device=DEV)

@@ -44,7 +44,12 @@ def test_merge_keeps_dtype_and_rejects_shape_mismatch():
     sd = {k: v.bfloat16() for k, v in deterministic_dit_state_dict(**TINY).items()}
     merge_lora_state_dict(sd, _lora(), 1.0)
     assert sd["blocks.0.self_attn.q.weight"].dtype == torch.bfloat16
-    bad = {"blocks.0.self_attn.q.lora_down.weight": torch.zeros(4, 100), "blocks.0.self_attn.q.lora_up.weight": torch.zeros(256, 4)}
+    bad = {"diffusion_model.blocks.0.self_attn.q.lora_down.weight": torch.zeros(4, 100),
+           "diffusion_model.blocks.0.self_attn.q.lora_up.weight": torch.zeros(256, 4)}
     import pytest
     with pytest.raises(ValueError, match="does not match"):
         merge_lora_state_dict(sd, bad, 1.0)
+    # a bare dotted name is cut at its FIRST dot by the reference (lora_utils.py:394): layer "blocks", no pair -> dropped, there and here
+    before = sd["blocks.0.self_attn.q.weight"].clone()
+    bare = {"blocks.0.self_attn.q.lora_down.weight": torch.ones(4, 256), "blocks.0.self_attn.q.lora_up.weight": torch.ones(256, 4)}
+    assert merge_lora_state_dict(sd, bare, 1.0) == 0 and torch.equal(sd["blocks.0.self_attn.q.weight"], before)

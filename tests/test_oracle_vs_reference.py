@@ -160,6 +160,55 @@ def test_product_host_code_vs_reference(ns):
         assert rel_l2(got[k], want[k]) < 1e-6, k
 
 
+@torch.no_grad()
+def test_lora_key_conventions_take_part_exactly_as_in_the_reference(ns):
+    """WHICH entries of a LoRA file are merged follows from the reference's renaming rules (lora_utils.py:378-395) -- including the
+    entries they silently drop: `diffusion_model.`-style names of modules outside the blocks (head, text / time embeddings), `lora_A`
+    names without `.default.`.  Every spelling below goes through the reference's merge_lora on the reference's model and through
+    merge_lora_state_dict on the same state dict: the same tensors change, by the same amounts."""
+    import types
+    from videocof_amd.lora_utils import merge_lora_state_dict
+    from videocof_amd.weights import deterministic_dit_state_dict
+    g = torch.Generator().manual_seed(3)
+    cfgd = dict(dim=256, ffn_dim=512, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=256)
+    base = deterministic_dit_state_dict(**cfgd)
+
+    def pair(name, o, i, style, alpha=2.0, r=4):
+        stem = {"dm": f"diffusion_model.{name}", "kohya": "lora_unet__" + name.replace(".", "_"), "kohya1": "lora_unet_" + name.replace(".", "_"),
+                "peft": name, "peft_dm": f"diffusion_model.{name}", "peft_nodefault": name}[style]
+        dn, up = {"peft": (".lora_A.default.weight", ".lora_B.default.weight"), "peft_dm": (".lora_A.default.weight", ".lora_B.default.weight"),
+                  "peft_nodefault": (".lora_A.weight", ".lora_B.weight")}.get(style, (".lora_down.weight", ".lora_up.weight"))
+        d = {stem + dn: torch.randn(r, i, generator=g) * 0.1, stem + up: torch.randn(o, r, generator=g) * 0.1}
+        if alpha is not None and not style.startswith("peft"):
+            d[stem + ".alpha"] = torch.tensor(alpha)
+        return d
+    cases = {
+        "dm, blocks": ({**pair("blocks.0.self_attn.q", 256, 256, "dm"), **pair("blocks.1.ffn.0", 512, 256, "dm"), **pair("blocks.1.cross_attn.v", 256, 256, "dm", alpha=None)}, 3),
+        "dm, outside the blocks: dropped": ({**pair("text_embedding.0", 256, 64, "dm"), **pair("time_embedding.2", 256, 256, "dm"), **pair("head.head", 64, 256, "dm"),
+                                             **pair("time_projection.1", 1536, 256, "dm"), **pair("blocks.0.ffn.2", 256, 512, "dm")}, 1),
+        "kohya, blocks and outside": ({**pair("blocks.0.cross_attn.o", 256, 256, "kohya"), **pair("head.head", 64, 256, "kohya"), **pair("text_embedding.2", 256, 256, "kohya"),
+                                       **pair("blocks.1.self_attn.k", 256, 256, "kohya1", alpha=None)}, 4),
+        "peft with .default.": ({**pair("blocks.0.self_attn.v", 256, 256, "peft"), **pair("blocks.1.ffn.2", 256, 512, "peft")}, 2),
+        "peft without .default.: dropped": (pair("blocks.0.self_attn.q", 256, 256, "peft_nodefault"), 0),
+        "text-encoder and unknown layers": ({**pair("blocks.0.self_attn.o", 256, 256, "dm"), **pair("blocks.7.self_attn.q", 256, 256, "dm"),
+                                             "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight": torch.zeros(4, 8),
+                                             "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight": torch.zeros(8, 4),
+                                             "diffusion_model.blocks.0.self_attn.norm_q.diff": torch.zeros(256)}, 1),
+    }
+    for what, (lora, n_merged) in cases.items():
+        m = ns.transformer.WanTransformer3DModel(model_type="t2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64,
+                                                 in_dim=16, out_dim=16, freq_dim=256, cross_attn_norm=True, qk_norm=True)
+        m.load_state_dict(base, strict=True)
+        ns.load_lora_utils().merge_lora(types.SimpleNamespace(transformer=m), None, 0.7, device="cpu", dtype=torch.float32,
+                                        state_dict=dict(lora), transformer_only=True)
+        want = m.state_dict()
+        got = {k: v.clone() for k, v in base.items()}
+        assert merge_lora_state_dict(got, dict(lora), 0.7) == n_merged, what
+        assert sum(1 for k in want if not torch.equal(want[k], base[k])) == n_merged, what
+        for k in want:
+            assert rel_l2(got[k], want[k]) < 1e-6, (what, k)
+
+
 def test_call_signatures_are_the_references():
     """Drop-in surface: every seam the reference calls has, on the mirror, the reference's
     parameter NAMES in the reference's ORDER with the reference's DEFAULTS -- read from the reference's source with `ast` (no import: its

@@ -10,7 +10,7 @@ before ``WanTransformer3DModel.load_state_dict`` packs it:
     merge_lora_state_dict(sd, load_file("videocof.safetensors"), 1.0, device="cuda")
     model.load_state_dict(sd)
 
-Key conventions accepted (the renaming rules of lora_utils.py:379-394):
+Key conventions (the renaming rules of lora_utils.py:379-394, restated as they stand in ``_groups`` -- including which entries they DROP):
   * ComfyUI/Wan:  ``diffusion_model.blocks.0.self_attn.q.lora_down.weight`` (+ ``lora_up``, ``alpha``)
   * PEFT:         ``blocks.0.self_attn.q.lora_A.default.weight`` / ``lora_B.default.weight``
   * kohya:        ``lora_unet__blocks_0_self_attn_q.lora_down.weight``
@@ -39,22 +39,38 @@ def _module_index(sd: Dict[str, torch.Tensor]) -> Dict[str, str]:
     return idx
 
 
-def _normalise(key: str):
-    """LoRA tensor name -> (flattened module name, element) or None."""
-    if "lora_te" in key:
-        return None
-    k = key
-    if k.startswith("lora_unet__"):
-        k = k[len("lora_unet__"):]
-    elif k.startswith("lora_unet_"):
-        k = k[len("lora_unet_"):]
-    k = k.replace("diffusion_model.", "")
-    k = k.replace(".lora_A.default.", ".lora_down.").replace(".lora_B.default.", ".lora_up.")
-    k = k.replace(".lora_A.", ".lora_down.").replace(".lora_B.", ".lora_up.")
-    for elem in ("lora_down.weight", "lora_up.weight", "alpha"):
-        if k.endswith("." + elem):
-            return k[:-len(elem) - 1].replace(".", "_"), elem
-    return None
+def _groups(lora_sd: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
+    """LoRA tensors grouped the way the reference groups them (lora_utils.py:378-395): flattened module name -> {element: tensor}.
+
+    The renaming rules are restated as they stand, because WHICH entries of a file take part follows from them:
+      * a name containing ``diffusion_model``: ``diffusion_model.`` -> ``lora_unet__``, ``blocks.`` -> ``blocks_``, and the dots around
+        ``self_attn`` / ``cross_attn`` / ``ffn`` become underscores -- nothing else, so ``diffusion_model.head.head.lora_up.weight`` or
+        ``diffusion_model.text_embedding.0.lora_down.weight`` keep a dot inside the module path;
+      * a name containing ``lora_A`` / ``lora_B`` (PEFT): the same, plus ``.lora_A.default.`` -> ``.lora_down.`` (only with ``.default.``);
+      * the name is then cut AT ITS FIRST DOT into (layer, element).
+    A pair is merged only if its layer holds elements called exactly ``lora_up.weight`` and ``lora_down.weight`` (:472-476) -- so the
+    ``head`` / ``text_embedding`` / ``time_embedding`` / ``time_projection`` entries of a ``diffusion_model.``-style file (layer = the part
+    before the remaining dot, element = ``head.lora_up.weight`` ...) are DROPPED by the reference, as are ``lora_A`` names without
+    ``.default.``; the kohya spelling of the same modules (``lora_unet__head_head.lora_up.weight``) is merged.  Mirrored, not repaired: a
+    checkpoint must give the weights here that it gives there.  ``lora_te`` layers (text encoder) are not this model's."""
+    groups: Dict[str, Dict[str, torch.Tensor]] = defaultdict(dict)
+    for key, val in lora_sd.items():
+        k = key
+        if "diffusion_model" in k:
+            k = (k.replace("diffusion_model.", "lora_unet__").replace("blocks.", "blocks_").replace(".self_attn.", "_self_attn_")
+                 .replace(".cross_attn.", "_cross_attn_").replace(".ffn.", "_ffn_"))
+        if "lora_A" in k or "lora_B" in k:
+            k = ("lora_unet__" + k).replace("blocks.", "blocks_").replace(".self_attn.", "_self_attn_") \
+                .replace(".cross_attn.", "_cross_attn_").replace(".ffn.", "_ffn_") \
+                .replace(".lora_A.default.", ".lora_down.").replace(".lora_B.default.", ".lora_up.")
+        if "." not in k:
+            raise ValueError(f"LoRA tensor name without an element part: {key!r}")          # (:394 fails to unpack the split)
+        layer, elem = k.split(".", 1)
+        if "lora_te" in layer:
+            continue
+        # the module the reference's attribute walk ends at (:417-468) is the one whose dotted path flattens to this name
+        groups[layer.split("lora_unet_")[-1].lstrip("_")][elem] = val
+    return groups
 
 
 @torch.no_grad()
@@ -63,11 +79,7 @@ def merge_lora_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.
     """In-place ``sd[w] += multiplier * alpha/r * up @ down`` for every LoRA pair that resolves to a
     weight of ``sd``.  Returns the number of merged layers."""
     index = _module_index(sd)
-    groups = defaultdict(dict)
-    for key, val in lora_sd.items():
-        n = _normalise(key)
-        if n is not None:
-            groups[n[0]][n[1]] = val
+    groups = _groups(lora_sd)
     merged = 0
     for flat, elems in groups.items():
         mod = index.get(flat)
@@ -110,11 +122,7 @@ def merge_lora(pipeline, lora_path, multiplier, device=None, dtype=torch.float32
         wdev = next(iter(weights.values())).device
         state_dict = load_file(lora_path, device=str(wdev))
     index = {name.replace(".", "_"): name for name in weights}
-    groups = defaultdict(dict)
-    for key, val in state_dict.items():
-        n = _normalise(key)
-        if n is not None:
-            groups[n[0]][n[1]] = val
+    groups = _groups(state_dict)
     merged, unresolved = 0, []
     for flat, elems in groups.items():
         if "lora_up.weight" not in elems or "lora_down.weight" not in elems:
