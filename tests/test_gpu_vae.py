@@ -181,6 +181,22 @@ def test_vae_vs_oracle_other_shape(vae):
     assert rel_l2(vae.decode(z.to(DEV)).sample[0], orc.decode(z[0])) < 3e-2
 
 
+@pytest.mark.parametrize("T,H,W", [(1, 16, 24), (2, 16, 16), (13, 24, 16), (9, 24, 40)])
+def test_vae_vs_oracle_clip_lengths_and_odd_planes(vae, T, H, W):
+    """A single image (T = 1), a clip whose tail does not fill a chunk (T = 2: the reference encodes 1 + (T - 1) // 4 chunks,
+    wan_vae.py:527-539), T = 13 (chunks 1, 4, 4, 4), latent planes with odd row / column counts (3 x 2, 3 x 5): encode -> parameters and
+    decode against the oracle (which equals the reference on these very shapes, tests/test_oracle_vs_reference.py)."""
+    orc = WanVAEOracle(deterministic_vae_state_dict())
+    video = det_uniform(f"vae.len{T}", (1, 3, T, H, W), 1.0)
+    ref = orc.encode(video[0])
+    got = vae.encode(video.to(DEV))[0].parameters[0]
+    assert got.shape == ref.shape and rel_l2(got, ref) < 3e-2
+    z = det_uniform(f"vae.len{T}.z", (1, 16, ref.shape[1], H // 8, W // 8), 1.5)
+    want = orc.decode(z[0])
+    out = vae.decode(z.to(DEV)).sample[0]
+    assert out.shape == want.shape and rel_l2(out, want) < 3e-2
+
+
 def test_vae_rejects_cpu_and_bad_sizes(vae):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         vae.encode(torch.zeros(1, 3, 1, 8, 8))

@@ -96,6 +96,13 @@ def test_vae_random_clip(ns):
     assert rel_l2(orc.encode(video[0])[:16], ref_mu[0]) < 1e-5
     z = torch.randn(1, 16, 2, 2, 3, generator=g)
     assert rel_l2(orc.decode(z[0]), vae.decode(z).sample[0]) < 1e-5
+    # a single image, a clip whose tail does not fill a chunk, 13 frames, odd latent planes (the shapes tests/test_gpu_vae.py runs the HIP path at)
+    for T, H, W in ((1, 16, 24), (2, 16, 16), (13, 24, 16), (9, 24, 40)):
+        video = torch.rand(1, 3, T, H, W, generator=g) * 2 - 1
+        ref_mu = vae.encode(video)[0].mode()
+        assert rel_l2(orc.encode(video[0])[:16], ref_mu[0]) < 1e-5, (T, H, W)
+        z = torch.randn(1, 16, ref_mu.shape[2], H // 8, W // 8, generator=g)
+        assert rel_l2(orc.decode(z[0]), vae.decode(z).sample[0]) < 1e-5, (T, H, W)
 
 
 @torch.no_grad()
@@ -327,3 +334,37 @@ def test_public_methods_of_the_reference_classes_exist_on_the_mirrors():
                            ("models/cache_utils.py", "TeaCache", cache_utils.TeaCache)):
         missing = {m for m in ref_methods(path, cls) if not hasattr(obj, m)}
         assert missing == allowed[cls], (cls, sorted(missing - allowed[cls]), sorted(allowed[cls] - missing))
+
+
+@torch.no_grad()
+def test_unipc_configuration_sweep(ns):
+    """648 scheduler configurations (steps x shift x solver order x lower_order_final x disable_corrector x bh1 / bh2): wherever the
+    reference's own trajectory is finite (it is not for bh1 or lower_order_final=False at the final sigma = 0, and its linear solve fails
+    for some), the mirror's timesteps / sigmas are equal and its trajectory matches to 1e-5; the mirror never fails where the reference runs."""
+    import itertools
+    from videocof_amd import FlowUniPCMultistepScheduler as Mine
+    g = torch.Generator().manual_seed(0)
+    equal = 0
+    for steps, shift, order, lof, dc, st in itertools.product([1, 2, 3, 4, 7, 20], [1.0, 3.0, 5.0], [1, 2, 3], [True, False], [[], [0], [1, 2]],
+                                                              ["bh1", "bh2"]):
+        kw = dict(num_train_timesteps=1000, shift=1, solver_order=order, lower_order_final=lof, disable_corrector=dc, solver_type=st)
+        r = ns.unipc.FlowUniPCMultistepScheduler(prediction_type="flow_prediction", **kw)
+        m = Mine(**kw)
+        r.set_timesteps(steps, device="cpu", shift=shift)
+        m.set_timesteps(steps, device="cpu", shift=shift)
+        assert torch.equal(m.timesteps, r.timesteps) and torch.equal(m.sigmas, r.sigmas)
+        a = b = torch.randn(1, 4, 2, 3, 3, generator=g)
+        ok = True
+        for tt in r.timesteps:
+            v = torch.randn(1, 4, 2, 3, 3, generator=g)
+            try:
+                a = r.step(v, tt, a, return_dict=False)[0]
+            except Exception:
+                ok = False
+            if not ok or not torch.isfinite(a).all():
+                ok = False
+                break
+            b = m.step(v, tt, b, return_dict=False)[0]
+            assert rel_l2(b, a) < 1e-5, (steps, shift, order, lof, dc, st)
+        equal += ok
+    assert equal >= 200, equal          # (234 here: every bh2 / lower_order_final configuration among them)
