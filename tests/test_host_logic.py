@@ -128,6 +128,14 @@ def test_pipeline_cof_loop_matches_reference(golden):
     for i in range(4):
         assert rel_l2(seen[i], g["steps"][i]) < 1e-5
     assert rel_l2(out.latents, g["steps"][3]) < 1e-5
+    # the callback receives the tensors named in callback_on_step_end_tensor_inputs (pipeline_wan.py:742-746), and latents it
+    # returns replace the loop's (:748)
+    keys = []
+    out2 = pipe(latents=lat, prompt_embeds=[torch.from_numpy(g["ctx"])], source_frames=9, reasoning_frames=4, num_inference_steps=2,
+                guidance_scale=1.0, shift=3, repeat_rope=True, cot=True, output_type="latent", weight_dtype=torch.float32,
+                callback_on_step_end_tensor_inputs=["latents", "prompt_embeds", "negative_prompt_embeds"],
+                callback_on_step_end=lambda p, i, t, kw: keys.append(sorted(kw)) or {"latents": torch.zeros_like(kw["latents"])})
+    assert keys == [["latents", "negative_prompt_embeds", "prompt_embeds"]] * 2 and float(out2.latents.abs().max()) == 0.0
 
 
 def test_pipeline_cfg_loop_matches_reference(golden):

@@ -383,7 +383,10 @@ class WanPipeline:
                 # else: already zero -- written by wan_unpatchify(zero_frames); CFG keeps it (0 + s * (0 - 0))
                 latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]     # :740
                 if callback_on_step_end is not None:
-                    out = callback_on_step_end(self, i, t, {"latents": latents})
+                    # :742-750 -- the tensors named in callback_on_step_end_tensor_inputs; only `latents` coming back has an effect
+                    # (there as here: the embeddings of the loop were concatenated before it started, :605-608)
+                    vals = {"latents": latents, "prompt_embeds": prompt_embeds, "negative_prompt_embeds": negative_prompt_embeds}
+                    out = callback_on_step_end(self, i, t, {k: vals[k] for k in (callback_on_step_end_tensor_inputs or ())})
                     if out:
                         latents = out.pop("latents", latents)
             return latents
