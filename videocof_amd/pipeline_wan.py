@@ -286,8 +286,7 @@ class WanPipeline:
         # `timesteps`: with a FlowUniPCMultistepScheduler the reference never looks at it (pipeline_wan.py:613-615 calls
         # set_timesteps(num_inference_steps, device=, shift=) and takes scheduler.timesteps); accepted and ignored here too.
         del timesteps
-        if num_videos_per_prompt != 1:
-            raise NotImplementedError("num_videos_per_prompt must be 1 (as in fast_infer.py / inference.py)")
+        num_videos_per_prompt = 1                  # :561 -- the reference overrides the argument at the top of __call__, whatever was passed
         self.check_inputs(prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds, negative_prompt_embeds)
         self._guidance_scale = guidance_scale
         self._attention_kwargs = attention_kwargs                                               # :575 (stored, read by nothing, as there)
