@@ -218,6 +218,22 @@ def box_object(box):
                     "before = after the warm-up steps, after = right after the timed region; the same kernels every round"}
 
 
+def normalised_split(tokens, wall, steps, layers, roof, box):
+    """`value_normalised` scales the WHOLE step by the probe, but only the self-attention launches follow the probe one to one (they run
+    its instruction mix: 0.97-0.98 of its rate on every box); the rest of a step -- Linears on another MFMA shape, HBM-bound rows --
+    follows it weakly.  Fitted on the 18 single-GPU headline lines of round 6 (10 boxes, probe 1 364 ... 1 532; profiles/r06/bench_14b*.json):
+    rest ~ probe^-0.3.  This figure normalises the two parts separately -- measured attention time x probe / reference, the remainder x
+    (probe / reference)^0.3 -- and spreads 2.5 % over those lines where `value_normalised` spreads 3.4 % (raw: 10 %); it does not
+    over-correct on boxes far from the reference.  None without kernel events or probe."""
+    if box is None or not roof or not roof.get("avg_ms"):
+        return None
+    rel = 0.5 * (box["before"]["mfma_mix_tflops"] + box["after"]["mfma_mix_tflops"]) / BOX_REFERENCE_MFMA_MIX_TFLOPS
+    attn_s = roof["avg_ms"] * 1e-3 * layers * steps
+    if not 0.0 < attn_s < wall:
+        return None
+    return round(tokens / (attn_s * rel + (wall - attn_s) * rel ** 0.3), 1)
+
+
 def committed_ingest():
     """What precedes the first edit of a process: checkpoint ingest + the three LoRA merges of fast_infer.py:366-386 at the real size
     (28.6 GB of bf16 safetensors shards, three rank-128 LoRA files), measured by tools/bench_ingest.py on a GPU box and committed -- it
@@ -831,6 +847,7 @@ def main():
         "roofline": roof,
         "box": box_object(box),
         "value_normalised": None if box is None else round(value * BOX_REFERENCE_MFMA_MIX_TFLOPS / (0.5 * (box["before"]["mfma_mix_tflops"] + box["after"]["mfma_mix_tflops"])), 1),
+        "value_normalised_split": normalised_split(tokens, wall, args.steps, wl["num_layers"], roof, box),
         "ranks_seen": dist.get_world_size() if grouped else 1,
         "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (host-staged, numbers meaningless)")
                     + (" -- ONE rank, force_ulysses: identity exchanges, the N > 1 code path only" if force_sp else "")) if grouped else None,

@@ -178,3 +178,27 @@ def test_committed_ingest_measurement_is_quoted_with_its_source():
     d = bench.committed_ingest()
     assert d is not None and d["source"].startswith("profiles/r") and d["measured_in_this_run"] is False
     assert d["check_ok"] is True and 25 < d["checkpoint_GB"] < 32 and d["load_s"] > 0 and d["merge_s"] > 0
+
+
+def test_split_normalisation_tightens_the_committed_lines():
+    """`value_normalised_split` (attention time x probe, the rest x probe^0.3) over the single-GPU headline lines committed under
+    profiles/r06: a tighter spread than `value_normalised`, which is tighter than the raw values; equal to the raw value at the reference probe."""
+    import glob
+    vals = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_14b*.json"))):
+        with open(f) as fh:
+            d = json.load(fh)
+        cfg = d.get("config", {})
+        if cfg.get("parallelism") != "single" or "VideoCoF layout, 4-step, 81f@480p" not in cfg.get("workload", "") or d.get("dtype") != "bf16":
+            continue
+        if d.get("attn_stress") or d.get("graph") or not d.get("box") or not d.get("roofline") or d["steps"] < 4:
+            continue
+        wall = d["ms_per_step"] * 1e-3 * d["steps"]
+        v = bench.normalised_split(67080 * d["steps"], wall, d["steps"], 40, d["roofline"], d["box"])
+        vals.append((v, d["value_normalised"], d["value"]))
+    assert len(vals) >= 10
+    spread = lambda i: max(v[i] for v in vals) / min(v[i] for v in vals) - 1
+    assert spread(0) < 0.025 < spread(1) < spread(2)
+    roof, box = {"avg_ms": 60.0}, {"before": {"mfma_mix_tflops": 1500.0}, "after": {"mfma_mix_tflops": 1500.0}}
+    assert bench.normalised_split(67080 * 4, 15.2, 4, 40, roof, box) == round(67080 * 4 / 15.2, 1)
+    assert bench.normalised_split(1, 1.0, 4, 40, None, box) is None and bench.normalised_split(1, 1.0, 4, 40, roof, None) is None
