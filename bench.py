@@ -535,6 +535,10 @@ def main():
     ap.add_argument("--sp-head-groups", type=int, default=2, choices=[1, 2],
                     help="sequence parallel: 2 (default) = q and o travel as two head groups, the second under the first group's attention and "
                          "vice versa (two attention launches per layer); 1 = one exchange + one launch (an A/B knob for a real N-GPU box)")
+    ap.add_argument("--cfg", type=float, default=0.0, metavar="S",
+                    help="classifier-free guidance with scale S > 1 as WanPipeline runs it (pipeline_wan.py:700-731): every step ONE forward "
+                         "over the batch [uncond, cond] (B = 2, two prompts), then uncond + S (cond - uncond) -- the per-step work of BASELINE "
+                         "configs[3] (inference.py defaults: guidance 5.0); tokens counted = B x L per step")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-box-probe", action="store_true",
                     help="skip the ~0.4 s box fingerprint (wan_box_probe) before and after the timed region")
@@ -648,10 +652,19 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0 if sp else rank)       # fast_infer.py:390 seeds per rank
     latents = torch.randn(1, 16, Ftot, wl["h"], wl["w"], device=dev, generator=g).bfloat16()
     ctx = [torch.randn(37, 4096, device=dev, generator=g).bfloat16()]
+    ctx1 = ctx                                   # the one-sample prompt list the untimed parity forward runs with
+    cfg_scale = float(args.cfg)
+    if cfg_scale and cfg_scale <= 1.0:
+        raise SystemExit("--cfg S: S > 1 (guidance 1.0 is the default single-sample step)")
+    if cfg_scale and (args.graph or args.graph_loop):
+        raise SystemExit("--cfg runs the eager loop")
+    nb = 2 if cfg_scale else 1                   # samples per forward
+    if cfg_scale:
+        ctx = [torch.randn(12, 4096, device=dev, generator=g).bfloat16()] + ctx          # [negative prompt, prompt] (:605-608)
     L = Ftot * (wl["h"] // 2) * (wl["w"] // 2)
     seq_len = L
-    fsi = [Fs] if cof else None
-    gfi = [(Fs, Fs + G)] if cof else None
+    fsi = [Fs] * nb if cof else None
+    gfi = [(Fs, Fs + G)] * nb if cof else None
     sched = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, solver_order=2)
 
     prof = [] if not args.no_kernel_events else None
@@ -687,7 +700,12 @@ def main():
                 sched._reset()
                 sched.set_begin_index(0)             # no device round trip inside a capture
             for t in sched.timesteps[:n_steps]:
-                v = fwd(lat, t.expand(1), c, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+                if cfg_scale:
+                    v2 = fwd(torch.cat([lat] * 2), t.expand(2), c, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+                    vu, vc = v2.chunk(2)
+                    v = vu + cfg_scale * (vc - vu)                                                   # :729-731
+                else:
+                    v = fwd(lat, t.expand(1), c, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
                 if cof and not args.graph and gloop is None:
                     v[:, :, :Fs] = 0
                 lat = sched.step(v, t, lat, return_dict=False)[0]
@@ -752,7 +770,7 @@ def main():
         model._probe_layer = wl["num_layers"] - 1
         tv = sched.timesteps[:1]
         try:
-            v = model(latents, tv.expand(1), ctx, seq_len, frame_split_indices=fsi, ground_frame_indices=gfi)
+            v = model(latents, tv.expand(1), ctx1, seq_len, frame_split_indices=fsi and fsi[:1], ground_frame_indices=gfi and gfi[:1])
             if sp:
                 grp = vdist.get_sp_group()
                 model._probe = grp.all_gather_tokens(model._probe.view(1, -1, wl["dim"]))[0].clone()
@@ -760,7 +778,7 @@ def main():
             model._probe_layer = None
         if rank == 0:
             try:
-                parity = verify_last_block(model, wl, latents, tv, ctx, seq_len, fsi, gfi, v, L)
+                parity = verify_last_block(model, wl, latents, tv, ctx1, seq_len, fsi and fsi[:1], gfi and gfi[:1], v, L)
                 if sp:
                     parity["what"] = ("sequence-parallel forward over %d ranks: " % world) + parity["what"] + \
                                      " (the probes are the ranks' token shards, gathered)"
@@ -820,6 +838,7 @@ def main():
                         dtype_peak="harmonic mix: QK^T at the dense fp8 MFMA rate (2 x bf16), P.V at the dense bf16 rate")
 
     units = world if (world > 1 and not sp) else 1            # dp: every rank denoises its own video
+    units *= nb                                                # --cfg: two samples per forward (tokens/s = B x L x steps / wall)
     tokens = units * L * args.steps
     value = tokens / wall
     tot_flop, attn_flop = dit_flops(L, wl["dim"], wl["ffn_dim"], wl["num_layers"])
@@ -833,7 +852,7 @@ def main():
         "data": "synthetic (random-init weights, N(0,1) latents + text embeddings)",
         "config": {"workload": wl["desc"], "layout": "VideoCoF (src|ground|tgt)" if cof else "T2V",
                    "latent": [1, 16, Ftot, wl["h"], wl["w"]], "grid": [Ftot, wl["h"] // 2, wl["w"] // 2],
-                   "tokens_per_sample": L, "global_batch": units, "guidance_scale": 1.0,
+                   "tokens_per_sample": L, "global_batch": units, "guidance_scale": cfg_scale or 1.0,
                    "layers_override": (wl["num_layers"] if args.layers > 0 else None),
                    "sp_padded_heads": (model._sp_pad.pad_heads if getattr(model, "_sp_pad", None) is not None else None),
                    "sp_head_groups": args.sp_head_groups if sp else None,
@@ -863,7 +882,7 @@ def main():
     if emu:
         res["metric"] = "PROJECTION (one rank of a %d-way Ulysses group emulated on one GPU): " % emu + res["metric"]
         res["tokens_per_s_per_gpu"] = round(value / emu, 1)
-        res["mfma_frac_whole_step"] = round(tot_flop * args.steps / wall / 1e12 / (PEAK_BF16_TFLOPS * emu), 4)
+        res["mfma_frac_whole_step"] = round(units * tot_flop * args.steps / wall / 1e12 / (PEAK_BF16_TFLOPS * emu), 4)
         res["projection"] = {
             "of_n_gpus": emu, "emulated_rank": 0, "ms_per_step_compute_side": round(wall / args.steps * 1e3, 2),
             "what": "ONE GPU ran what rank 0 of %d computes per step -- token-local kernels on L/%d rows, self-attention on H/%d heads over all "
@@ -871,7 +890,7 @@ def main():
                     "the RCCL exchanges would be.  `value` = L * steps / wall: the whole-job rate a %d-GPU run reaches if every rank takes "
                     "this long, i.e. its compute-side bound; exposed xGMI time comes on top.  No byte crossed a link; the output is not a "
                     "latent (parity skipped)." % (emu, emu, emu, emu)}
-    if rank == 0 and world == 1 and not force_sp and not emu and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
+    if rank == 0 and world == 1 and not force_sp and not emu and not cfg_scale and not args.no_e2e and args.workload in ("14b-cof", "14b-cof-33f") and not (args.fp8 or args.attn_stress or args.graph or args.graph_loop):
         try:        # the metric's second half (sec / video of a whole edit); separate from the timed region above, never takes it down
             res["e2e"] = e2e_edit(model, wl, dev)
         except Exception as e:
