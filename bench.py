@@ -35,6 +35,7 @@ Rank 0 prints ONE JSON line; it also carries
                    compare across boxes and rounds (the chips are power-limited here and differ by ~4 %);
   rank_wall_s   -- (N > 1) every rank's own wall clock of the timed region and max / min.
 `--force-sp` runs the whole sequence-parallel line over a 1-rank RCCL group (code path, not scaling).
+`--cfg S` runs every step with classifier-free guidance as WanPipeline does (one forward over [uncond, cond], B = 2; BASELINE configs[3]).
 `--emulate-sp P` (one GPU) runs what ONE rank of a P-way Ulysses group computes -- the shard shapes of every kernel, device-local
 copies where the exchanges would be (videocof_amd.dist.EmulatedRank) -- and prints a PROJECTION line: the compute-side bound of a
 P-GPU run, not a measurement of one (`projection` object; `parity` is skipped, the output is not a latent).
