@@ -639,6 +639,30 @@ def test_bench_sequence_parallel_line_over_rccl_with_one_rank():
     assert line["roofline"]["heads_local"] == 12 and "e2e" not in line
 
 
+def test_bench_cfg_and_emulated_rank_lines():
+    """`bench.py --cfg S` (a step with classifier-free guidance as WanPipeline runs it: one forward over [uncond, cond], B = 2 -- BASELINE
+    configs[3]'s per-step work) and `--emulate-sp P` (the PROJECTION line of one rank of P): the lines say what they are."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+
+    def line(*args):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "1.3b-small", "--layers", "3", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", *args], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = line(), line("--cfg", "5.0")
+    assert (one["config"]["global_batch"], one["config"]["guidance_scale"]) == (1, 1.0)
+    assert (two["config"]["global_batch"], two["config"]["guidance_scale"]) == (2, 5.0) and two["parity"]["ok"] is True
+    assert two["roofline"]["flop_per_launch"] == 2 * one["roofline"]["flop_per_launch"] and "e2e" not in two
+    emu = line("--emulate-sp", "4", "--cfg", "5.0")
+    assert emu["metric"].startswith("PROJECTION") and emu["projection"]["of_n_gpus"] == 4 and "skipped" in emu["parity"]
+    assert emu["config"]["parallelism"].startswith("EMULATED rank 0 of ulysses-sp4") and emu["roofline"]["heads_local"] == 3 and emu["n_gpus"] == 1
+    assert emu["tokens_per_s_per_gpu"] == round(emu["value"] / 4, 1) and emu["cpu_baseline"] is None
+
+
 def test_emulated_rank_runs_the_shard_shapes_and_degree_one_is_the_single_device():
     """`bench.py --emulate-sp P` (videocof_amd.dist.EmulatedRank): ONE rank's work of a P-way group with device-local copies for the
     exchanges.  With P = 1 the copies ARE the exchanges of a one-rank group, so the forward must equal the single-device one
