@@ -42,6 +42,27 @@ def test_dit_forward_random_inputs(ns):
     assert rel_l2(out, ref) < 1e-5
     ref_pad = m(lat[:1], t=t[:1], context=ctx[:1], seq_len=seq_len + 8)                  # padded sequence, plain T2V
     assert rel_l2(O.dit_forward(sd, cfg, lat[:1], t[:1], ctx[:1], seq_len + 8), ref_pad) < 1e-5
+    # the layouts tests/test_gpu_dit.py::test_forward_random_layouts_vs_oracle runs the HIP path on (same generator, same seed): odd
+    # grids, t2v / paired (a split without grounding frames) / CoF with one or more grounding frames, batch 1 / 2, prompt lengths
+    import random
+    rnd = random.Random(7)
+    for case in range(14):
+        F, Hl, Wl = rnd.randint(1, 9), 2 * rnd.randint(1, 7), 2 * rnd.randint(1, 9)
+        B = rnd.choice([1, 1, 2])
+        L = F * (Hl // 2) * (Wl // 2)
+        rnd.choice([0, 0, 1, 5, 64])                 # (the GPU test's seq_len padding draw: keeps the two streams in step)
+        mode = ("t2v", "paired", "cof", "cof")[case % 4] if F >= 3 else "t2v"
+        fsi = gfi = None
+        if mode != "t2v":
+            fs = rnd.randint(1, F - 2)
+            fsi = [fs] * B
+            if mode == "cof":
+                gfi = [(fs, fs + rnd.randint(1, F - 1 - fs))] * B
+        lat_c = torch.randn(B, 16, F, Hl, Wl, generator=g)
+        ctx_c = [torch.randn(rnd.randint(1, 77), 96, generator=g) for _ in range(B)]
+        t_c = torch.tensor([rnd.choice([999, 899, 749, 499, 37])] * B)
+        want = m(lat_c, t=t_c, context=ctx_c, seq_len=L, frame_split_indices=fsi, ground_frame_indices=gfi)
+        assert rel_l2(O.dit_forward(sd, cfg, lat_c, t_c, ctx_c, L, fsi, gfi), want) < 1e-5, (case, (B, F, Hl, Wl), mode, fsi, gfi)
 
 
 @torch.no_grad()
