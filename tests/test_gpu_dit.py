@@ -708,6 +708,37 @@ def test_unipc_12_step_trajectory_on_device(golden):
         assert rel_l2(cur.float(), g["traj"][11]) < tol
 
 
+def test_unipc_device_path_equals_host_path_over_configurations():
+    """The scheduler's CUDA path (one fused wan_lincomb per update) against its own torch path on CPU tensors -- which
+    tests/test_oracle_vs_reference.py pins to the reference over 648 configurations -- for every configuration whose trajectory is finite:
+    steps x shift x solver order x lower_order_final x disable_corrector x bh1 / bh2, fp32 latents."""
+    import itertools
+    g = torch.Generator().manual_seed(0)
+    compared = 0
+    for steps, shift, order, lof, dc, st in itertools.product([1, 2, 4, 7], [1.0, 3.0], [1, 2, 3], [True, False], [[], [0], [1, 2]], ["bh1", "bh2"]):
+        kw = dict(num_train_timesteps=1000, shift=1, solver_order=order, lower_order_final=lof, disable_corrector=dc, solver_type=st)
+        host, dev = FlowUniPCMultistepScheduler(**kw), FlowUniPCMultistepScheduler(**kw)
+        host.set_timesteps(steps, device="cpu", shift=shift)
+        dev.set_timesteps(steps, device=DEV, shift=shift)
+        a = torch.randn(1, 16, 2, 6, 6, generator=g)
+        b = a.to(DEV)
+        ok = True
+        for th, td in zip(host.timesteps, dev.timesteps):
+            v = torch.randn(1, 16, 2, 6, 6, generator=g)
+            try:
+                a = host.step(v, th, a, return_dict=False)[0]
+            except (ZeroDivisionError, np.linalg.LinAlgError):      # (degenerate at the final sigma = 0: the reference is not finite / solvable there either)
+                ok = False
+                break
+            if not torch.isfinite(a).all():
+                ok = False
+                break
+            b = dev.step(v.to(DEV), td, b, return_dict=False)[0]
+            assert rel_l2(b, a) < 1e-5, (steps, shift, order, lof, dc, st)
+        compared += ok
+    assert compared >= 60, compared
+
+
 def test_unipc_order_3_and_bh1_on_device(golden):
     """solver_order 3 / solver_type bh1 on CUDA tensors (updates of up to five terms: four go through the fused wan_lincomb, the
     five-term corrector through the fp32 torch chain) against the trajectories captured from the reference (fixture g7c)."""
